@@ -1,0 +1,80 @@
+"""ctypes binding of libcountr_hip.so (C ABI declared in include/countr_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcountr_hip.so")
+
+F32, BF16 = 0, 1
+OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
+ACT_NONE, ACT_GELU = 0, 1
+
+
+class CountrError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p),
+        ("bias", C.c_void_p), ("resid", C.c_void_p), ("partial", C.c_void_p),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldres", C.c_int64),
+        ("sA0", C.c_int64), ("sA1", C.c_int64), ("sB0", C.c_int64), ("sB1", C.c_int64),
+        ("sC0", C.c_int64), ("sC1", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("res_mod", C.c_int32), ("act", C.c_int32), ("out_bf16", C.c_int32),
+        ("nbatch", C.c_int32), ("nb1", C.c_int32), ("splitk", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("alpha", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises CountrError if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CountrError(
+                "libcountr_hip.so is not built (run `python -m countr_amd.build` or __graft_entry__.build()); "
+                "the HIP path has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    L.countr_last_error.restype = C.c_char_p
+    L.countr_init.argtypes = [i32]
+    L.countr_version.argtypes = []
+    L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
+    L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    for name, sig in _SIGS.items():
+        if hasattr(L, name):
+            getattr(L, name).argtypes = sig
+    for name in dir(L):
+        pass
+
+
+# argtypes of the remaining entry points are registered here by name (filled as kernels are added)
+_SIGS = {}
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().countr_last_error()
+        raise CountrError("%s failed (rc=%d): %s" % (what or "countr call", rc, msg.decode() if msg else ""))
+
+
+def exported_symbols():
+    """Names declared in include/countr_hip.h (parsed), used by the CPU-side ABI test."""
+    import re
+    hdr = os.path.join(_HERE, "..", "include", "countr_hip.h")
+    txt = open(hdr).read()
+    return sorted(set(re.findall(r"\b(countr_[a-z0-9_]+)\s*\(", txt)))

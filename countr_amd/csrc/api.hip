@@ -1,0 +1,47 @@
+// Library management + error plumbing of libcountr_hip.so (see include/countr_hip.h).
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+#include <string.h>
+#include <stdio.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+extern "C" void countr_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+int countr_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s: launch failed: %s", what, hipGetErrorString(e));
+    countr_set_error(buf);
+    return -10;
+  }
+  return 0;
+}
+
+extern "C" const char* countr_last_error(void) { return g_err; }
+extern "C" int countr_version(void) { return 1; }
+
+extern "C" int countr_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    countr_set_error("countr_init: no HIP device visible (the HIP path has no CPU fallback)");
+    return -1;
+  }
+  if (device < 0 || device >= n) { countr_set_error("countr_init: device index out of range"); return -1; }
+  if (hipSetDevice(device) != hipSuccess) { countr_set_error("countr_init: hipSetDevice failed"); return -1; }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) { countr_set_error("countr_init: cannot query device"); return -1; }
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "countr_init: device arch %s is not gfx950 (kernels are built for MI355X only)", p.gcnArchName);
+    countr_set_error(buf);
+    return -2;
+  }
+  return 0;
+}

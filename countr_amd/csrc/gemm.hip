@@ -1,0 +1,452 @@
+// Generic MFMA GEMM for gfx950 (MI355X): one 128x128 block tile, 4 waves (2x2) of 64x64, register-
+// staged double-buffered LDS, one barrier per K tile.  Operands are addressed through four modes
+// (row / col / 3x3-im2col-row / 3x3-im2col-col) so that nn.Linear forward, dgrad and wgrad, the
+// unfused attention products and the 3x3 convolutions (fwd, dgrad, wgrad) all run on this kernel.
+//   bf16: v_mfma_f32_16x16x32_bf16, K-strided operands read with ds_read_b64_tr_b16
+//   fp32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain) for the parity mode
+// Reference call sites: models_crossvit.py:62,65,84-92,115-127; models_mae_cross.py:47-100,138,152.
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int ROW_PITCH = 144;      // 128 B of K + 16 B pad
+constexpr int OP_BYTES = 18432;     // per operand per stage (max over layouts)
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> {
+  static constexpr int EPC = 8;     // elements per 16-byte chunk
+  static constexpr int BK = 64;
+  static constexpr int COL_PITCH = 272;  // 128 rows * 2 B + 16
+};
+template <> struct Cfg<float> {
+  static constexpr int EPC = 4;
+  static constexpr int BK = 32;
+  static constexpr int COL_PITCH = 528;  // 128 rows * 4 B + 16
+};
+
+struct OpDesc {
+  const char* ptr;
+  int64_t ld;   // elements
+  int rows;     // valid rows of this operand (M or N)
+  int H, W, C;  // conv geometry
+};
+
+// ---------------------------------------------------------------------------------------------
+// Global -> register -> LDS staging, one specialisation per addressing mode.
+// Each thread owns 4 chunks (16 B) of the 128 x BK operand tile.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE> struct Loader;
+
+template <typename T> struct Loader<T, COUNTR_OP_ROW> {
+  static constexpr int EPC = Cfg<T>::EPC;
+  const char* rp[4];
+  int kc;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    kc = (tid & 7) * EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row0 + (tid >> 3) + 32 * i;
+      rp[i] = (r < d.rows) ? d.ptr + (int64_t)r * d.ld * sizeof(T) : nullptr;
+    }
+  }
+  __device__ void load(int k0, int kend, uint4 (&v)[4]) {
+    const int k = k0 + kc;
+    const bool kok = (k + EPC) <= kend;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (kok && rp[i]) v[i] = *reinterpret_cast<const uint4*>(rp[i] + (int64_t)k * sizeof(T));
+    }
+  }
+  __device__ void store(char* lds, int tid, const uint4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(lds + ((tid >> 3) + 32 * i) * ROW_PITCH + (tid & 7) * 16) = v[i];
+  }
+};
+
+template <typename T> struct Loader<T, COUNTR_OP_COL> {
+  static constexpr int EPC = Cfg<T>::EPC;
+  static constexpr int CPR = 128 / EPC;       // chunks per k-row
+  static constexpr int KSTEP = 256 / CPR;     // k-rows covered per pass
+  const char* base;
+  int64_t ldb;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    const int r0 = row0 + (tid % CPR) * EPC;
+    base = (r0 + EPC <= d.rows) ? d.ptr + (int64_t)r0 * sizeof(T) : nullptr;
+    ldb = d.ld * (int64_t)sizeof(T);
+  }
+  __device__ void load(int k0, int kend, uint4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + (threadIdx.x / CPR) + KSTEP * i;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (base && k < kend) v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)k * ldb);
+    }
+  }
+  __device__ void store(char* lds, int tid, const uint4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(lds + ((tid / CPR) + KSTEP * i) * Cfg<T>::COL_PITCH + (tid % CPR) * 16) = v[i];
+  }
+};
+
+// rows = pixels (b,y,x) of an NHWC map, k = tap*C + c, 3x3 window, zero padding 1.
+template <typename T> struct Loader<T, COUNTR_OP_IM2ROW> {
+  static constexpr int EPC = Cfg<T>::EPC;
+  const char* ptr;
+  int pix[4], py[4], px[4];  // linear pixel, y, x ; pix = -1 when the row is out of range
+  int H, W, C, kc;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    ptr = d.ptr; H = d.H; W = d.W; C = d.C;
+    kc = (tid & 7) * EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = row0 + (tid >> 3) + 32 * i;
+      pix[i] = (m < d.rows) ? m : -1;
+      px[i] = m % W;
+      py[i] = (m / W) % H;
+    }
+  }
+  __device__ void load(int k0, int kend, uint4 (&v)[4]) {
+    const int tap = k0 / C;                 // wave-uniform: BK divides C
+    const int ci = k0 - tap * C + kc;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const bool kok = (k0 + kc + EPC) <= kend;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = make_uint4(0, 0, 0, 0);
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      if (kok && pix[i] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v[i] = *reinterpret_cast<const uint4*>(
+            ptr + ((int64_t)(pix[i] + dy * W + dx) * C + ci) * sizeof(T));
+    }
+  }
+  __device__ void store(char* lds, int tid, const uint4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(lds + ((tid >> 3) + 32 * i) * ROW_PITCH + (tid & 7) * 16) = v[i];
+  }
+};
+
+// rows = tap*C + c, k = pixel (b,y,x): the wgrad view of the same gather.
+template <typename T> struct Loader<T, COUNTR_OP_IM2COL> {
+  static constexpr int EPC = Cfg<T>::EPC;
+  static constexpr int CPR = 128 / EPC;
+  static constexpr int KSTEP = 256 / CPR;
+  static constexpr int BK = Cfg<T>::BK;
+  const char* ptr;
+  int py[4], px[4];
+  int H, W, C, ci, dy, dx;
+  bool colok;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    ptr = d.ptr; H = d.H; W = d.W; C = d.C;
+    const int r0 = row0 + (tid % CPR) * EPC;
+    colok = (r0 + EPC) <= d.rows;
+    const int tap = r0 / C;
+    ci = r0 - tap * C;
+    dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = kstart + (tid / CPR) + KSTEP * i;
+      px[i] = p % W;
+      py[i] = (p / W) % H;
+    }
+  }
+  __device__ void load(int k0, int kend, uint4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = k0 + (threadIdx.x / CPR) + KSTEP * i;
+      v[i] = make_uint4(0, 0, 0, 0);
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      if (colok && p < kend && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v[i] = *reinterpret_cast<const uint4*>(ptr + ((int64_t)(p + dy * W + dx) * C + ci) * sizeof(T));
+      // advance this chunk's pixel by one K tile
+      px[i] += BK;
+      while (px[i] >= W) { px[i] -= W; py[i] = (py[i] + 1 == H) ? 0 : py[i] + 1; }
+    }
+  }
+  __device__ void store(char* lds, int tid, const uint4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(lds + ((tid / CPR) + KSTEP * i) * Cfg<T>::COL_PITCH + (tid % CPR) * 16) = v[i];
+  }
+};
+
+constexpr bool is_rowlike(int mode) { return mode == COUNTR_OP_ROW || mode == COUNTR_OP_IM2ROW; }
+
+// ---------------------------------------------------------------------------------------------
+// LDS -> MFMA fragments.  `row` is the tile-local row this lane contributes (already including the
+// N-side permutation), `row4` the first of the 4 consecutive rows this lane addresses for a
+// transpose read.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row, int row4, int kk, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  if constexpr (is_rowlike(MODE)) {
+    return *reinterpret_cast<const bf16x8_t*>(lds + row * ROW_PITCH + (kk * 32 + g * 8) * 2);
+  } else {
+    // K-major image [k][row]: two hardware-transposing reads of a [4 k][16 rows] block each.
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    const char* p0 = lds + (kk * 32 + g * 8 + (i >> 2)) * Cfg<bf16_t>::COL_PITCH + row4 * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p0 + 4 * Cfg<bf16_t>::COL_PITCH));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, r);
+  }
+}
+
+// fp32: 4 consecutive MFMA k-steps' operands; lane (i, g) holds k = c16*16 + 4*g + s, s = 0..3.
+template <int MODE>
+__device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, int lane) {
+  const int g = lane >> 4;
+  if constexpr (is_rowlike(MODE)) {
+    return *reinterpret_cast<const float4*>(lds + row * ROW_PITCH + (c16 * 16 + g * 4) * 4);
+  } else {
+    const char* p = lds + (c16 * 16 + g * 4) * Cfg<float>::COL_PITCH + row * 4;
+    float4 r;
+    r.x = *reinterpret_cast<const float*>(p);
+    r.y = *reinterpret_cast<const float*>(p + Cfg<float>::COL_PITCH);
+    r.z = *reinterpret_cast<const float*>(p + 2 * Cfg<float>::COL_PITCH);
+    r.w = *reinterpret_cast<const float*>(p + 3 * Cfg<float>::COL_PITCH);
+    return r;
+  }
+}
+
+template <typename T, int MA, int MB>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g) {
+  constexpr int BK = Cfg<T>::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // stage s: A tile at smem + 2*s*OP_BYTES, B tile right behind it
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tilesN = (g.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tilesN, tile_n = blockIdx.x - tile_m * tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // batch / split-K decode
+  int kstart = 0, kend = g.K;
+  int64_t offA = 0, offB = 0, offC = 0;
+  const int z = blockIdx.z;
+  if (g.splitk > 1) {
+    const int tiles = (g.K + BK - 1) / BK;
+    const int per = (tiles + g.splitk - 1) / g.splitk;
+    kstart = z * per * BK;
+    kend = min(g.K, kstart + per * BK);
+  } else if (g.nbatch > 1) {
+    const int b0 = z / g.nb1, b1 = z - b0 * g.nb1;
+    offA = b0 * g.sA0 + b1 * g.sA1;
+    offB = b0 * g.sB0 + b1 * g.sB1;
+    offC = b0 * g.sC0 + b1 * g.sC1;
+  }
+
+  OpDesc dA{reinterpret_cast<const char*>(g.A) + offA * (int64_t)sizeof(T), g.lda, g.M, g.H, g.W, g.Cin};
+  OpDesc dB{reinterpret_cast<const char*>(g.B) + offB * (int64_t)sizeof(T), g.ldb, g.N, g.H, g.W, g.Cin};
+  Loader<T, MA> la;
+  Loader<T, MB> lb;
+  la.init(dA, m0, kstart, tid);
+  lb.init(dB, n0, kstart, tid);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int li = lane & 15;
+  // N-side row permutation: MFMA output row i of tile tn is column wn0 + (i>>2)*16 + tn*4 + (i&3),
+  // so that a lane ends up holding 16 consecutive output columns (vector stores in the epilogue).
+  const int nrow_base = wn0 + (li >> 2) * 16 + (li & 3);
+  const int nrow4_base = wn0 + (li & 3) * 16;
+
+  uint4 va[4], vb[4];
+  const int ntiles = (kend > kstart) ? (kend - kstart + BK - 1) / BK : 0;
+  if (ntiles > 0) {
+    la.load(kstart, kend, va);
+    lb.load(kstart, kend, vb);
+    la.store(smem, tid, va);
+    lb.store(smem + OP_BYTES, tid, vb);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1) < ntiles;
+    if (more) {
+      la.load(kstart + (t + 1) * BK, kend, va);
+      lb.load(kstart + (t + 1) * BK, kend, vb);
+    }
+    const char* sa = smem + cur * 2 * OP_BYTES;
+    const char* sb = sa + OP_BYTES;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t xf[4], wf[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          xf[tm] = frag_bf16<MA>(sa, wm0 + tm * 16 + li, wm0 + tm * 16 + (li & 3) * 4, kk, lane);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          wf[tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c16 = 0; c16 < 2; ++c16) {
+        float4 xf[4], wf[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) xf[tm] = frag_f32<MA>(sa, wm0 + tm * 16 + li, c16, lane);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) wf[tn] = frag_f32<MB>(sb, nrow_base + tn * 4, c16, lane);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn].x, xf[tm].x, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn].y, xf[tm].y, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn].z, xf[tm].z, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn].w, xf[tm].w, acc[tm][tn], 0, 0, 0);
+          }
+      }
+    }
+    if (more) {
+      la.store(smem + (cur ^ 1) * 2 * OP_BYTES, tid, va);
+      lb.store(smem + (cur ^ 1) * 2 * OP_BYTES + OP_BYTES, tid, vb);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: lane (j = lane&15, gq = lane>>4) owns, per tm, row m and the 16
+  // consecutive columns nb .. nb+15 (acc[tm][tn][reg] -> column nb + tn*4 + reg).
+  const int gq = lane >> 4;
+  const int nb = n0 + wn0 + gq * 16;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm0 + tm * 16 + li;
+    if (m >= g.M) continue;
+    if (g.splitk > 1) {
+      float* dst = g.partial + ((int64_t)z * g.M + m) * g.N + nb;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        if (nb + tn * 4 < g.N) {
+          const float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+          st4<float>(dst + tn * 4, v);
+        }
+      }
+      continue;
+    }
+    const int64_t crow = offC + (int64_t)m * g.ldc;
+    const float* rrow = nullptr;
+    if (g.resid) rrow = g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = nb + tn * 4;
+      if (n >= g.N) continue;
+      float v[4] = {acc[tm][tn][0] * g.alpha, acc[tm][tn][1] * g.alpha, acc[tm][tn][2] * g.alpha,
+                    acc[tm][tn][3] * g.alpha};
+      if (g.bias) {
+        float b[4];
+        ld4<float>(g.bias + n, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+      }
+      if (g.C2) {
+        if (g.out_bf16) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C2) + crow + n, v);
+        else st4<float>(reinterpret_cast<float*>(g.C2) + crow + n, v);
+      }
+      if (g.act == COUNTR_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (rrow) {
+        float r[4];
+        ld4<float>(rrow + n, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      if (g.out_bf16) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + crow + n, v);
+      else st4<float>(reinterpret_cast<float*>(g.C) + crow + n, v);
+    }
+  }
+}
+
+template <typename T, int MA, int MB>
+int launch(const countr_gemm_args& a, hipStream_t s) {
+  const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+  const int zdim = a.splitk > 1 ? a.splitk : (a.nbatch > 1 ? a.nbatch : 1);
+  dim3 grid(tilesM * tilesN, 1, zdim);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * OP_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB>), grid, dim3(NTHREADS), 4 * OP_BYTES, s, a);
+  COUNTR_LAUNCH_CHECK("countr_gemm");
+}
+
+template <typename T>
+int dispatch(const countr_gemm_args& a, int ma, int mb, hipStream_t s) {
+  if (ma == COUNTR_OP_ROW && mb == COUNTR_OP_ROW) return launch<T, COUNTR_OP_ROW, COUNTR_OP_ROW>(a, s);
+  if (ma == COUNTR_OP_ROW && mb == COUNTR_OP_COL) return launch<T, COUNTR_OP_ROW, COUNTR_OP_COL>(a, s);
+  if (ma == COUNTR_OP_COL && mb == COUNTR_OP_COL) return launch<T, COUNTR_OP_COL, COUNTR_OP_COL>(a, s);
+  if (ma == COUNTR_OP_COL && mb == COUNTR_OP_ROW) return launch<T, COUNTR_OP_COL, COUNTR_OP_ROW>(a, s);
+  if (ma == COUNTR_OP_IM2ROW && mb == COUNTR_OP_ROW) return launch<T, COUNTR_OP_IM2ROW, COUNTR_OP_ROW>(a, s);
+  if (ma == COUNTR_OP_COL && mb == COUNTR_OP_IM2COL) return launch<T, COUNTR_OP_COL, COUNTR_OP_IM2COL>(a, s);
+  countr_set_error("countr_gemm: unsupported operand mode combination");
+  return -2;
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int splitk,
+                                     int64_t MN, int N, int taps, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int z = 0; z < splitk; ++z) s += partial[(int64_t)z * MN + i];
+  int64_t o = i;
+  if (taps > 0) {  // [co][tap][ci] -> [co][ci][tap]
+    const int cin = N / taps;
+    const int64_t co = i / N;
+    const int r = (int)(i - co * N);
+    const int tap = r / cin, ci = r - tap * cin;
+    o = co * N + (int64_t)ci * taps + tap;
+  }
+  out[o] = accumulate ? out[o] + s : s;
+}
+
+}  // namespace
+
+extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
+  if (!a || !a->A || !a->B || (!a->C && a->splitk <= 1)) { countr_set_error("countr_gemm: null pointer"); return -1; }
+  if (a->splitk > 1 && (!a->partial || a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
+  const int epc = dtype == COUNTR_BF16 ? 8 : 4;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->N & 3)) { countr_set_error("countr_gemm: bad shape (need N % 4 == 0)"); return -1; }
+  if ((modeA == COUNTR_OP_ROW || modeB == COUNTR_OP_ROW) && (a->K % epc)) { countr_set_error("countr_gemm: K must be a multiple of the 16-byte chunk"); return -1; }
+  if (modeA == COUNTR_OP_COL && (a->M % epc)) { countr_set_error("countr_gemm: M must be a multiple of the chunk for COL A"); return -1; }
+  if (modeB == COUNTR_OP_COL && (a->N % epc)) { countr_set_error("countr_gemm: N must be a multiple of the chunk for COL B"); return -1; }
+  if ((modeA == COUNTR_OP_IM2ROW || modeB == COUNTR_OP_IM2COL) && (a->Cin % 64 || a->H <= 0 || a->W <= 0)) { countr_set_error("countr_gemm: conv modes need Cin % 64 == 0"); return -1; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COUNTR_BF16) return dispatch<bf16_t>(*a, modeA, modeB, s);
+  if (dtype == COUNTR_F32) return dispatch<float>(*a, modeA, modeB, s);
+  countr_set_error("countr_gemm: bad dtype");
+  return -1;
+}
+
+extern "C" int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, int N, int perm_taps,
+                                    int accumulate, void* stream) {
+  if (!partial || !out || splitk < 1) { countr_set_error("countr_splitk_reduce: bad args"); return -1; }
+  const int64_t MN = (int64_t)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), partial, out, splitk, MN, N, perm_taps, accumulate);
+  COUNTR_LAUNCH_CHECK("countr_splitk_reduce");
+}

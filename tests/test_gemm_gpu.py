@@ -1,0 +1,175 @@
+"""GPU parity of the generic MFMA GEMM (countr_gemm) against torch fp64 matmul on the same inputs.
+
+Covers every operand-mode combination, both dtypes, ragged M/N/K, batching, split-K and the
+epilogue (bias, GELU, residual with row modulo, second output).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from countr_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _mk(shape, dtype, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1)
+    return x.to("cuda").to(dtype)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ma,mb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (576, 768, 768), (200, 144, 96), (64, 2304, 32), (1152, 576, 64)])
+def test_gemm_modes(hip, dt, ma, mb, M, N, K):
+    # logical A[M,K], B[N,K]; stored transposed for COL mode
+    A = _mk((M, K), dt, 1)
+    B = _mk((N, K), dt, 2)
+    As = A if ma == 0 else A.t().contiguous()
+    Bs = B if mb == 0 else B.t().contiguous()
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C = As.data_ptr(), Bs.data_ptr(), out.data_ptr()
+    a.lda = K if ma == 0 else M
+    a.ldb = K if mb == 0 else N
+    a.ldc = N
+    a.M, a.N, a.K = M, N, K
+    a.alpha = 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    _lib.check(hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, ma, mb, _stream()), "gemm")
+    torch.cuda.synchronize()
+    ref = (A.double() @ B.double().t())
+    # operands are exactly representable in both dtypes -> only fp32 accumulation-order error
+    err = (out.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 1e-4 * scale + 1e-5, (err, scale)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue(hip, dt):
+    M, N, K = 1152, 256, 128
+    A = _mk((M, K), dt, 3)
+    B = _mk((N, K), dt, 4)
+    bias = _mk((N,), torch.float32, 5)
+    resid = _mk((576, N), torch.float32, 6)
+    for out_bf16 in (0, 1):
+        odt = torch.bfloat16 if out_bf16 else torch.float32
+        out = torch.empty((M, N), device="cuda", dtype=odt)
+        pre = torch.empty((M, N), device="cuda", dtype=odt)
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C, a.C2 = A.data_ptr(), B.data_ptr(), out.data_ptr(), pre.data_ptr()
+        a.bias, a.resid = bias.data_ptr(), resid.data_ptr()
+        a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
+        a.M, a.N, a.K = M, N, K
+        a.res_mod = 576
+        a.act = 1
+        a.out_bf16 = out_bf16
+        a.alpha = 0.5
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        _lib.check(hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 0, 0, _stream()), "gemm")
+        torch.cuda.synchronize()
+        z = 0.5 * (A.double() @ B.double().t()) + bias.double()
+        ref = torch.nn.functional.gelu(z) + resid.double().repeat(2, 1)
+        tol = 2e-2 if out_bf16 else 1e-4
+        assert (pre.double() - z).abs().max().item() <= tol * z.abs().max().item()
+        assert (out.double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_batched_and_splitk(hip, dt):
+    # batched: q k^T per (b, h) read straight out of a packed qkv [B, N, 3, H, dh]
+    Bsz, Ntok, H, dh = 2, 576, 3, 64
+    qkv = _mk((Bsz, Ntok, 3, H, dh), dt, 7)
+    scores = torch.empty((Bsz, H, Ntok, Ntok), device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A = qkv.data_ptr()
+    a.B = qkv.data_ptr() + H * dh * qkv.element_size()
+    a.C = scores.data_ptr()
+    a.lda = a.ldb = 3 * H * dh
+    a.ldc = Ntok
+    a.M = a.N = Ntok
+    a.K = dh
+    a.nbatch = Bsz * H; a.nb1 = H; a.splitk = 1
+    a.sA0 = a.sB0 = Ntok * 3 * H * dh
+    a.sA1 = a.sB1 = dh
+    a.sC0 = H * Ntok * Ntok
+    a.sC1 = Ntok * Ntok
+    a.alpha = dh ** -0.5
+    _lib.check(hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 0, 0, _stream()), "gemm")
+    q = qkv[:, :, 0].permute(0, 2, 1, 3).double()
+    k = qkv[:, :, 1].permute(0, 2, 1, 3).double()
+    ref = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    torch.cuda.synchronize()
+    assert (scores.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5
+
+    # split-K wgrad-style: dW[N,K] = dY[M,N]^T X[M,K]
+    M, N, K = 4608, 256, 384
+    dY = _mk((M, N), dt, 8)
+    X = _mk((M, K), dt, 9)
+    splitk = 4
+    part = torch.empty((splitk, N, K), device="cuda", dtype=torch.float32)
+    dW = torch.full((N, K), 1.0, device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.partial = dY.data_ptr(), X.data_ptr(), part.data_ptr()
+    a.lda, a.ldb, a.ldc = N, K, K
+    a.M, a.N, a.K = N, K, M
+    a.nbatch = 1; a.nb1 = 1; a.splitk = splitk
+    a.alpha = 1.0
+    _lib.check(hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 1, 1, _stream()), "gemm")
+    _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dW.data_ptr(), splitk, N, K, 0, 1, _stream()), "reduce")
+    torch.cuda.synchronize()
+    ref = dY.double().t() @ X.double() + 1.0
+    assert (dW.double() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout", [(2, 24, 24, 128, 256), (1, 12, 20, 64, 128), (3, 8, 8, 256, 512)])
+def test_conv3x3_implicit_gemm(hip, dt, Bsz, H, W, Cin, Cout):
+    x = _mk((Bsz, Cin, H, W), dt, 10)            # logical NCHW
+    w = _mk((Cout, Cin, 3, 3), dt, 11) * 0.1
+    w = w.to(dt)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous()   # [Cout][tap][Cin]
+    bias = _mk((Cout,), torch.float32, 12)
+    M = Bsz * H * W
+    out = torch.empty((M, Cout), device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C, a.bias = x_nhwc.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), bias.data_ptr()
+    a.ldb, a.ldc = 9 * Cin, Cout
+    a.M, a.N, a.K = M, Cout, 9 * Cin
+    a.H, a.W, a.Cin = H, W, Cin
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    a.alpha = 1.0
+    code = 0 if dt == torch.float32 else 1
+    _lib.check(hip.countr_gemm(C.byref(a), code, 2, 0, _stream()), "conv fwd")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert (out.double() - ref_nhwc).abs().max().item() <= 2e-4 * ref_nhwc.abs().max().item()
+
+    # wgrad: dW[co][tap][ci] = sum_p dY[p][co] * X[p+off][ci]   (split-K, then permute to OIHW)
+    dy = _mk((M, Cout), dt, 13)
+    splitk = 3
+    part = torch.empty((splitk, Cout, 9 * Cin), device="cuda", dtype=torch.float32)
+    dw = torch.zeros((Cout, Cin, 3, 3), device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.partial = dy.data_ptr(), x_nhwc.data_ptr(), part.data_ptr()
+    a.lda, a.ldc = Cout, 9 * Cin
+    a.M, a.N, a.K = Cout, 9 * Cin, M
+    a.H, a.W, a.Cin = H, W, Cin
+    a.nbatch = 1; a.nb1 = 1; a.splitk = splitk
+    a.alpha = 1.0
+    _lib.check(hip.countr_gemm(C.byref(a), code, 1, 3, _stream()), "conv wgrad")
+    _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dw.data_ptr(), splitk, Cout, 9 * Cin, 9, 0, _stream()), "reduce")
+    torch.cuda.synchronize()
+    xd = x.double().requires_grad_(False)
+    wd = w.double().clone().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xd, wd, None, padding=1)
+    gy = dy.double().reshape(Bsz, H, W, Cout).permute(0, 3, 1, 2)
+    (gw,) = torch.autograd.grad(y, wd, gy)
+    assert (dw.double() - gw).abs().max().item() <= 2e-4 * gw.abs().max().item()
