@@ -1,0 +1,155 @@
+"""Deterministic synthetic weights for the CounTR SupervisedMAE (test infrastructure).
+
+No checkpoint or dataset is available offline, so parity is pinned on generated weights: each
+tensor is drawn from its own numpy RandomState seeded by crc32(name) ^ seed, scaled like the
+reference initialisation (models_mae_cross.py:108-134; torch defaults for Conv2d/GroupNorm) but with
+non-zero biases and perturbed norm gains so that every parameter influences the output.
+State-dict keys/shapes follow the reference schema.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+CONFIGS = {
+    # name: (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads)   models_mae_cross.py:210-253
+    "mae_vit_base_patch16": (16, 768, 12, 12, 512, 2, 16),
+    "mae_vit_base4_patch16": (16, 768, 12, 12, 512, 4, 16),
+    "mae_vit_base6_patch16": (16, 768, 12, 12, 512, 6, 16),
+    "mae_vit_large_patch16": (16, 1024, 24, 16, 512, 2, 16),
+    "mae_vit_huge_patch14": (14, 1280, 32, 16, 512, 2, 16),
+    # reduced-depth configuration used for fast CPU tests (not a reference factory)
+    "tiny_test": (16, 768, 2, 12, 512, 1, 16),
+}
+
+
+def sincos_1d(dim, pos):
+    """util/pos_embed.py:49-67 (float64 table)."""
+    omega = np.arange(dim // 2, dtype=np.float64) / (dim / 2.0)
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1).astype(np.float64), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_2d(dim, grid):
+    """util/pos_embed.py:20-46: first half encodes the column (w) index, second half the row."""
+    gh = np.arange(grid, dtype=np.float32)
+    gw = np.arange(grid, dtype=np.float32)
+    g = np.stack(np.meshgrid(gw, gh), axis=0).reshape(2, 1, grid, grid)  # g[0] = w index
+    return np.concatenate([sincos_1d(dim // 2, g[0]), sincos_1d(dim // 2, g[1])], axis=1)
+
+
+def schema(model="mae_vit_base_patch16", img_size=384):
+    """Ordered (name, shape, kind) list in the reference's state_dict order."""
+    p, D, depth, H, Dd, ddepth, Hd = CONFIGS[model]
+    grid = img_size // p
+    N = grid * grid
+    S = []
+    S.append(("pos_embed", (1, N, D), "pos"))
+    S.append(("decoder_pos_embed", (1, N, Dd), "pos"))
+    S.append(("shot_token", (512,), "token"))
+    S.append(("patch_embed.proj.weight", (D, 3, p, p), "patch_w"))
+    S.append(("patch_embed.proj.bias", (D,), "bias"))
+
+    def lin(prefix, out_f, in_f):
+        S.append((prefix + ".weight", (out_f, in_f), "linear_w"))
+        S.append((prefix + ".bias", (out_f,), "bias"))
+
+    def norm(prefix, d):
+        S.append((prefix + ".weight", (d,), "norm_w"))
+        S.append((prefix + ".bias", (d,), "norm_b"))
+
+    def conv(prefix, co, ci, k):
+        S.append((prefix + ".weight", (co, ci, k, k), "conv_w"))
+        S.append((prefix + ".bias", (co,), "conv_b:%d" % (ci * k * k)))
+
+    for i in range(depth):
+        b = "blocks.%d" % i
+        norm(b + ".norm1", D)
+        lin(b + ".attn.qkv", 3 * D, D)
+        lin(b + ".attn.proj", D, D)
+        norm(b + ".norm2", D)
+        lin(b + ".mlp.fc1", 4 * D, D)
+        lin(b + ".mlp.fc2", D, 4 * D)
+    norm("norm", D)
+    lin("decoder_embed", Dd, D)
+    conv("decoder_proj1.0", 64, 3, 3)
+    conv("decoder_proj2.0", 128, 64, 3)
+    conv("decoder_proj3.0", 256, 128, 3)
+    conv("decoder_proj4.0", Dd, 256, 3)
+    for i in range(ddepth):
+        b = "decoder_blocks.%d" % i
+        norm(b + ".norm0", Dd)
+        lin(b + ".selfattn.qkv", 3 * Dd, Dd)
+        lin(b + ".selfattn.proj", Dd, Dd)
+        norm(b + ".norm1", Dd)
+        lin(b + ".attn.wq", Dd, Dd)
+        lin(b + ".attn.wk", Dd, Dd)
+        lin(b + ".attn.wv", Dd, Dd)
+        lin(b + ".attn.proj", Dd, Dd)
+        norm(b + ".norm2", Dd)
+        lin(b + ".mlp.fc1", 4 * Dd, Dd)
+        lin(b + ".mlp.fc2", Dd, 4 * Dd)
+    norm("decoder_norm", Dd)
+    conv("decode_head0.0", 256, Dd, 3)
+    norm("decode_head0.1", 256)
+    conv("decode_head1.0", 256, 256, 3)
+    norm("decode_head1.1", 256)
+    conv("decode_head2.0", 256, 256, 3)
+    norm("decode_head2.1", 256)
+    conv("decode_head3.0", 256, 256, 3)
+    norm("decode_head3.1", 256)
+    conv("decode_head3.3", 1, 256, 1)
+    return S
+
+
+def make_state_dict(model="mae_vit_base_patch16", seed=0, img_size=384):
+    """OrderedDict name -> float32 numpy array."""
+    p = CONFIGS[model][0]
+    grid = img_size // p
+    sd = OrderedDict()
+    for name, shape, kind in schema(model, img_size):
+        rs = np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        if kind == "pos":
+            a = sincos_2d(shape[-1], grid)[None]
+        elif kind == "token":
+            a = rs.normal(0.0, 0.02, size=shape)
+        elif kind in ("linear_w", "patch_w"):
+            fan_out = shape[0]
+            fan_in = int(np.prod(shape[1:]))
+            bound = np.sqrt(6.0 / (fan_in + fan_out))  # xavier uniform (models_mae_cross.py:118-119,129)
+            a = rs.uniform(-bound, bound, size=shape)
+        elif kind == "bias":
+            a = rs.uniform(-0.02, 0.02, size=shape)
+        elif kind == "norm_w":
+            a = 1.0 + rs.uniform(-0.1, 0.1, size=shape)
+        elif kind == "norm_b":
+            a = rs.uniform(-0.05, 0.05, size=shape)
+        elif kind == "conv_w":
+            fan_in = int(np.prod(shape[1:]))
+            bound = 1.0 / np.sqrt(fan_in)  # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+            a = rs.uniform(-bound, bound, size=shape)
+        elif kind.startswith("conv_b"):
+            bound = 1.0 / np.sqrt(int(kind.split(":")[1]))
+            a = rs.uniform(-bound, bound, size=shape)
+        else:
+            raise ValueError(kind)
+        sd[name] = np.ascontiguousarray(a, dtype=np.float32)
+    return sd
+
+
+def make_inputs(batch, shots=3, seed=0, img_size=384):
+    """Synthetic inputs of SURVEY.md section 8d: imgs, boxes ~ U[0,1); gaussian-dot density x60; loss mask."""
+    rs = np.random.RandomState(1000 + seed)
+    imgs = rs.uniform(0, 1, size=(batch, 3, img_size, img_size)).astype(np.float32)
+    boxes = rs.uniform(0, 1, size=(batch, shots, 3, 64, 64)).astype(np.float32)
+    gt = np.zeros((batch, img_size, img_size), dtype=np.float32)
+    from scipy.ndimage import gaussian_filter
+    for b in range(batch):
+        k = rs.randint(5, 201)
+        ys = rs.randint(0, img_size, size=k)
+        xs = rs.randint(0, img_size, size=k)
+        np.add.at(gt[b], (ys, xs), 1.0)
+        gt[b] = gaussian_filter(gt[b], sigma=(1, 1), order=0) * 60.0  # util/FSC147.py:275-278
+    mask = rs.binomial(1, 0.8, size=(img_size, img_size)).astype(np.float32)  # FSC_finetune_cross.py:290
+    return imgs, boxes, gt, mask
