@@ -56,14 +56,41 @@ def _declare(L):
     L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
     L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     for name, sig in _SIGS.items():
-        if hasattr(L, name):
-            getattr(L, name).argtypes = sig
-    for name in dir(L):
-        pass
+        fn = getattr(L, name)  # AttributeError here means the .so is stale: rebuild
+        fn.argtypes = sig
+        fn.restype = _RESTYPES.get(name, C.c_int)
 
 
-# argtypes of the remaining entry points are registered here by name (filled as kernels are added)
-_SIGS = {}
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "countr_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "countr_layernorm_bwd_nblocks": [],
+    "countr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "countr_colsum_partials": [_vp, _vp, _i, _i, _i, _vp],
+    "countr_groupnorm_nsplit": [_i],
+    "countr_groupnorm_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_groupnorm_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "countr_instnorm_relu_pool_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_instnorm_relu_pool_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "countr_softmax_fwd": [_vp, _vp, _i64, _i, _i, _vp],
+    "countr_softmax_bwd": [_vp, _vp, _vp, _i64, _i, _f, _i, _vp],
+    "countr_xattn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_xattn_bwd_workspace_floats": [_i, _i, _i, _i],
+    "countr_xattn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_im2patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "countr_conv3x3_c3_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "countr_conv3x3_c3_wgrad_nblocks": [],
+    "countr_conv3x3_c3_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "countr_upsample2x_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "countr_upsample2x_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "countr_gelu_bwd": [_vp, _vp, _vp, _i64, _i, _vp],
+    "countr_colsum_nparts": [],
+    "countr_colsum": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "countr_cast_permute": [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "countr_masked_mse": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "countr_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp, _vp],
+}
+_RESTYPES = {"countr_xattn_bwd_workspace_floats": C.c_int64}
 
 
 def check(rc, what=""):

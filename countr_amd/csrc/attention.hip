@@ -1,0 +1,265 @@
+// Attention pieces (reference: models_crossvit.py:69-128).
+//   softmax rows fwd/bwd  : the unfused self-attention path (scores via countr_gemm), fp32 statistics
+//   cross attention       : q [B*N, D] against S <= 8 exemplar tokens; one wave per query row
+//   (the fused flash-style self-attention forward lives in flash_attn.hip)
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+
+namespace {
+
+constexpr int SMAX_PER_LANE = 16;  // row length <= 1024
+
+// P = softmax(S) row-wise; S fp32 (already scaled), P stored as TO.  One wave per row.
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, TO* __restrict__ p, int64_t rows, int n) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + row * n;
+  float v[SMAX_PER_LANE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SMAX_PER_LANE; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = (c < n) ? sr[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < SMAX_PER_LANE; ++i) {
+    v[i] = (i * 64 + lane < n) ? __expf(v[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  const float inv = 1.f / wave_sum(sum);
+  TO* pr = p + row * n;
+#pragma unroll
+  for (int i = 0; i < SMAX_PER_LANE; ++i) {
+    const int c = i * 64 + lane;
+    if (c < n) stf<TO>(pr + c, v[i] * inv);
+  }
+}
+
+// dS = P * (dP - sum(dP * P)) * scale ; P is T, dP fp32 (from the dO V^T GEMM), dS stored as T.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, const float* __restrict__ dp, T* __restrict__ ds,
+                                                          int64_t rows, int n, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float pv[SMAX_PER_LANE], dv[SMAX_PER_LANE];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < SMAX_PER_LANE; ++i) {
+    const int c = i * 64 + lane;
+    pv[i] = (c < n) ? ldf<T>(p + row * n + c) : 0.f;
+    dv[i] = (c < n) ? dp[row * n + c] : 0.f;
+    dot += pv[i] * dv[i];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < SMAX_PER_LANE; ++i) {
+    const int c = i * 64 + lane;
+    if (c < n) stf<T>(ds + row * n + c, pv[i] * (dv[i] - dot) * scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cross attention (models_crossvit.py:111-128) for S <= 8 keys.  D = H * dh, dh == 32:
+// one wave per query row: lane = head * 4 + quarter, each lane owns 8 channels of its head.
+// ------------------------------------------------------------------------------------------
+constexpr int XS = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        T* __restrict__ o, int B, int N, int S, int D, int ldkv, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * N) return;
+  const int b = (int)(row / N);
+  for (int c0 = lane * 8; c0 < D; c0 += 512) {  // D = 512 -> one pass
+    float qv[8];
+    ld8<T>(q + row * D + c0, qv);
+    float sc[XS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+      sc[j] = -INFINITY;
+      if (j < S) {
+        float kv[8];
+        ld8<T>(k + ((int64_t)b * S + j) * ldkv + c0, kv);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qv[e] * kv[e];
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        sc[j] = d * scale;
+        mx = fmaxf(mx, sc[j]);
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) { sc[j] = (j < S) ? __expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+    const float inv = 1.f / sum;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+      if (j < S) {
+        float vv[8];
+        ld8<T>(v + ((int64_t)b * S + j) * ldkv + c0, vv);
+        const float pj = sc[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
+      }
+    }
+    st8<T>(o + row * D + c0, acc);
+  }
+}
+
+// Backward: recomputes P; dq per row; dk/dv are reduced over the rows of a block in LDS and written as
+// per-block partials  partial[blockIdx.x][2][S][D]  (blocks never straddle a batch element).
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        const T* __restrict__ dout, T* __restrict__ dq, float* __restrict__ partial,
+                                                        int N, int S, int D, int ldkv, float scale, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+  float* sm = reinterpret_cast<float*>(smem_x);  // [4 waves][2][S][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blocks_per_b = (N + rows_per_block - 1) / rows_per_block;
+  const int b = blockIdx.x / blocks_per_b;
+  const int r0 = (blockIdx.x - b * blocks_per_b) * rows_per_block;
+  const int r1 = min(N, r0 + rows_per_block);
+  const int c0 = lane * 8;  // D == 512
+  float kv[XS][8], vv[XS][8], dk[XS][8], dvv[XS][8];
+#pragma unroll
+  for (int j = 0; j < XS; ++j) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dk[j][e] = 0.f; dvv[j][e] = 0.f; kv[j][e] = 0.f; vv[j][e] = 0.f; }
+    if (j < S) {
+      ld8<T>(k + ((int64_t)b * S + j) * ldkv + c0, kv[j]);
+      ld8<T>(v + ((int64_t)b * S + j) * ldkv + c0, vv[j]);
+    }
+  }
+  for (int r = r0 + wave; r < r1; r += 4) {
+    const int64_t row = (int64_t)b * N + r;
+    float qv[8], dov[8];
+    ld8<T>(q + row * D + c0, qv);
+    ld8<T>(dout + row * D + c0, dov);
+    float sc[XS], dp[XS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+      float d = 0.f, g = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { d += qv[e] * kv[j][e]; g += dov[e] * vv[j][e]; }
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
+      g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+      sc[j] = (j < S) ? d * scale : -INFINITY;
+      dp[j] = g;
+      mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) { sc[j] = (j < S) ? __expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+    const float inv = 1.f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) { sc[j] *= inv; dot += sc[j] * dp[j]; }
+    float dqv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dqv[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+      const float ds = sc[j] * (dp[j] - dot) * scale;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dqv[e] += ds * kv[j][e];
+        dk[j][e] += ds * qv[e];
+        dvv[j][e] += sc[j] * dov[e];
+      }
+    }
+    st8<T>(dq + row * D + c0, dqv);
+  }
+  // reduce the 4 waves and emit this block's partial
+  for (int j = 0; j < S; ++j) {
+    st8<float>(sm + ((wave * 2 + 0) * S + j) * D + c0, dk[j]);
+    st8<float>(sm + ((wave * 2 + 1) * S + j) * D + c0, dvv[j]);
+  }
+  __syncthreads();
+  const int tot = 2 * S * D;
+  for (int i = threadIdx.x; i < tot; i += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += sm[w * tot + i];
+    partial[(int64_t)blockIdx.x * tot + i] = s;
+  }
+}
+
+// dkv[b][which][j][:] = sum over the blocks of batch b
+__global__ void xattn_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dk, float* __restrict__ dv,
+                                        int blocks_per_b, int S, int D) {
+  const int b = blockIdx.y;
+  const int tot = 2 * S * D;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tot) return;
+  float s = 0.f;
+  for (int p = 0; p < blocks_per_b; ++p) s += partial[((int64_t)b * blocks_per_b + p) * tot + i];
+  const int which = i / (S * D), r = i - which * S * D;
+  (which == 0 ? dk : dv)[(int64_t)b * S * D + r] = s;
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream) {
+  if (!s || !p || n > 64 * SMAX_PER_LANE || n <= 0) { countr_set_error("countr_softmax_fwd: row length must be <= 1024"); return -1; }
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (out_bf16) hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), s, (bf16_t*)p, rows, n);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, STREAM(stream), s, (float*)p, rows, n);
+  COUNTR_LAUNCH_CHECK("countr_softmax_fwd");
+}
+
+extern "C" int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,
+                                  void* stream) {
+  if (!p || !dp || !ds || n > 64 * SMAX_PER_LANE) { countr_set_error("countr_softmax_bwd: bad args"); return -1; }
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)p, dp, (bf16_t*)ds, rows, n, scale);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, STREAM(stream), (const float*)p, dp, (float*)ds, rows, n, scale);
+  COUNTR_LAUNCH_CHECK("countr_softmax_bwd");
+}
+
+extern "C" int countr_xattn_fwd(const void* q, const void* k, const void* v, void* out, int B, int N, int S, int D, int heads,
+                                int ldkv, float scale, int dtype, void* stream) {
+  if (!q || !k || !v || !out || S < 1 || S > XS || D != 512 || heads * 32 != D) { countr_set_error("countr_xattn_fwd: need 1 <= S <= 8, D == 512, head_dim == 32"); return -1; }
+  dim3 grid((unsigned)(((int64_t)B * N + 3) / 4)), block(256);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(xattn_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, B, N, S, D, ldkv, scale);
+  else hipLaunchKernelGGL(xattn_fwd_kernel<float>, grid, block, 0, STREAM(stream), (const float*)q, (const float*)k, (const float*)v, (float*)out, B, N, S, D, ldkv, scale);
+  COUNTR_LAUNCH_CHECK("countr_xattn_fwd");
+}
+
+static const int XATTN_ROWS_PER_BLOCK = 32;
+extern "C" int64_t countr_xattn_bwd_workspace_floats(int B, int N, int S, int D) {
+  const int bpb = (N + XATTN_ROWS_PER_BLOCK - 1) / XATTN_ROWS_PER_BLOCK;
+  return (int64_t)B * bpb * 2 * S * D;
+}
+
+// dk, dv: fp32 [B, S, D] (overwritten)
+extern "C" int countr_xattn_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, float* dk, float* dv,
+                                float* workspace, int B, int N, int S, int D, int heads, int ldkv, float scale, int dtype,
+                                void* stream) {
+  if (!q || !k || !v || !dout || !dq || !dk || !dv || !workspace || S < 1 || S > XS || D != 512 || heads * 32 != D) { countr_set_error("countr_xattn_bwd: bad args"); return -1; }
+  const int bpb = (N + XATTN_ROWS_PER_BLOCK - 1) / XATTN_ROWS_PER_BLOCK;
+  const size_t lds = (size_t)4 * 2 * S * D * sizeof(float);
+  if (dtype == COUNTR_BF16) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * XS * 512 * 4);
+    hipLaunchKernelGGL(xattn_bwd_kernel<bf16_t>, dim3(B * bpb), dim3(256), lds, STREAM(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dq, workspace, N, S, D, ldkv, scale, XATTN_ROWS_PER_BLOCK);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * XS * 512 * 4);
+    hipLaunchKernelGGL(xattn_bwd_kernel<float>, dim3(B * bpb), dim3(256), lds, STREAM(stream), (const float*)q, (const float*)k, (const float*)v, (const float*)dout, (float*)dq, workspace, N, S, D, ldkv, scale, XATTN_ROWS_PER_BLOCK);
+  }
+  hipLaunchKernelGGL(xattn_bwd_finish_kernel, dim3((2 * S * D + 255) / 256, B), dim3(256), 0, STREAM(stream), workspace, dk, dv, bpb, S, D);
+  COUNTR_LAUNCH_CHECK("countr_xattn_bwd");
+}

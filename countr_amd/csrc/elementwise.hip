@@ -1,0 +1,433 @@
+// Data-movement / elementwise kernels of the CounTR hot path (HBM-bound, 16-byte vector accesses).
+//   im2patch        : timm PatchEmbed conv k16 s16 gather          (models_mae_cross.py:138)
+//   conv3x3_c3      : first exemplar conv 3->64 (direct, VALU)      (models_mae_cross.py:48)
+//   upsample2x      : F.interpolate(bilinear, align_corners=False)  (models_mae_cross.py:189-196)
+//   gelu_bwd, colsum: autograd pieces of Mlp / Linear bias          (models_crossvit.py:60-67)
+//   cast / permute  : weight shadows (OIHW -> OHWI, dgrad form)
+//   masked mse loss : FSC_finetune_cross.py:290-303
+//   adamw           : torch.optim.AdamW(betas=(0.9,0.95))           (FSC_finetune_cross.py:235)
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+
+extern "C" int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream);
+
+namespace {
+
+// ---------------- patch gather: img fp32 NCHW [B,3,H,W] -> patches [B*gh*gw, 3*p*p], k = (c, py, px)
+template <typename T>
+__global__ void im2patch_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int p, int gh,
+                                int gw) {
+  const int K = 3 * p * p;
+  const int64_t total = (int64_t)B * gh * gw * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int64_t t = i / K;
+    const int j = (int)(t % gw), ii = (int)((t / gw) % gh), b = (int)(t / ((int64_t)gw * gh));
+    const int c = k / (p * p), r = k - c * p * p, py = r / p, px = r - py * p;
+    stf<T>(out + i, img[(((int64_t)b * 3 + c) * H + ii * p + py) * W + j * p + px]);
+  }
+}
+
+// ---------------- first exemplar conv: in fp32 NCHW [S,3,H,W], w fp32 [64,3,3,3], out NHWC [S,H,W,64]
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int S,
+                                                             int H, int W) {
+  __shared__ float sw[27 * 64];  // [k][co]
+  __shared__ float sb[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) { const int co = i / 27, k = i - co * 27; sw[k * 64 + co] = w[i]; }
+  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int cv = threadIdx.x & 7;  // 8 output channels
+  const int64_t npix = (int64_t)S * H * W;
+  for (int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (int64_t)gridDim.x * 32) {
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), s = (int)(pix / ((int64_t)W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = sb[cv * 8 + e];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          float v = 0.f;
+          if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = in[(((int64_t)s * 3 + c) * H + yy) * W + xx];
+          const float* wr = sw + ((c * 3 + ky) * 3 + kx) * 64 + cv * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v * wr[e];
+        }
+    st8<T>(out + pix * 64 + cv * 8, acc);
+  }
+}
+
+// wgrad of the same conv: partial[block][64*27] (+ bias grad partial[block][64] behind it).
+// Each thread owns 7 of the 1728+64 outputs (padded) and walks the block's pixel range through LDS tiles.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __restrict__ in, const T* __restrict__ dy,
+                                                               float* __restrict__ partial, int S, int H, int W) {
+  __shared__ float s_dy[64][65];  // [pixel][co]
+  __shared__ float s_in[64][28];  // [pixel][k], k = 27 is the constant 1 (bias grad)
+  const int64_t npix = (int64_t)S * H * W;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  float acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) acc[i] = 0.f;
+  for (int64_t base = p0; base < p1; base += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+      const int pp = i >> 3, c8 = i & 7;
+      float v[8];
+      if (base + pp < p1) ld8<T>(dy + (base + pp) * 64 + c8 * 8, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_dy[pp][c8 * 8 + e] = v[e];
+    }
+    for (int i = threadIdx.x; i < 64 * 28; i += 256) {
+      const int pp = i / 28, k = i - pp * 28;
+      float v = 0.f;
+      const int64_t pix = base + pp;
+      if (pix < p1) {
+        if (k == 27) v = 1.f;
+        else {
+          const int x = (int)(pix % W), y = (int)((pix / W) % H), s = (int)(pix / ((int64_t)W * H));
+          const int c = k / 9, r = k - c * 9, ky = r / 3, kx = r - ky * 3;
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = in[(((int64_t)s * 3 + c) * H + yy) * W + xx];
+        }
+      }
+      s_in[pp][k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int o = threadIdx.x + 256 * i;  // output id = co*28 + k
+      if (o < 64 * 28) {
+        const int co = o / 28, k = o - co * 28;
+        float a = 0.f;
+        for (int pp = 0; pp < 64; ++pp) a += s_dy[pp][co] * s_in[pp][k];
+        acc[i] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int o = threadIdx.x + 256 * i;
+    if (o < 64 * 28) partial[(int64_t)blockIdx.x * (64 * 28) + o] = acc[i];
+  }
+}
+
+// partial [nb][64][28] -> dw [64][27] (torch OIHW order co, c, ky, kx == k) and db [64]
+__global__ void conv3x3_c3_wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                               int nb, int accumulate) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= 64 * 28) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * (64 * 28) + o];
+  const int co = o / 28, k = o - co * 28;
+  float* dst = (k == 27) ? (db + co) : (dw + co * 27 + k);
+  *dst = accumulate ? *dst + s : s;
+}
+
+// ---------------- bilinear x2 (align_corners=False) on NHWC, VEC channels per thread
+// out[2m] = .25 in[m-1] + .75 in[m], out[2m+1] = .75 in[m] + .25 in[m+1], indices clamped.
+template <typename T, int VEC>
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+  const int CV = C / VEC;
+  const int64_t total = (int64_t)B * 2 * H * 2 * W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    int64_t t = i / CV;
+    const int ox = (int)(t % (2 * W)); t /= (2 * W);
+    const int oy = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    const int my = oy >> 1, mx = ox >> 1;
+    const int y0 = (oy & 1) ? my : max(my - 1, 0), y1 = (oy & 1) ? min(my + 1, H - 1) : my;
+    const int x0 = (ox & 1) ? mx : max(mx - 1, 0), x1 = (ox & 1) ? min(mx + 1, W - 1) : mx;
+    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+    const T* base = in + (int64_t)b * H * W * C + cv * VEC;
+    float a[VEC], bq[VEC], c[VEC], d[VEC], o[VEC];
+    if constexpr (VEC == 8) {
+      ld8<T>(base + ((int64_t)y0 * W + x0) * C, a); ld8<T>(base + ((int64_t)y0 * W + x1) * C, bq);
+      ld8<T>(base + ((int64_t)y1 * W + x0) * C, c); ld8<T>(base + ((int64_t)y1 * W + x1) * C, d);
+    } else {
+      a[0] = ldf<T>(base + ((int64_t)y0 * W + x0) * C); bq[0] = ldf<T>(base + ((int64_t)y0 * W + x1) * C);
+      c[0] = ldf<T>(base + ((int64_t)y1 * W + x0) * C); d[0] = ldf<T>(base + ((int64_t)y1 * W + x1) * C);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float top = wx0 * a[e] + (1.f - wx0) * bq[e];
+      const float bot = wx0 * c[e] + (1.f - wx0) * d[e];
+      o[e] = wy0 * top + (1.f - wy0) * bot;
+    }
+    T* dst = out + (((int64_t)b * 2 * H + oy) * 2 * W + ox) * C + cv * VEC;
+    if constexpr (VEC == 8) st8<T>(dst, o); else stf<T>(dst, o[0]);
+  }
+}
+
+// adjoint: din[m] = sum over the (up to) 4x4 fine pixels that read coarse pixel m.
+// 1-D weights of fine index f on coarse m: f=2m-1 -> .25, 2m -> .75, 2m+1 -> .75, 2m+2 -> .25, with the
+// clamped borders folding the out-of-range neighbour back (m=0: f=0 gets +.25; m=H-1: f=2H-1 gets +.25).
+__device__ __forceinline__ void up2_adj_taps(int m, int n, int (&f)[4], float (&w)[4]) {
+  f[0] = 2 * m - 1; w[0] = 0.25f;
+  f[1] = 2 * m;     w[1] = 0.75f;
+  f[2] = 2 * m + 1; w[2] = 0.75f;
+  f[3] = 2 * m + 2; w[3] = 0.25f;
+  if (m == 0) { w[0] = 0.f; f[0] = 0; w[1] = 1.0f; }
+  if (m == n - 1) { w[3] = 0.f; f[3] = 2 * n - 1; w[2] = 1.0f; }
+}
+
+template <typename T, int VEC>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int H, int W, int C) {
+  const int CV = C / VEC;
+  const int64_t total = (int64_t)B * H * W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    int64_t t = i / CV;
+    const int mx = (int)(t % W); t /= W;
+    const int my = (int)(t % H);
+    const int b = (int)(t / H);
+    int fy[4], fx[4];
+    float wy[4], wx[4];
+    up2_adj_taps(my, H, fy, wy);
+    up2_adj_taps(mx, W, fx, wx);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    const T* base = dout + (int64_t)b * 4 * H * W * C + cv * VEC;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (wy[a] == 0.f) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (wx[c] == 0.f) continue;
+        float v[VEC];
+        if constexpr (VEC == 8) ld8<T>(base + ((int64_t)fy[a] * 2 * W + fx[c]) * C, v);
+        else v[0] = ldf<T>(base + ((int64_t)fy[a] * 2 * W + fx[c]) * C);
+        const float ww = wy[a] * wx[c];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += ww * v[e];
+      }
+    }
+    T* dst = din + (((int64_t)b * H + my) * W + mx) * C + cv * VEC;
+    if constexpr (VEC == 8) st8<T>(dst, acc); else stf<T>(dst, acc[0]);
+  }
+}
+
+// ---------------- dpre = dh * gelu'(pre)
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ pre, T* __restrict__ dpre, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float d[8], p[8], o[8];
+    ld8<T>(dh + i * 8, d);
+    ld8<T>(pre + i * 8, p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_erf_grad(p[e]);
+    st8<T>(dpre + i * 8, o);
+  }
+}
+
+// ---------------- column sums (bias gradients): partial[blockIdx.y][N] over row chunks
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, int M, int N) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(M, r0 + per);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += ldf<T>(x + (int64_t)r * N + col);
+  partial[(int64_t)blockIdx.y * N + col] = s;
+}
+
+// ---------------- weight shadows
+// mode 0: plain cast [n]; mode 1: OIHW [Co][Ci][T] -> OHWI [Co][T][Ci];
+// mode 2: dgrad form Wd[ci][tap'][co] = W[co][ci][T-1-tap'] (conv3x3 dgrad == fwd conv with Wd)
+template <typename T>
+__global__ void cast_permute_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n, int mode, int Co, int Ci,
+                                    int taps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s = i;
+    if (mode == 1) {
+      const int ci = (int)(i % Ci); const int tap = (int)((i / Ci) % taps); const int co = (int)(i / ((int64_t)Ci * taps));
+      s = ((int64_t)co * Ci + ci) * taps + tap;
+    } else if (mode == 2) {
+      const int co = (int)(i % Co); const int tap = (int)((i / Co) % taps); const int ci = (int)(i / ((int64_t)Co * taps));
+      s = ((int64_t)co * Ci + ci) * taps + (taps - 1 - tap);
+    }
+    stf<T>(dst + i, src[s]);
+  }
+}
+
+// ---------------- masked MSE loss + its gradient + counts (FSC_finetune_cross.py:290-303)
+// loss = sum((pred-gt)^2 * mask / HW) / B ; dpred = 2 (pred-gt) mask / (HW * B) * grad_scale
+// sums[0] = loss, sums[1 + b] = sum(pred[b]) / 60, sums[1 + B + b] = sum(gt[b]) / 60   (must be zeroed before)
+__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         const float* __restrict__ mask, float* __restrict__ dpred,
+                                                         float* __restrict__ sums, int B, int HW, float grad_scale) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y;
+  float l = 0.f, sp = 0.f, sg = 0.f;
+  const float inv = 1.f / ((float)HW * B);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float p = pred[(int64_t)b * HW + i], g = gt[(int64_t)b * HW + i], m = mask[i];
+    const float d = p - g;
+    l += d * d * m;
+    sp += p; sg += g;
+    if (dpred) dpred[(int64_t)b * HW + i] = 2.f * d * m * inv * grad_scale;
+  }
+  l = block_sum<4>(l, sm);
+  sp = block_sum<4>(sp, sm);
+  sg = block_sum<4>(sg, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums, l * inv);
+    atomicAdd(sums + 1 + b, sp / 60.f);
+    atomicAdd(sums + 1 + B + b, sg / 60.f);
+  }
+}
+
+// ---------------- fused AdamW over flat fp32 buffers, with an optional low-precision shadow of the params
+struct AdamRanges {
+  int n;
+  int64_t start[8], end[8];
+  float wd[8];
+};
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ shadow, AdamRanges R, float lr, float b1, float b2, float eps, float bc1,
+                             float bc2, float grad_scale, const float* __restrict__ hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; grad_scale = hyper[3]; }  // graph-replay safe
+  for (int r = 0; r < R.n; ++r) {
+    const float wd = R.wd[r];
+    for (int64_t i = R.start[r] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.end[r];
+         i += (int64_t)gridDim.x * blockDim.x) {
+      const float gi = g[i] * grad_scale;
+      float pi = p[i] * (1.f - lr * wd);
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+      p[i] = pi;
+      if (shadow) shadow[i] = f2bf(pi);
+    }
+  }
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+static inline int nblocks(int64_t work, int per_block = 256, int cap = 4096) {
+  int64_t b = (work + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" int countr_im2patch(const float* img, void* out, int B, int H, int W, int patch, int dtype, void* stream) {
+  if (!img || !out || patch <= 0) { countr_set_error("countr_im2patch: bad args"); return -1; }
+  const int gh = H / patch, gw = W / patch;
+  const int64_t total = (int64_t)B * gh * gw * 3 * patch * patch;
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(im2patch_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), img, (bf16_t*)out, B, H, W, patch, gh, gw);
+  else hipLaunchKernelGGL(im2patch_kernel<float>, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), img, (float*)out, B, H, W, patch, gh, gw);
+  COUNTR_LAUNCH_CHECK("countr_im2patch");
+}
+
+extern "C" int countr_conv3x3_c3_fwd(const float* in, const float* w, const float* bias, void* out, int S, int H, int W,
+                                     int dtype, void* stream) {
+  if (!in || !w || !bias || !out) { countr_set_error("countr_conv3x3_c3_fwd: null"); return -1; }
+  const int nb = nblocks((int64_t)S * H * W, 32, 2048);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (bf16_t*)out, S, H, W);
+  else hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (float*)out, S, H, W);
+  COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_fwd");
+}
+
+extern "C" int countr_conv3x3_c3_wgrad_nblocks(void) { return 256; }
+extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* dw, float* db, float* workspace, int S, int H,
+                                       int W, int dtype, int accumulate, void* stream) {
+  if (!in || !dy || !dw || !db || !workspace) { countr_set_error("countr_conv3x3_c3_wgrad: null"); return -1; }
+  const int nb = 256;
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const bf16_t*)dy, workspace, S, H, W);
+  else hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const float*)dy, workspace, S, H, W);
+  hipLaunchKernelGGL(conv3x3_c3_wgrad_finish_kernel, dim3((64 * 28 + 255) / 256), dim3(256), 0, STREAM(stream), workspace, dw, db, nb, accumulate);
+  COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_wgrad");
+}
+
+extern "C" int countr_upsample2x_fwd(const void* in, void* out, int B, int H, int W, int C, int dtype, void* stream) {
+  if (!in || !out || (C != 1 && C % 8)) { countr_set_error("countr_upsample2x_fwd: C must be 1 or a multiple of 8"); return -1; }
+  const int64_t total = (int64_t)B * 4 * H * W * (C == 1 ? 1 : C / 8);
+  const int nb = nblocks(total, 256, 8192);
+  if (dtype == COUNTR_BF16) {
+    if (C == 1) hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
+  } else {
+    if (C == 1) hipLaunchKernelGGL((upsample2x_fwd_kernel<float, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_fwd_kernel<float, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
+  }
+  COUNTR_LAUNCH_CHECK("countr_upsample2x_fwd");
+}
+
+extern "C" int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, int W, int C, int dtype, void* stream) {
+  if (!dout || !din || (C != 1 && C % 8)) { countr_set_error("countr_upsample2x_bwd: C must be 1 or a multiple of 8"); return -1; }
+  const int64_t total = (int64_t)B * H * W * (C == 1 ? 1 : C / 8);
+  const int nb = nblocks(total, 256, 8192);
+  if (dtype == COUNTR_BF16) {
+    if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C);
+  } else {
+    if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, C);
+  }
+  COUNTR_LAUNCH_CHECK("countr_upsample2x_bwd");
+}
+
+extern "C" int countr_gelu_bwd(const void* dh, const void* pre, void* dpre, int64_t n, int dtype, void* stream) {
+  if (!dh || !pre || !dpre || (n & 7)) { countr_set_error("countr_gelu_bwd: n must be a multiple of 8"); return -1; }
+  const int nb = nblocks(n / 8, 256, 8192);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dh, (const bf16_t*)pre, (bf16_t*)dpre, n / 8);
+  else hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dh, (const float*)pre, (float*)dpre, n / 8);
+  COUNTR_LAUNCH_CHECK("countr_gelu_bwd");
+}
+
+extern "C" int countr_colsum_nparts(void) { return 32; }
+// workspace: fp32 [32][N]
+extern "C" int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, int accumulate, void* stream);
+
+extern "C" int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co, int Ci, int taps, int dtype,
+                                   void* stream) {
+  if (!src || !dst) { countr_set_error("countr_cast_permute: null"); return -1; }
+  const int nb = nblocks(n, 256, 4096);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(cast_permute_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), src, (bf16_t*)dst, n, mode, Co, Ci, taps);
+  else hipLaunchKernelGGL(cast_permute_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), src, (float*)dst, n, mode, Co, Ci, taps);
+  COUNTR_LAUNCH_CHECK("countr_cast_permute");
+}
+
+extern "C" int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums, int B,
+                                 int HW, float grad_scale, void* stream) {
+  if (!pred || !gt || !mask || !sums) { countr_set_error("countr_masked_mse: null"); return -1; }
+  (void)hipMemsetAsync(sums, 0, sizeof(float) * (1 + 2 * B), STREAM(stream));
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(nblocks(HW, 256, 64), B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, sums, B, HW, grad_scale);
+  COUNTR_LAUNCH_CHECK("countr_masked_mse");
+}
+
+extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
+                                 const int64_t* starts, const int64_t* ends, const float* wds, float lr, float beta1,
+                                 float beta2, float eps, int step, float grad_scale, const float* hyper_dev, void* stream) {
+  if (!p || !g || !m || !v || nranges < 1 || nranges > 8 || (step < 1 && !hyper_dev)) { countr_set_error("countr_adamw_step: bad args (1..8 ranges, step >= 1)"); return -1; }
+  AdamRanges R;
+  R.n = nranges;
+  int64_t total = 0;
+  for (int i = 0; i < nranges; ++i) { R.start[i] = starts[i]; R.end[i] = ends[i]; R.wd[i] = wds[i]; total += ends[i] - starts[i]; }
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(total, 256, 2048)), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev);
+  COUNTR_LAUNCH_CHECK("countr_adamw_step");
+}
+
+extern "C" int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, int accumulate, void* stream) {
+  if (!x || !out || !workspace) { countr_set_error("countr_colsum: null"); return -1; }
+  const int parts = 32;
+  dim3 grid((N + 255) / 256, parts);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, M, N);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, STREAM(stream), (const float*)x, workspace, M, N);
+  return countr_colsum_partials(workspace, out, parts, N, accumulate, stream);
+}

@@ -1,0 +1,678 @@
+// Normalisation kernels (HBM-bound; fp32 statistics, 16-byte vector loads, wave-shuffle reductions).
+//   LayerNorm fwd/bwd      : nn.LayerNorm(eps=1e-6)          models_mae_cross.py:146,182; models_crossvit.py:153-155
+//   GroupNorm(8)+ReLU      : decode_head*                     models_mae_cross.py:80-100   (NHWC maps)
+//   InstanceNorm+ReLU+pool : decoder_proj1-4                  models_mae_cross.py:47-71    (NHWC maps)
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row; x is the fp32 residual stream, y is the GEMM operand dtype.
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, TO* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * D;
+  constexpr int MAXV = 8;  // D <= 2048
+  float v[MAXV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < D) {
+      ld4<float>(xr + c, v[i]);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  TO* yr = y + (int64_t)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < D) {
+      float g[4], b[4], o[4];
+      ld4<float>(gamma + c, g);
+      ld4<float>(beta + c, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      st4<TO>(yr + c, o);
+    }
+  }
+}
+
+// Backward: dx (+)= rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)); per-block partial dgamma / dbeta.
+// Grid = NB blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NB, ...
+template <typename TI>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ partial, int rows, int D, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ln[];
+  float* sm = reinterpret_cast<float*>(smem_ln);  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int MAXV = 8;
+  float dg[MAXV][4], db[MAXV][4];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const TI* dyr = dy + (int64_t)row * D;
+    const float* xr = x + (int64_t)row * D;
+    float xh[MAXV][4], gy[MAXV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (c < D) {
+        float d[4], xv[4], g[4];
+        ld4<TI>(dyr + c, d);
+        ld4<float>(xr + c, xv);
+        ld4<float>(gamma + c, g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          gy[i][e] = d[e] * g[e];
+          s1 += gy[i][e];
+          s2 += gy[i][e] * xh[i][e];
+          dg[i][e] += d[e] * xh[i][e];
+          db[i][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+    float* dxr = dx + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (c < D) {
+        float o[4];
+        if (accumulate) ld4<float>(dxr + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += rs * (gy[i][e] - s1 - xh[i][e] * s2);
+        st4<float>(dxr + c, o);
+      }
+    }
+  }
+  // block reduce of the per-wave column sums, then one partial row per block: [block][2][D]
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < D) {
+      st4<float>(sm + (wave * 2 + 0) * D + c, dg[i]);
+      st4<float>(sm + (wave * 2 + 1) * D + c, db[i]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int which = c / D, col = c - which * D;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += sm[(w * 2 + which) * D + col];
+    partial[((int64_t)blockIdx.x * 2 + which) * D + col] = s;
+  }
+}
+
+// out[c] (+)= sum_p partial[p][c]
+__global__ void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts, int C,
+                                       int64_t stride, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// out[0] (+)= sum of n floats (single block; used for tiny reductions such as the 1x1-conv bias grad)
+__global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__ in, int64_t n, float* __restrict__ out,
+                                                       int accumulate) {
+  __shared__ float sm[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += in[i];
+  s = block_sum<16>(s, sm);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm(G groups) on NHWC [B, HW, C], C = 256, 8 channels per thread (32 threads per pixel,
+// 8 pixels per pass).  Statistics are accumulated per (image, pixel-split) block and combined with
+// Chan's parallel formula by every consumer block (tiny), which keeps the result deterministic.
+// ------------------------------------------------------------------------------------------
+constexpr int GN_C = 256;
+
+// reduce `v` over the lanes/waves that share (threadIdx.x & 31): result valid in every thread.
+__device__ __forceinline__ float reduce_same_chanvec(float v, float* sm /* [8][32] */) {
+  v += __shfl_xor(v, 32, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane < 32) sm[wave * 32 + lane] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) r += sm[w * 32 + (threadIdx.x & 31)];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part /* [B][ns][G][2] */,
+                                                       int HW, int G) {
+  __shared__ float sm[128];
+  const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
+  const int per = (HW + ns - 1) / ns;
+  const int p0 = split * per, p1 = min(HW, p0 + per);
+  const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const T* xb = x + (int64_t)b * HW * GN_C;
+  float s = 0.f, q = 0.f;
+  for (int p = p0 + slot; p < p1; p += 8) {
+    float v[8];
+    ld8<T>(xb + (int64_t)p * GN_C + cv * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s += v[e]; q += v[e] * v[e]; }
+  }
+  s = reduce_same_chanvec(s, sm);
+  q = reduce_same_chanvec(q, sm);
+  // channel-vector cv belongs to group cv / (cpg/8); sum the cvs of a group
+  const int cvpg = (GN_C / G) / 8;
+  __syncthreads();
+  if (threadIdx.x < 32) { sm[threadIdx.x] = s; sm[32 + threadIdx.x] = q; }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float gs = 0.f, gq = 0.f;
+    for (int i = 0; i < cvpg; ++i) { gs += sm[threadIdx.x * cvpg + i]; gq += sm[32 + threadIdx.x * cvpg + i]; }
+    const float n = (float)(p1 - p0) * (GN_C / G);
+    const float m = n > 0 ? gs / n : 0.f;
+    float* o = part + (((int64_t)b * ns + split) * G + threadIdx.x) * 2;
+    o[0] = m;
+    o[1] = fmaxf(gq - gs * m, 0.f);  // M2 about the split mean
+  }
+}
+
+// combine split statistics of image b into sm_mean[G], sm_rstd[G] (called by all threads of a block)
+__device__ __forceinline__ void gn_combine(const float* __restrict__ part, int b, int ns, int HW, int G, float eps,
+                                           float* sm_mean, float* sm_rstd) {
+  if (threadIdx.x < G) {
+    const int per = (HW + ns - 1) / ns;
+    const float cpg = (float)(GN_C / G);
+    float ntot = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < ns; ++s) {
+      const int p0 = s * per, p1 = min(HW, p0 + per);
+      const float n = (float)max(p1 - p0, 0) * cpg;
+      if (n <= 0.f) continue;
+      const float* o = part + (((int64_t)b * ns + s) * G + threadIdx.x) * 2;
+      const float d = o[0] - mean;
+      const float nn = ntot + n;
+      mean += d * (n / nn);
+      m2 += o[1] + d * d * (ntot * n / nn);
+      ntot = nn;
+    }
+    sm_mean[threadIdx.x] = mean;
+    sm_rstd[threadIdx.x] = rsqrtf(m2 / ntot + eps);
+  }
+  __syncthreads();
+}
+
+// y = relu(gn(x)); with w1 != nullptr instead writes out1[b, p] = sum_c y[p, c] * w1[c] + b1 (the fused
+// 1x1 conv of decode_head3, models_mae_cross.py:99) and y may be nullptr.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ part,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          T* __restrict__ y, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, float* __restrict__ out1,
+                                                          float* __restrict__ stats_out /* [B][G][2] */, int HW, int G,
+                                                          int ns, float eps) {
+  __shared__ float sm_mean[32], sm_rstd[32];
+  const int b = blockIdx.y;
+  gn_combine(part, b, ns, HW, G, eps, sm_mean, sm_rstd);
+  if (blockIdx.x == 0 && threadIdx.x < G && stats_out) {
+    stats_out[((int64_t)b * G + threadIdx.x) * 2] = sm_mean[threadIdx.x];
+    stats_out[((int64_t)b * G + threadIdx.x) * 2 + 1] = sm_rstd[threadIdx.x];
+  }
+  const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int g = (cv * 8) / (GN_C / G);
+  const float mu = sm_mean[g], rs = sm_rstd[g];
+  float ga[8], be[8], w[8];
+  ld8<float>(gamma + cv * 8, ga);
+  ld8<float>(beta + cv * 8, be);
+  if (w1) ld8<float>(w1 + cv * 8, w);
+  const float bias1 = w1 ? b1[0] : 0.f;
+  const T* xb = x + (int64_t)b * HW * GN_C;
+  for (int p = blockIdx.x * 8 + slot; p < HW; p += gridDim.x * 8) {
+    float v[8];
+    ld8<T>(xb + (int64_t)p * GN_C + cv * 8, v);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = fmaxf((v[e] - mu) * rs * ga[e] + be[e], 0.f);
+      if (w1) dot += v[e] * w[e];
+    }
+    if (y) st8<T>(y + ((int64_t)b * HW + p) * GN_C + cv * 8, v);
+    if (w1) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+      if (cv == 0) out1[(int64_t)b * HW + p] = dot + bias1;
+    }
+  }
+}
+
+// Backward pass 1: per-channel sums of g = dy * 1[y>0] and g * xhat over a pixel split.
+// dy is either a tensor (T) or, for the fused 1x1 head, d1[b,p] * w1[c].
+// partial layout: [B][ns][3][C] = {sum g, sum g*xhat, sum d1*y (dw1, head only)}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 const float* __restrict__ d1, const float* __restrict__ w1,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ partial,
+                                                                 int HW, int G) {
+  __shared__ float sm[128];
+  const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
+  const int per = (HW + ns - 1) / ns;
+  const int p0 = split * per, p1 = min(HW, p0 + per);
+  const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int g = (cv * 8) / (GN_C / G);
+  const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
+  float ga[8], be[8], w[8];
+  ld8<float>(gamma + cv * 8, ga);
+  ld8<float>(beta + cv * 8, be);
+  if (w1) ld8<float>(w1 + cv * 8, w);
+  float sg[8], sgx[8], sw[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sgx[e] = 0.f; sw[e] = 0.f; }
+  const int64_t base = (int64_t)b * HW * GN_C;
+  for (int p = p0 + slot; p < p1; p += 8) {
+    float v[8], d[8];
+    ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v);
+    float dd = 0.f;
+    if (w1) dd = d1[(int64_t)b * HW + p];
+    else ld8<T>(dy + base + (int64_t)p * GN_C + cv * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float yv = xh * ga[e] + be[e];
+      const float gg = (yv > 0.f) ? (w1 ? dd * w[e] : d[e]) : 0.f;
+      sg[e] += gg;
+      sgx[e] += gg * xh;
+      if (w1) sw[e] += dd * fmaxf(yv, 0.f);
+    }
+  }
+  float* o = partial + ((int64_t)b * ns + split) * 3 * GN_C;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float a = reduce_same_chanvec(sg[e], sm);
+    const float c = reduce_same_chanvec(sgx[e], sm);
+    const float d = w1 ? reduce_same_chanvec(sw[e], sm) : 0.f;
+    if (threadIdx.x < 32) {
+      o[cv * 8 + e] = a;
+      o[GN_C + cv * 8 + e] = c;
+      o[2 * GN_C + cv * 8 + e] = d;
+    }
+  }
+}
+
+// Backward pass 2: dx = rstd * (g*gamma - m1 - xhat*m2), m1/m2 = group means of g*gamma, g*gamma*xhat.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                const float* __restrict__ d1, const float* __restrict__ w1,
+                                                                const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ partial,
+                                                                T* __restrict__ dx, int HW, int G, int ns) {
+  __shared__ float sm_m1[32], sm_m2[32];
+  const int b = blockIdx.y;
+  if (threadIdx.x < G) {
+    const int cpg = GN_C / G;
+    float a = 0.f, c = 0.f;
+    for (int s = 0; s < ns; ++s) {
+      const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
+      for (int ch = threadIdx.x * cpg; ch < (threadIdx.x + 1) * cpg; ++ch) {
+        a += o[ch] * gamma[ch];
+        c += o[GN_C + ch] * gamma[ch];
+      }
+    }
+    const float n = (float)HW * cpg;
+    sm_m1[threadIdx.x] = a / n;
+    sm_m2[threadIdx.x] = c / n;
+  }
+  __syncthreads();
+  const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int g = (cv * 8) / (GN_C / G);
+  const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
+  const float m1 = sm_m1[g], m2 = sm_m2[g];
+  float ga[8], be[8], w[8];
+  ld8<float>(gamma + cv * 8, ga);
+  ld8<float>(beta + cv * 8, be);
+  if (w1) ld8<float>(w1 + cv * 8, w);
+  const int64_t base = (int64_t)b * HW * GN_C;
+  for (int p = blockIdx.x * 8 + slot; p < HW; p += gridDim.x * 8) {
+    float v[8], d[8], o[8];
+    ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v);
+    float dd = 0.f;
+    if (w1) dd = d1[(int64_t)b * HW + p];
+    else ld8<T>(dy + base + (int64_t)p * GN_C + cv * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float yv = xh * ga[e] + be[e];
+      const float gg = (yv > 0.f) ? (w1 ? dd * w[e] : d[e]) : 0.f;
+      o[e] = rs * (gg * ga[e] - m1 - xh * m2);
+    }
+    st8<T>(dx + base + (int64_t)p * GN_C + cv * 8, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// InstanceNorm2d (affine=False, eps, biased var) + ReLU + MaxPool2 (or global average pool) on NHWC
+// [S, H, W, C].  One block per (sample, 64-channel chunk): thread = (8-channel vector, pixel slot).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float reduce_same_cv8(float v, float* sm /* [4][8] */) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane < 8) sm[wave * 8 + lane] = v;
+  __syncthreads();
+  return sm[threadIdx.x & 7] + sm[8 + (threadIdx.x & 7)] + sm[16 + (threadIdx.x & 7)] + sm[24 + (threadIdx.x & 7)];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               float* __restrict__ stats /* [S][C][2] */, int H, int W, int C,
+                                                               int avgpool, float eps) {
+  __shared__ float sm[32];
+  const int s = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;  // 32 pixel slots
+  const int HW = H * W;
+  const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  float sum[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
+  for (int p = slot; p < HW; p += 32) {
+    float v[8];
+    ld8<T>(xs + (int64_t)p * C, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] += v[e];
+  }
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mean[e] = reduce_same_cv8(sum[e], sm) / HW;
+  for (int p = slot; p < HW; p += 32) {
+    float v[8];
+    ld8<T>(xs + (int64_t)p * C, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean[e]; sq[e] += d * d; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rstd[e] = rsqrtf(reduce_same_cv8(sq[e], sm) / HW + eps);
+  if (slot == 0 && stats) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      stats[((int64_t)s * C + c0 + cv * 8 + e) * 2] = mean[e];
+      stats[((int64_t)s * C + c0 + cv * 8 + e) * 2 + 1] = rstd[e];
+    }
+  }
+  if (!avgpool) {
+    const int Ho = H / 2, Wo = W / 2;
+    T* ys = y + (int64_t)s * Ho * Wo * C + c0 + cv * 8;
+    for (int po = slot; po < Ho * Wo; po += 32) {
+      const int oy = po / Wo, ox = po - oy * Wo;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = 0.f;  // relu floor
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[8];
+        ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (v[e] - mean[e]) * rstd[e]);
+      }
+      st8<T>(ys + (int64_t)po * C, m);
+    }
+  } else {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int p = slot; p < HW; p += 32) {
+      float v[8];
+      ld8<T>(xs + (int64_t)p * C, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += fmaxf((v[e] - mean[e]) * rstd[e], 0.f);
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = reduce_same_cv8(acc[e], sm) / HW;
+    if (slot == 0) st8<T>(y + (int64_t)s * C + c0 + cv * 8, o);
+  }
+}
+
+// Backward of the same block: dyp is the gradient of the pooled output ([S,H/2,W/2,C] or [S,C]).
+// g = routed gradient (first max of the 2x2 window as in torch, or dy/HW for the average pool),
+// gated by relu; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)).
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
+                                                               const float* __restrict__ stats, T* __restrict__ dx, int H,
+                                                               int W, int C, int avgpool) {
+  __shared__ float sm[32];
+  const int s = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int HW = H * W, Ho = H / 2, Wo = W / 2;
+  const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  T* dxs = dx + (int64_t)s * HW * C + c0 + cv * 8;
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mean[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2];
+    rstd[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2 + 1];
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  float davg[8];
+  if (avgpool) {
+    ld8<T>(dyp + (int64_t)s * C + c0 + cv * 8, davg);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) davg[e] /= HW;
+  }
+  // pass 1: sums of g and g*xhat.  Work is organised per pooled window (4 input pixels).
+  const int nwin = avgpool ? HW : Ho * Wo;
+  for (int po = slot; po < nwin; po += 32) {
+    if (avgpool) {
+      float v[8];
+      ld8<T>(xs + (int64_t)po * C, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[e] - mean[e]) * rstd[e];
+        const float g = xh > 0.f ? davg[e] : 0.f;
+        s1[e] += g; s2[e] += g * xh;
+      }
+    } else {
+      const int oy = po / Wo, ox = po - oy * Wo;
+      float d[8], best[8];
+      ld8<T>(dyp + ((int64_t)s * Ho * Wo + po) * C + c0 + cv * 8, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[8];
+        ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (best[e] - mean[e]) * rstd[e];
+        const float g = xh > 0.f ? d[e] : 0.f;
+        s1[e] += g; s2[e] += g * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s1[e] = reduce_same_cv8(s1[e], sm) / HW;
+    s2[e] = reduce_same_cv8(s2[e], sm) / HW;
+  }
+  // pass 2: write dx
+  for (int po = slot; po < nwin; po += 32) {
+    if (avgpool) {
+      float v[8], o[8];
+      ld8<T>(xs + (int64_t)po * C, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[e] - mean[e]) * rstd[e];
+        const float g = xh > 0.f ? davg[e] : 0.f;
+        o[e] = rstd[e] * (g - s1[e] - xh * s2[e]);
+      }
+      st8<T>(dxs + (int64_t)po * C, o);
+    } else {
+      const int oy = po / Wo, ox = po - oy * Wo;
+      float d[8], v[4][8];
+      int arg[8];
+      float best[8];
+      ld8<T>(dyp + ((int64_t)s * Ho * Wo + po) * C + c0 + cv * 8, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v[q]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (v[q][e] > best[e]) { best[e] = v[q][e]; arg[e] = q; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[q][e] - mean[e]) * rstd[e];
+          const float g = (arg[e] == q && xh > 0.f) ? d[e] : 0.f;
+          o[e] = rstd[e] * (g - s1[e] - xh * s2[e]);
+        }
+        st8<T>(dxs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, o);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int countr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                                    float* rstd, int rows, int D, float eps, int out_bf16, void* stream) {
+  if (!x || !gamma || !beta || !y || D % 4 || D > 2048 || rows <= 0) { countr_set_error("countr_layernorm_fwd: bad args (need D % 4 == 0, D <= 2048)"); return -1; }
+  dim3 grid((rows + 3) / 4), block(256);
+  if (out_bf16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), x, gamma, beta, (bf16_t*)y, mean, rstd, rows, D, eps);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, block, 0, STREAM(stream), x, gamma, beta, (float*)y, mean, rstd, rows, D, eps);
+  COUNTR_LAUNCH_CHECK("countr_layernorm_fwd");
+}
+
+extern "C" int countr_layernorm_bwd_nblocks(void) { return 256; }
+
+extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                    float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int D,
+                                    int dy_bf16, int accumulate_dx, int accumulate_dgb, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace || D % 4 || D > 2048) { countr_set_error("countr_layernorm_bwd: bad args"); return -1; }
+  const int nb = 256;
+  const size_t lds = (size_t)4 * 2 * D * sizeof(float);
+  if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
+  // workspace is [nb][2][D]: row p holds {dgamma[D], dbeta[D]} -> treat as nb parts of 2D columns
+  // dgamma and dbeta are separate outputs: reduce the two halves separately via strided views
+  if (dgamma && dbeta) {
+    // parts are 2*D apart; reuse the kernel with C = 2*D when dgamma/dbeta are contiguous, else two passes
+    if (dbeta == dgamma + D) {
+      hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, 2 * D, (int64_t)2 * D, accumulate_dgb);
+    } else {
+      countr_set_error("countr_layernorm_bwd: dbeta must directly follow dgamma in memory");
+      return -1;
+    }
+  }
+  COUNTR_LAUNCH_CHECK("countr_layernorm_bwd");
+}
+
+extern "C" int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream) {
+  if (!partial || !out) { countr_set_error("countr_colsum_partials: null"); return -1; }
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, STREAM(stream), partial, out, nparts, C, (int64_t)C, accumulate);
+  COUNTR_LAUNCH_CHECK("countr_colsum_partials");
+}
+
+static int gn_splits(int HW) { int ns = HW / 576; if (ns < 1) ns = 1; if (ns > 64) ns = 64; return ns; }
+extern "C" int countr_groupnorm_nsplit(int HW) { return gn_splits(HW); }
+
+extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
+                                         const float* b1, float* out1, float* stats, float* workspace, int B, int HW, int C,
+                                         int G, float eps, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !stats || !workspace || C != GN_C || G > 32 || (GN_C / G) % 8 || (!y && !w1)) { countr_set_error("countr_groupnorm_relu_fwd: bad args (C must be 256)"); return -1; }
+  const int ns = gn_splits(HW);
+  const int nblk = min((HW + 7) / 8, 512);
+  if (dtype == COUNTR_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, HW, G);
+    hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, gamma, beta, (bf16_t*)y, w1, b1, out1, stats, HW, G, ns, eps);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, HW, G);
+    hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, gamma, beta, (float*)y, w1, b1, out1, stats, HW, G, ns, eps);
+  }
+  COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_fwd");
+}
+
+// workspace: fp32 [B][ns][3][C]; dgamma/dbeta(/dw1) accumulate flag applies to all.
+extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const float* d1, const float* w1, const float* stats,
+                                         const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta,
+                                         float* dw1, float* db1, float* workspace, int B, int HW, int C, int G, int dtype,
+                                         int accumulate, void* stream) {
+  if (!x || !stats || !gamma || !beta || !dx || !workspace || C != GN_C || (!dy && !(d1 && w1))) { countr_set_error("countr_groupnorm_relu_bwd: bad args"); return -1; }
+  const int ns = gn_splits(HW);
+  const int nblk = min((HW + 7) / 8, 512);
+  if (dtype == COUNTR_BF16) {
+    hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, (bf16_t*)dx, HW, G, ns);
+  } else {
+    hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, (float*)dx, HW, G, ns);
+  }
+  // parameter gradients: partial[p] = {sum g (dbeta) [C], sum g*xhat (dgamma) [C], sum d1*y (dw1) [C]}
+  float* outs[3] = {dbeta, dgamma, dw1};
+  for (int i = 0; i < 3; ++i) {
+    if (!outs[i]) continue;
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(1), dim3(256), 0, STREAM(stream), workspace + i * GN_C, outs[i], B * ns, GN_C,
+                       (int64_t)3 * GN_C, accumulate);
+  }
+  if (db1 && d1)
+    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, STREAM(stream), d1, (int64_t)B * HW, db1, accumulate);
+  COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_bwd");
+}
+
+extern "C" int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C, int avgpool,
+                                             float eps, int dtype, void* stream) {
+  if (!x || !y || C % 64 || (H & 1) || (W & 1)) { countr_set_error("countr_instnorm_relu_pool_fwd: bad args (C % 64, even H/W)"); return -1; }
+  dim3 grid(C / 64, S), block(256);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(in_relu_pool_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, stats, H, W, C, avgpool, eps);
+  else hipLaunchKernelGGL(in_relu_pool_fwd_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, (float*)y, stats, H, W, C, avgpool, eps);
+  COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_fwd");
+}
+
+extern "C" int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H, int W,
+                                             int C, int avgpool, int dtype, void* stream) {
+  if (!x || !dyp || !stats || !dx || C % 64) { countr_set_error("countr_instnorm_relu_pool_bwd: bad args"); return -1; }
+  dim3 grid(C / 64, S), block(256);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, (bf16_t*)dx, H, W, C, avgpool);
+  else hipLaunchKernelGGL(in_relu_pool_bwd_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, (float*)dx, H, W, C, avgpool);
+  COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_bwd");
+}

@@ -83,6 +83,88 @@ int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void
 int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, int N, int perm_taps,
                          int accumulate, void* stream);
 
+
+/* -------- LayerNorm (nn.LayerNorm eps=1e-6: models_mae_cross.py:146,182; models_crossvit.py:153-155;
+ * timm Block.norm1/norm2).  x is the fp32 residual stream [rows, D]; y is fp32 or bf16.
+ * mean/rstd (fp32 [rows]) are optional outputs kept for the backward. */
+int countr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                         float* rstd, int rows, int D, float eps, int out_bf16, void* stream);
+/* dx (+)= LN backward of dy; dgamma[D] followed directly by dbeta[D] in memory (may be NULL).
+ * workspace: fp32 [countr_layernorm_bwd_nblocks()][2][D]. */
+int countr_layernorm_bwd_nblocks(void);
+int countr_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                         const float* rstd, float* dx, float* dgamma, float* dbeta, float* workspace,
+                         int rows, int D, int dy_bf16, int accumulate_dx, int accumulate_dgb, void* stream);
+int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream);
+
+/* -------- GroupNorm(8, 256) + ReLU on NHWC maps (decode_head*: models_mae_cross.py:80-100).
+ * With w1 != NULL the 1x1 conv 256->1 of decode_head3 (:99) is fused: out1[b,p] = sum_c y*w1[c] + b1 and
+ * y may be NULL.  stats: fp32 [B][G][2] (mean, rstd) output.  workspace: fp32 >= B*nsplit*3*256. */
+int countr_groupnorm_nsplit(int HW);
+int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
+                              const float* b1, float* out1, float* stats, float* workspace, int B, int HW,
+                              int C, int G, float eps, int dtype, void* stream);
+/* dy (same dtype as x) is the gradient of y, or pass dy = NULL with d1 [B,HW] fp32 + w1 for the fused head.
+ * dgamma/dbeta/dw1 [256], db1 [1] fp32 (each optional). */
+int countr_groupnorm_relu_bwd(const void* x, const void* dy, const float* d1, const float* w1,
+                              const float* stats, const float* gamma, const float* beta, void* dx,
+                              float* dgamma, float* dbeta, float* dw1, float* db1, float* workspace, int B,
+                              int HW, int C, int G, int dtype, int accumulate, void* stream);
+
+/* -------- InstanceNorm2d(affine=False) + ReLU + MaxPool2d(2) | AdaptiveAvgPool2d(1) on NHWC
+ * (decoder_proj1-4: models_mae_cross.py:47-71).  stats: fp32 [S][C][2]. */
+int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C,
+                                  int avgpool, float eps, int dtype, void* stream);
+int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H,
+                                  int W, int C, int avgpool, int dtype, void* stream);
+
+/* -------- softmax rows for the unfused attention path (models_crossvit.py:87-88) */
+int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream);
+int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,
+                       void* stream);
+
+/* -------- cross attention against S <= 8 exemplar tokens (CrossAttention.forward,
+ * models_crossvit.py:111-128; D = 512, 16 heads of 32).  q/out [B*N, D]; k, v [B*S, ldkv]. */
+int countr_xattn_fwd(const void* q, const void* k, const void* v, void* out, int B, int N, int S, int D,
+                     int heads, int ldkv, float scale, int dtype, void* stream);
+int64_t countr_xattn_bwd_workspace_floats(int B, int N, int S, int D);
+int countr_xattn_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, float* dk,
+                     float* dv, float* workspace, int B, int N, int S, int D, int heads, int ldkv, float scale,
+                     int dtype, void* stream);
+
+/* -------- data movement / elementwise */
+/* timm PatchEmbed gather (models_mae_cross.py:138): img fp32 NCHW -> patches [B*gh*gw, 3*p*p], k=(c,py,px) */
+int countr_im2patch(const float* img, void* out, int B, int H, int W, int patch, int dtype, void* stream);
+/* decoder_proj1 conv 3->64 (models_mae_cross.py:48): in fp32 NCHW [S,3,H,W], w fp32 OIHW, out NHWC */
+int countr_conv3x3_c3_fwd(const float* in, const float* w, const float* bias, void* out, int S, int H, int W,
+                          int dtype, void* stream);
+int countr_conv3x3_c3_wgrad_nblocks(void);
+/* workspace: fp32 [nblocks][64*28] */
+int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* dw, float* db, float* workspace, int S,
+                            int H, int W, int dtype, int accumulate, void* stream);
+/* F.interpolate(x2, bilinear, align_corners=False) on NHWC (models_mae_cross.py:189-196); C==1 or C%8==0 */
+int countr_upsample2x_fwd(const void* in, void* out, int B, int H, int W, int C, int dtype, void* stream);
+int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, int W, int C, int dtype, void* stream);
+int countr_gelu_bwd(const void* dh, const void* pre, void* dpre, int64_t n, int dtype, void* stream);
+/* bias gradient: out[N] (+)= column sums of x [M,N]; workspace fp32 [countr_colsum_nparts()][N] */
+int countr_colsum_nparts(void);
+int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, int accumulate,
+                  void* stream);
+/* weight shadows: mode 0 cast, 1 OIHW->OHWI, 2 conv-dgrad form Wd[ci][tap'][co] = W[co][ci][T-1-tap'] */
+int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co, int Ci, int taps, int dtype,
+                        void* stream);
+
+/* -------- loss + optimizer (FSC_finetune_cross.py:290-303, :235) */
+/* sums (fp32 [1+2B]) = {loss, pred counts[B], gt counts[B]}; dpred optional (= dloss/dpred * grad_scale) */
+int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums, int B,
+                      int HW, float grad_scale, void* stream);
+/* fused AdamW over flat fp32 buffers; up to 8 [start,end) ranges each with its weight decay.
+ * hyper_dev (optional, device fp32[4] = {lr, 1-beta1^t, 1-beta2^t, grad_scale}) overrides the scalars so a
+ * captured graph can be replayed with new values.  shadow_bf16 (optional) receives bf16(p). */
+int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
+                      const int64_t* starts, const int64_t* ends, const float* wds, float lr, float beta1,
+                      float beta2, float eps, int step, float grad_scale, const float* hyper_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

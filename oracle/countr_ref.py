@@ -121,8 +121,9 @@ def instance_norm_relu(x, eps=1e-5):
 
 
 def max_pool2(x):
-    B, C, H, W = x.shape
-    return x.reshape(B, C, H // 2, 2, W // 2, 2).amax((3, 5))
+    """nn.MaxPool2d(2) (models_mae_cross.py:51).  torch's own op is used so that the backward routes the
+    gradient to the first maximum of a window exactly like the reference (ties matter for bf16 inputs)."""
+    return F.max_pool2d(x, 2)
 
 
 def group_norm_relu(x, w, b, groups=8, eps=1e-5):

@@ -1,0 +1,322 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle's functions
+(oracle/countr_ref.py) on the same seeded inputs.  fp32 mode: <= 1e-4 rel; bf16 storage mode: tolerance
+set by bf16 rounding of inputs/outputs (2^-8), stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from countr_amd import _lib
+from oracle import countr_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DT = [(torch.float32, 0, 2e-4), (torch.bfloat16, 1, 2e-2)]
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("D", [768, 512, 1024])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_layernorm_fwd_bwd(hip, D, tdt, code, tol):
+    rows = 1157
+    x = rnd((rows, D), 1, 2.0) + 0.3
+    g = 1 + 0.1 * rnd((D,), 2)
+    b = 0.1 * rnd((D,), 3)
+    dy = rnd((rows, D), 4).to(tdt)
+    xd, gd, bd = x.cuda(), g.cuda(), b.cuda()
+    y = torch.empty((rows, D), device="cuda", dtype=tdt)
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    _lib.check(hip.countr_layernorm_fwd(P(xd), P(gd), P(bd), P(y), P(mean), P(rstd), rows, D, 1e-6, code, st()))
+    xr = x.double().requires_grad_(True)
+    gr = g.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = R.layer_norm(xr, gr, br)
+    assert relerr(y, yr) < tol
+    nb = hip.countr_layernorm_bwd_nblocks()
+    ws = torch.empty((nb, 2, D), device="cuda")
+    dx = torch.full((rows, D), 0.5, device="cuda")
+    dgb = torch.zeros((2, D), device="cuda")
+    dyd = dy.cuda()
+    _lib.check(hip.countr_layernorm_bwd(P(dyd), P(xd), P(gd), P(mean), P(rstd), P(dx), P(dgb[0]), P(dgb[1]), P(ws), rows, D,
+                                        code, 1, 0, st()))
+    yr.backward(dy.double())
+    assert relerr(dx - 0.5, xr.grad) < 1e-4
+    assert relerr(dgb[0], gr.grad) < 1e-4
+    assert relerr(dgb[1], br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("HW", [24 * 24, 96 * 96])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
+    B, Cc, G = 2, 256, 8
+    x = (rnd((B, HW, Cc), 5, 1.5) + 0.2).to(tdt)
+    g = 1 + 0.1 * rnd((Cc,), 6)
+    b = 0.1 * rnd((Cc,), 7)
+    dy = rnd((B, HW, Cc), 8).to(tdt)
+    w1 = 0.1 * rnd((Cc,), 9)
+    b1 = torch.tensor([0.05])
+    d1 = rnd((B, HW), 10)
+    ns = hip.countr_groupnorm_nsplit(HW)
+    ws = torch.empty(B * ns * 3 * Cc, device="cuda")
+    stats = torch.empty((B, G, 2), device="cuda")
+    xd, gd, bd = x.cuda(), g.cuda(), b.cuda()
+    y = torch.empty((B, HW, Cc), device="cuda", dtype=tdt)
+    _lib.check(hip.countr_groupnorm_relu_fwd(P(xd), P(gd), P(bd), P(y), None, None, None, P(stats), P(ws), B, HW, Cc, G, 1e-5,
+                                             code, st()))
+    side = int(HW ** 0.5)
+    xr = x.double().reshape(B, side, side, Cc).permute(0, 3, 1, 2).requires_grad_(True)
+    gr = g.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = R.group_norm_relu(xr, gr, br)
+    y_ref = yr.permute(0, 2, 3, 1).reshape(B, HW, Cc)
+    assert relerr(y, y_ref) < tol
+    # backward (plain)
+    dx = torch.empty_like(xd)
+    dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
+    dyd = dy.cuda()
+    _lib.check(hip.countr_groupnorm_relu_bwd(P(xd), P(dyd), None, None, P(stats), P(gd), P(bd), P(dx), P(dg), P(db), None, None,
+                                             P(ws), B, HW, Cc, G, code, 0, st()))
+    yr.backward(dy.double().reshape(B, side, side, Cc).permute(0, 3, 1, 2))
+    dx_ref = xr.grad.permute(0, 2, 3, 1).reshape(B, HW, Cc)
+    assert relerr(dx, dx_ref) < (tol if code else 5e-4)
+    assert relerr(dg, gr.grad) < 2e-3 and relerr(db, br.grad) < 2e-3
+    # fused 1x1 head forward + backward
+    out1 = torch.empty((B, HW), device="cuda")
+    w1d, b1d, d1d = w1.cuda(), b1.cuda(), d1.cuda()
+    _lib.check(hip.countr_groupnorm_relu_fwd(P(xd), P(gd), P(bd), None, P(w1d), P(b1d), P(out1), P(stats), P(ws), B, HW, Cc, G,
+                                             1e-5, code, st()))
+    xr2 = x.double().reshape(B, side, side, Cc).permute(0, 3, 1, 2).requires_grad_(True)
+    gr2 = g.double().requires_grad_(True); br2 = b.double().requires_grad_(True)
+    w1r = w1.double().requires_grad_(True); b1r = b1.double().requires_grad_(True)
+    o_ref = (R.group_norm_relu(xr2, gr2, br2) * w1r.view(1, Cc, 1, 1)).sum(1) + b1r
+    assert relerr(out1, o_ref.reshape(B, HW)) < 1e-3
+    dw1 = torch.zeros(Cc, device="cuda"); db1 = torch.zeros(1, device="cuda")
+    _lib.check(hip.countr_groupnorm_relu_bwd(P(xd), None, P(d1d), P(w1d), P(stats), P(gd), P(bd), P(dx), P(dg), P(db), P(dw1),
+                                             P(db1), P(ws), B, HW, Cc, G, code, 0, st()))
+    o_ref.backward(d1.double().reshape(B, side, side))
+    assert relerr(dx, xr2.grad.permute(0, 2, 3, 1).reshape(B, HW, Cc)) < (tol if code else 5e-4)
+    assert relerr(dg, gr2.grad) < 2e-3 and relerr(db, br2.grad) < 2e-3
+    assert relerr(dw1, w1r.grad) < 2e-3 and relerr(db1, b1r.grad) < 1e-4
+
+
+@pytest.mark.parametrize("H,Cc,avg", [(64, 64, 0), (16, 256, 0), (8, 512, 1)])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_instnorm_relu_pool(hip, H, Cc, avg, tdt, code, tol):
+    S = 3
+    x = (rnd((S, H, H, Cc), 11, 1.3) + 0.1).to(tdt)
+    xd = x.cuda()
+    oshape = (S, Cc) if avg else (S, H // 2, H // 2, Cc)
+    y = torch.empty(oshape, device="cuda", dtype=tdt)
+    stats = torch.empty((S, Cc, 2), device="cuda")
+    _lib.check(hip.countr_instnorm_relu_pool_fwd(P(xd), P(y), P(stats), S, H, H, Cc, avg, 1e-5, code, st()))
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    a = R.instance_norm_relu(xr)
+    yr = a.mean((2, 3)) if avg else R.max_pool2(a).permute(0, 2, 3, 1)
+    assert relerr(y, yr) < tol
+    dyp = rnd(oshape, 12).to(tdt)
+    dx = torch.empty_like(xd)
+    dypd = dyp.cuda()
+    _lib.check(hip.countr_instnorm_relu_pool_bwd(P(xd), P(dypd), P(stats), P(dx), S, H, H, Cc, avg, code, st()))
+    yr.backward(dyp.double())
+    assert relerr(dx, xr.grad.permute(0, 2, 3, 1)) < (tol if code else 5e-4)
+
+
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_softmax_fwd_bwd(hip, tdt, code, tol):
+    rows, n = 2 * 16 * 576, 576
+    s = rnd((rows, n), 13, 3.0)
+    sd = s.cuda()
+    p = torch.empty((rows, n), device="cuda", dtype=tdt)
+    _lib.check(hip.countr_softmax_fwd(P(sd), P(p), rows, n, code, st()))
+    sr = s.double().requires_grad_(True)
+    pr = torch.softmax(sr, -1)
+    assert relerr(p, pr) < tol
+    dp = rnd((rows, n), 14)
+    ds = torch.empty_like(p)
+    dpd = dp.cuda()
+    _lib.check(hip.countr_softmax_bwd(P(p), P(dpd), P(ds), rows, n, 0.25, code, st()))
+    pp = p.double().cpu()
+    ref = pp * (dp.double() - (pp * dp.double()).sum(-1, keepdim=True)) * 0.25
+    assert relerr(ds, ref) < tol
+
+
+@pytest.mark.parametrize("S", [1, 3, 8])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_cross_attention_fwd_bwd(hip, S, tdt, code, tol):
+    B, N, D, Hh = 2, 576, 512, 16
+    q = rnd((B, N, D), 15).to(tdt)
+    k = rnd((B, S, D), 16).to(tdt)
+    v = rnd((B, S, D), 17).to(tdt)
+    do = rnd((B, N, D), 18).to(tdt)
+    qd, kd, vd, dod = q.cuda(), k.cuda(), v.cuda(), do.cuda()
+    o = torch.empty_like(qd)
+    scale = 32 ** -0.5
+    _lib.check(hip.countr_xattn_fwd(P(qd), P(kd), P(vd), P(o), B, N, S, D, Hh, D, scale, code, st()))
+    qr = q.double().requires_grad_(True); kr = k.double().requires_grad_(True); vr = v.double().requires_grad_(True)
+    qh = qr.reshape(B, N, Hh, 32).transpose(1, 2)
+    kh = kr.reshape(B, S, Hh, 32).transpose(1, 2)
+    vh = vr.reshape(B, S, Hh, 32).transpose(1, 2)
+    a = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    oref = (a @ vh).transpose(1, 2).reshape(B, N, D)
+    assert relerr(o, oref) < tol
+    dq = torch.empty_like(qd)
+    dk = torch.empty((B, S, D), device="cuda"); dv = torch.empty((B, S, D), device="cuda")
+    ws = torch.empty(hip.countr_xattn_bwd_workspace_floats(B, N, S, D), device="cuda")
+    _lib.check(hip.countr_xattn_bwd(P(qd), P(kd), P(vd), P(dod), P(dq), P(dk), P(dv), P(ws), B, N, S, D, Hh, D, scale, code, st()))
+    oref.backward(do.double())
+    assert relerr(dq, qr.grad) < tol
+    assert relerr(dk, kr.grad) < 1e-3 and relerr(dv, vr.grad) < 1e-3
+
+
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_im2patch_and_c3conv(hip, tdt, code, tol):
+    B = 2
+    img = torch.rand((B, 3, 384, 384), generator=torch.Generator().manual_seed(19))
+    out = torch.empty((B * 576, 768), device="cuda", dtype=tdt)
+    imgd = img.cuda()
+    _lib.check(hip.countr_im2patch(P(imgd), P(out), B, 384, 384, 16, code, st()))
+    ref = img.reshape(B, 3, 24, 16, 24, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * 576, 768)
+    assert relerr(out, ref) < (1e-7 if code == 0 else 4e-3)
+    # first exemplar conv
+    S = 4
+    bx = torch.rand((S, 3, 64, 64), generator=torch.Generator().manual_seed(20))
+    w = rnd((64, 3, 3, 3), 21, 0.2); bias = rnd((64,), 22, 0.1)
+    y = torch.empty((S, 64, 64, 64), device="cuda", dtype=tdt)
+    bxd, wd, bd = bx.cuda(), w.cuda(), bias.cuda()
+    _lib.check(hip.countr_conv3x3_c3_fwd(P(bxd), P(wd), P(bd), P(y), S, 64, 64, code, st()))
+    wr = w.double().requires_grad_(True); br = bias.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(bx.double(), wr, br, padding=1)
+    assert relerr(y, yr.permute(0, 2, 3, 1)) < tol
+    dy = rnd((S, 64, 64, 64), 23).to(tdt)
+    dw = torch.zeros_like(wd); db = torch.zeros_like(bd)
+    ws = torch.empty(hip.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28, device="cuda")
+    dyd = dy.cuda()
+    _lib.check(hip.countr_conv3x3_c3_wgrad(P(bxd), P(dyd), P(dw), P(db), P(ws), S, 64, 64, code, 0, st()))
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    assert relerr(dw, wr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("Cc", [256, 1])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_upsample2x_fwd_bwd(hip, Cc, tdt, code, tol):
+    B, H, W = 2, 24, 20
+    x = rnd((B, H, W, Cc), 24).to(tdt)
+    xd = x.cuda()
+    y = torch.empty((B, 2 * H, 2 * W, Cc), device="cuda", dtype=tdt)
+    _lib.check(hip.countr_upsample2x_fwd(P(xd), P(y), B, H, W, Cc, code, st()))
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = R.upsample2x(xr)
+    ref_t = torch.nn.functional.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    assert relerr(yr, ref_t) < 1e-12  # oracle restatement == torch semantics
+    assert relerr(y, yr.permute(0, 2, 3, 1)) < tol
+    dy = rnd((B, 2 * H, 2 * W, Cc), 25).to(tdt)
+    dx = torch.empty_like(xd)
+    dyd = dy.cuda()
+    _lib.check(hip.countr_upsample2x_bwd(P(dyd), P(dx), B, H, W, Cc, code, st()))
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    assert relerr(dx, xr.grad.permute(0, 2, 3, 1)) < tol
+
+
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_gelu_bwd_colsum(hip, tdt, code, tol):
+    M, N = 1152, 2048
+    pre = rnd((M, N), 26, 1.5).to(tdt)
+    dh = rnd((M, N), 27).to(tdt)
+    pred, dhd = pre.cuda(), dh.cuda()
+    out = torch.empty_like(pred)
+    _lib.check(hip.countr_gelu_bwd(P(dhd), P(pred), P(out), M * N, code, st()))
+    pr = pre.double().requires_grad_(True)
+    R.gelu(pr).backward(dh.double())
+    assert relerr(out, pr.grad) < tol
+    cs = torch.ones(N, device="cuda")
+    ws = torch.empty(hip.countr_colsum_nparts() * N, device="cuda")
+    _lib.check(hip.countr_colsum(P(dhd), P(cs), P(ws), M, N, code, 1, st()))
+    assert relerr(cs, dh.double().sum(0) + 1) < 1e-4
+
+
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_conv_dgrad_via_permuted_weights(hip, tdt, code, tol):
+    # cast_permute mode 1 (OHWI) feeds the forward conv; mode 2 (dgrad form) turns dgrad into a forward conv
+    B, H, W, Ci, Co = 2, 12, 12, 128, 256
+    w = rnd((Co, Ci, 3, 3), 28, 0.05)
+    wd = w.cuda()
+    w_f = torch.empty((Co, 9, Ci), device="cuda", dtype=tdt)
+    w_d = torch.empty((Ci, 9, Co), device="cuda", dtype=tdt)
+    _lib.check(hip.countr_cast_permute(P(wd), P(w_f), w.numel(), 1, Co, Ci, 9, code, st()))
+    _lib.check(hip.countr_cast_permute(P(wd), P(w_d), w.numel(), 2, Co, Ci, 9, code, st()))
+    assert relerr(w_f, w.permute(0, 2, 3, 1).reshape(Co, 9, Ci)) < 5e-3
+    dy = rnd((B, H, W, Co), 29).to(tdt)
+    dyd = dy.cuda()
+    dx = torch.empty((B * H * W, Ci), device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C = dyd.data_ptr(), w_d.data_ptr(), dx.data_ptr()
+    a.ldb, a.ldc = 9 * Co, Ci
+    a.M, a.N, a.K = B * H * W, Ci, 9 * Co
+    a.H, a.W, a.Cin = H, W, Co
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1; a.alpha = 1.0
+    _lib.check(hip.countr_gemm(C.byref(a), code, 2, 0, st()))
+    wq = w_f.double().cpu().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)  # weights as the kernel sees them
+    xr = torch.zeros((B, Ci, H, W), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xr, wq, None, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    assert relerr(dx, xr.grad.permute(0, 2, 3, 1).reshape(B * H * W, Ci)) < 1e-4
+
+
+def test_masked_mse_and_adamw(hip):
+    B, HW = 3, 384 * 384
+    g = torch.Generator().manual_seed(30)
+    pred = torch.rand((B, HW), generator=g); gt = torch.rand((B, HW), generator=g)
+    mask = (torch.rand(HW, generator=g) < 0.8).float()
+    pd, gd, md = pred.cuda(), gt.cuda(), mask.cuda()
+    dp = torch.empty_like(pd)
+    sums = torch.empty(1 + 2 * B, device="cuda")
+    _lib.check(hip.countr_masked_mse(P(pd), P(gd), P(md), P(dp), P(sums), B, HW, 1.0, st()))
+    pr = pred.double().requires_grad_(True)
+    loss = R.masked_mse_loss(pr.reshape(B, 384, 384), gt.double().reshape(B, 384, 384), mask.double().reshape(384, 384))
+    loss.backward()
+    assert abs(sums[0].item() - loss.item()) < 1e-5 * loss.item()
+    assert relerr(dp, pr.grad) < 1e-5
+    assert relerr(sums[1:1 + B], R.counts(pred.double())) < 1e-5
+    assert relerr(sums[1 + B:], R.counts(gt.double())) < 1e-5
+    # AdamW: 3 steps, two ranges (wd / no wd), scalars and device-hyper forms
+    n = 100003
+    p0 = rnd((n,), 31); p = p0.cuda().clone()
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    shadow = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    pr_, mr, vr = p0.double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    starts = (C.c_int64 * 2)(0, 60000); ends = (C.c_int64 * 2)(60000, n); wds = (C.c_float * 2)(0.05, 0.0)
+    for step in range(1, 4):
+        gsteps = rnd((n,), 40 + step)
+        gdev = gsteps.cuda()
+        lr = 1e-3 * step
+        if step < 3:
+            _lib.check(hip.countr_adamw_step(P(p), P(gdev), P(m), P(v), P(shadow), 2, starts, ends, wds, lr, 0.9, 0.95, 1e-8,
+                                             step, 1.0, None, st()))
+        else:
+            hyper = torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 1.0], device="cuda")
+            _lib.check(hip.countr_adamw_step(P(p), P(gdev), P(m), P(v), P(shadow), 2, starts, ends, wds, 0.0, 0.9, 0.95, 1e-8,
+                                             0, 0.0, P(hyper), st()))
+        a, ma, va = R.adamw_step(pr_[:60000], gsteps.double()[:60000], mr[:60000], vr[:60000], step, lr, wd=0.05)
+        b, mb, vb = R.adamw_step(pr_[60000:], gsteps.double()[60000:], mr[60000:], vr[60000:], step, lr, wd=0.0)
+        pr_, mr, vr = torch.cat([a, b]), torch.cat([ma, mb]), torch.cat([va, vb])
+        assert relerr(p, pr_) < 1e-5
+    assert relerr(shadow, pr_) < 5e-3
