@@ -233,9 +233,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   int kstart = 0, kend = g.K;
   int64_t offA = 0, offB = 0, offC = 0;
   const int z = blockIdx.z;
-  if (g.splitk > 1) {
+  const bool split = g.partial != nullptr;  // raw fp32 partial sums (split-K, also with splitk == 1)
+  if (split) {
+    const int nsplit = g.splitk > 1 ? g.splitk : 1;
     const int tiles = (g.K + BK - 1) / BK;
-    const int per = (tiles + g.splitk - 1) / g.splitk;
+    const int per = (tiles + nsplit - 1) / nsplit;
     kstart = z * per * BK;
     kend = min(g.K, kstart + per * BK);
   } else if (g.nbatch > 1) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   for (int tm = 0; tm < 4; ++tm) {
     const int m = m0 + wm0 + tm * 16 + li;
     if (m >= g.M) continue;
-    if (g.splitk > 1) {
+    if (split) {
       float* dst = g.partial + ((int64_t)z * g.M + m) * g.N + nb;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
 template <typename T, int MA, int MB>
 int launch(const countr_gemm_args& a, hipStream_t s) {
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
-  const int zdim = a.splitk > 1 ? a.splitk : (a.nbatch > 1 ? a.nbatch : 1);
+  const int zdim = a.partial ? (a.splitk > 1 ? a.splitk : 1) : (a.nbatch > 1 ? a.nbatch : 1);
   dim3 grid(tilesM * tilesN, 1, zdim);
   static bool attr_set = false;
   if (!attr_set) {
@@ -427,8 +429,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 }  // namespace
 
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
-  if (!a || !a->A || !a->B || (!a->C && a->splitk <= 1)) { countr_set_error("countr_gemm: null pointer"); return -1; }
-  if (a->splitk > 1 && (!a->partial || a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
+  if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
+  if ((a->splitk > 1 && !a->partial) || (a->partial && a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
   const int epc = dtype == COUNTR_BF16 ? 8 : 4;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->N & 3)) { countr_set_error("countr_gemm: bad shape (need N % 4 == 0)"); return -1; }
   if ((modeA == COUNTR_OP_ROW || modeB == COUNTR_OP_ROW) && (a->K % epc)) { countr_set_error("countr_gemm: K must be a multiple of the 16-byte chunk"); return -1; }

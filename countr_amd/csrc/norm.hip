@@ -593,17 +593,9 @@ extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float*
   const size_t lds = (size_t)4 * 2 * D * sizeof(float);
   if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
-  // workspace is [nb][2][D]: row p holds {dgamma[D], dbeta[D]} -> treat as nb parts of 2D columns
-  // dgamma and dbeta are separate outputs: reduce the two halves separately via strided views
-  if (dgamma && dbeta) {
-    // parts are 2*D apart; reuse the kernel with C = 2*D when dgamma/dbeta are contiguous, else two passes
-    if (dbeta == dgamma + D) {
-      hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, 2 * D, (int64_t)2 * D, accumulate_dgb);
-    } else {
-      countr_set_error("countr_layernorm_bwd: dbeta must directly follow dgamma in memory");
-      return -1;
-    }
-  }
+  // workspace rows are {dgamma[D], dbeta[D]} per block
+  if (dgamma) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, D, (int64_t)2 * D, accumulate_dgb);
+  if (dbeta) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, STREAM(stream), workspace + D, dbeta, nb, D, (int64_t)2 * D, accumulate_dgb);
   COUNTR_LAUNCH_CHECK("countr_layernorm_bwd");
 }
 

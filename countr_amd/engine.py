@@ -1,0 +1,681 @@
+"""Static-plan execution engine for the CounTR SupervisedMAE hot path on MI355X.
+
+PyTorch is used only for device memory and streams.  For every (batch, shot_num, train) configuration
+the engine builds ONE launch list over pre-allocated buffers (no allocation, no host sync inside), so a
+whole forward / finetune step can be replayed from a hipGraph.  All math runs in libcountr_hip.so.
+
+Mirrors (file:line of the reference):
+  forward_encoder  models_mae_cross.py:136-148      forward_decoder  models_mae_cross.py:150-199
+  Block            timm 0.4.9 / models_crossvit.py:69-94   CrossAttentionBlock models_crossvit.py:130-156
+  loss / step      FSC_finetune_cross.py:286-316, util/misc.py:266-280 (no GradScaler: bf16 needs none)
+Layouts: tokens [B*N, C]; feature maps NHWC; parameters live in one flat fp32 buffer (frozen region, then
+the trainable decoder-side region ordered by backward completion so that gradient buckets are contiguous).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL, ACT_NONE, ACT_GELU, GemmArgs
+
+ALIGN = 64  # elements; every tensor starts on a 256-byte boundary of the flat buffers
+
+
+def is_trainable(name):
+    """Encoder runs under no_grad (models_mae_cross.py:204-205); pos-embeds are frozen (:30,42)."""
+    if name in ("pos_embed", "decoder_pos_embed"):
+        return False
+    return name.startswith(("decoder_", "decode_head", "shot_token"))
+
+
+def no_weight_decay(name, shape):
+    """timm.optim.optim_factory.add_weight_decay (call site FSC_finetune_cross.py:234)."""
+    return len(shape) == 1 or name.endswith(".bias")
+
+
+def _bucket(name):
+    if name.startswith(("decode_head", "decoder_norm")):
+        return 0
+    if name.startswith(("decoder_blocks", "decoder_embed")):
+        return 1
+    if name.startswith("decoder_proj"):
+        return 2
+    return 3  # shot_token
+
+
+class ParamLayout:
+    """Offsets of every state-dict tensor inside the flat buffers."""
+
+    def __init__(self, named_shapes):
+        self.shapes = dict(named_shapes)
+        frozen = [n for n, _ in named_shapes if not is_trainable(n)]
+        train = [n for n, _ in named_shapes if is_trainable(n)]
+        train.sort(key=lambda n: (_bucket(n), 0 if no_weight_decay(n, self.shapes[n]) else 1))
+        self.order = frozen + train
+        self.off = {}
+        o = 0
+        for n in frozen:
+            self.off[n] = o
+            o += -(-math.prod(self.shapes[n]) // ALIGN) * ALIGN
+        self.train_start = o
+        self.segments = []  # (bucket, nodecay?, start, end) relative to train_start, contiguous
+        for n in train:
+            self.off[n] = o
+            sz = -(-math.prod(self.shapes[n]) // ALIGN) * ALIGN
+            key = (_bucket(n), no_weight_decay(n, self.shapes[n]))
+            if self.segments and self.segments[-1][0] == key:
+                self.segments[-1][2] = o + sz - self.train_start
+            else:
+                self.segments.append([key, o - self.train_start, o + sz - self.train_start])
+            o += sz
+        self.total = o
+        self.n_train = o - self.train_start
+        self.train_names = train
+        self.frozen_names = frozen
+
+    def bucket_range(self, bucket):
+        segs = [s for s in self.segments if s[0][0] == bucket]
+        return (segs[0][1], segs[-1][2]) if segs else (0, 0)
+
+
+class _Fake:
+    """Stand-in tensor used by the sizing pass of a plan build (no memory is touched)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def data_ptr(self):
+        return 0
+
+    def element_size(self):
+        return torch.empty((), dtype=self.dtype).element_size()
+
+
+class Plan:
+    """Launch lists + buffers for one (B, S, train) configuration."""
+
+    def __init__(self):
+        self.fwd = []
+        self.bwd_head = []   # backward until bucket 0 (head + decoder_norm) gradients are final
+        self.bwd_rest = []
+        self.buf = {}
+
+
+class Engine:
+    def __init__(self, cfg, named_shapes, device, precision="bf16", img_size=384, attention="auto"):
+        """cfg = (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads)."""
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.CountrError("the CounTR HIP engine needs a GPU device (no CPU fallback)")
+        _lib.check(self.L.countr_init(self.device.index or 0), "countr_init")
+        self.cfg = cfg
+        self.patch, self.D, self.depth, self.H, self.Dd, self.ddepth, self.Hd = cfg
+        self.img = img_size
+        self.grid = img_size // self.patch
+        self.N = self.grid * self.grid
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        self.code = BF16 if precision == "bf16" else F32
+        self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.attention = attention
+        self.layout = ParamLayout(named_shapes)
+        lay = self.layout
+        self.P = torch.zeros(lay.total, device=self.device, dtype=torch.float32)
+        self.G = torch.zeros(lay.n_train, device=self.device, dtype=torch.float32)
+        self.M = None  # AdamW state, allocated on first optimizer use
+        self.V = None
+        self.Wt = self.P if precision == "fp32" else torch.zeros(lay.total, device=self.device, dtype=torch.bfloat16)
+        # permuted conv-weight shadows: OHWI for the forward/wgrad implicit GEMM, "dgrad form" for dgrad
+        self.conv_names = ["decoder_proj%d.0.weight" % i for i in (2, 3, 4)] + ["decode_head%d.0.weight" % i for i in range(4)]
+        self.Wf, self.Wd = {}, {}
+        for n in self.conv_names:
+            numel = math.prod(lay.shapes[n])
+            self.Wf[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
+            self.Wd[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
+        self.plans = {}
+        self.hyper = torch.zeros(4, device=self.device, dtype=torch.float32)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.step_count = 0
+        self._ws = {}
+        self._need = {}
+        self._sizing = False
+
+    # ------------------------------------------------------------------ parameter views
+    def pview(self, name):
+        o = self.layout.off[name]
+        shp = self.layout.shapes[name]
+        return self.P[o:o + math.prod(shp)].view(shp)
+
+    def gview(self, name):
+        o = self.layout.off[name] - self.layout.train_start
+        shp = self.layout.shapes[name]
+        return self.G[o:o + math.prod(shp)].view(shp)
+
+    def _pp(self, name):  # fp32 master pointer
+        return self.P.data_ptr() + 4 * self.layout.off[name]
+
+    def _wp(self, name):  # GEMM-operand (T) pointer of a linear weight
+        return self.Wt.data_ptr() + self.Wt.element_size() * self.layout.off[name]
+
+    def _gp(self, name):
+        return self.G.data_ptr() + 4 * (self.layout.off[name] - self.layout.train_start)
+
+    def sync_weights(self, trainable_only=False, stream=None):
+        """Refresh the low-precision / permuted shadows from the fp32 master buffer."""
+        st = self._stream() if stream is None else stream
+        L, lay = self.L, self.layout
+        if self.precision == "bf16":
+            lo = lay.train_start if trainable_only else 0
+            _lib.check(L.countr_cast_permute(self.P.data_ptr() + 4 * lo, self.Wt.data_ptr() + 2 * lo, lay.total - lo, 0, 0, 0, 0,
+                                             BF16, st), "cast")
+        for n in self.conv_names:
+            co, ci, kh, kw = lay.shapes[n]
+            numel = co * ci * kh * kw
+            _lib.check(L.countr_cast_permute(self._pp(n), self.Wf[n].data_ptr(), numel, 1, co, ci, kh * kw, self.code, st), "perm")
+            _lib.check(L.countr_cast_permute(self._pp(n), self.Wd[n].data_ptr(), numel, 2, co, ci, kh * kw, self.code, st), "perm")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ plan helpers
+    def _alloc(self, plan, key, shape, dtype):
+        if self._sizing:
+            return _Fake(dtype)
+        t = torch.empty(shape, device=self.device, dtype=dtype)
+        plan.buf[key] = t
+        return t
+
+    def _shared(self, key, numel, dtype=torch.float32):
+        """Scratch shared by all plans.  A sizing pass records the maximum request; the real pass then finds
+        the buffer already large enough, so pointers baked into launch lists stay valid."""
+        if self._sizing:
+            old = self._need.get(key, (0, dtype))
+            self._need[key] = (max(old[0], int(numel)), dtype)
+            return _Fake(dtype)
+        cur = self._ws[key]
+        assert cur.numel() >= numel and cur.dtype == dtype, key
+        return cur
+
+    def _reserve(self):
+        grew = False
+        for key, (numel, dtype) in self._need.items():
+            cur = self._ws.get(key)
+            if cur is None or cur.numel() < numel or cur.dtype != dtype:
+                self._ws[key] = torch.empty(max(numel, 1), device=self.device, dtype=dtype)
+                grew = True
+        if grew:
+            self.plans.clear()  # launch lists of older plans hold pointers into the replaced scratch
+
+    def _gemm(self, ops, dtype_code, ma, mb, **kw):
+        a = GemmArgs()
+        a.alpha = 1.0
+        a.nbatch = 1
+        a.nb1 = 1
+        a.splitk = 1
+        for k, v in kw.items():
+            setattr(a, k, v)
+        ops.append((self.L.countr_gemm, (C.byref(a), dtype_code, ma, mb), a))
+
+    def _op(self, ops, fn, *args):
+        ops.append((fn, args, None))
+
+    def run(self, ops, stream=None):
+        st = self._stream() if stream is None else stream
+        for fn, args, _keep in ops:
+            rc = fn(*args, st)
+            if rc != 0:
+                _lib.check(rc, getattr(fn, "__name__", "countr op"))
+
+    # linear forward: out = act(x W^T + b) (+ resid)
+    def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True):
+        out_bf16 = (out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        self._gemm(ops, self.code, OP_ROW, OP_ROW, A=x.data_ptr(), B=self._wp(wname), C=out.data_ptr(),
+                   C2=(pre.data_ptr() if pre is not None else None),
+                   bias=(self._pp(wname[:-6] + "bias") if bias else None),
+                   resid=(resid if isinstance(resid, int) else (resid.data_ptr() if resid is not None else None)),
+                   lda=K, ldb=K, ldc=N, ldres=N, M=M, N=N, K=K, res_mod=res_mod, act=act, out_bf16=int(out_bf16))
+
+    def _splitk(self, tiles, ktiles):
+        sk = max(1, min(64, ktiles, int(round(768.0 / max(tiles, 1)))))
+        return sk
+
+    # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
+    def _linear_wgrad(self, ops, dy, x, wname, M, N, K, lddy=None, ldx=None):
+        lddy = N if lddy is None else lddy
+        ldx = K if ldx is None else ldx
+        bk = 64 if self.code == BF16 else 32
+        tiles = -(-N // 128) * -(-K // 128)
+        sk = self._splitk(tiles, -(-M // bk))
+        part = self._shared("splitk", sk * N * K)
+        self._gemm(ops, self.code, OP_COL, OP_COL, A=dy.data_ptr() if not isinstance(dy, int) else dy,
+                   B=x.data_ptr() if not isinstance(x, int) else x, partial=part.data_ptr(), lda=lddy, ldb=ldx, ldc=K,
+                   M=N, N=K, K=M, splitk=sk)
+        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, 0)
+
+    def _bias_grad(self, ops, dy, bname, M, N):
+        ws = self._shared("colsum", 32 * 4096)
+        self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, 0)
+
+    def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None):
+        """dx[M,K] = dy[M,N] W[N,K] (+ resid)."""
+        out_bf16 = (dx.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        self._gemm(ops, self.code, OP_ROW, OP_COL, A=dy.data_ptr(), B=self._wp(wname), C=dx.data_ptr(),
+                   resid=(resid.data_ptr() if resid is not None else None), lda=N, ldb=K, ldc=K, ldres=K, M=M, N=K, K=N,
+                   out_bf16=int(out_bf16))
+
+    def _cast(self, ops, src_f32, dst_t, n):
+        if self.code == F32:
+            return src_f32
+        self._op(ops, self.L.countr_cast_permute, src_f32.data_ptr(), dst_t.data_ptr(), n, 0, 0, 0, 0, BF16)
+        return dst_t
+
+    def _layernorm(self, ops, x, name, y, rows, D, mean=None, rstd=None):
+        self._op(ops, self.L.countr_layernorm_fwd, x.data_ptr(), self._pp(name + ".weight"), self._pp(name + ".bias"), y.data_ptr(),
+                 mean.data_ptr() if mean is not None else None, rstd.data_ptr() if rstd is not None else None, rows, D, 1e-6,
+                 int(y.dtype == torch.bfloat16))
+
+    def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate):
+        ws = self._shared("lnbwd", 256 * 2 * 2048)
+        self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
+                 rstd.data_ptr(), dx.data_ptr(), self._gp(name + ".weight"), self._gp(name + ".bias"), ws.data_ptr(), rows, D,
+                 int(dy.dtype == torch.bfloat16), int(accumulate), 0)
+
+    # unfused self-attention forward on a packed qkv [rows, 3*Dm]
+    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None):
+        N, dh = self.N, Dm // heads
+        scale = dh ** -0.5
+        scores = self._shared("scores", B * heads * N * N)
+        if probs is None:
+            probs = self._shared("probs", B * heads * N * N, self.tdt)
+        es = qkv.element_size()
+        self._gemm(ops, self.code, OP_ROW, OP_ROW, A=qkv.data_ptr(), B=qkv.data_ptr() + Dm * es, C=scores.data_ptr(),
+                   lda=3 * Dm, ldb=3 * Dm, ldc=N, M=N, N=N, K=dh, nbatch=B * heads, nb1=heads, sA0=N * 3 * Dm, sA1=dh,
+                   sB0=N * 3 * Dm, sB1=dh, sC0=heads * N * N, sC1=N * N, alpha=scale, out_bf16=0)
+        self._op(ops, self.L.countr_softmax_fwd, scores.data_ptr(), probs.data_ptr(), B * heads * N, N, int(self.code == BF16))
+        self._gemm(ops, self.code, OP_ROW, OP_COL, A=probs.data_ptr(), B=qkv.data_ptr() + 2 * Dm * es, C=out.data_ptr(),
+                   lda=N, ldb=3 * Dm, ldc=Dm, M=N, N=dh, K=N, nbatch=B * heads, nb1=heads, sA0=heads * N * N, sA1=N * N,
+                   sB0=N * 3 * Dm, sB1=dh, sC0=N * Dm, sC1=dh, out_bf16=int(self.code == BF16))
+
+    def _attention_bwd(self, ops, qkv, probs, dout, dqkv, B, heads, Dm):
+        """dout [rows, Dm] (T) -> dqkv [rows, 3*Dm] (T); probs [B,h,N,N] (T) saved by the forward."""
+        N, dh = self.N, Dm // heads
+        scale = dh ** -0.5
+        es = qkv.element_size()
+        dP = self._shared("scores", B * heads * N * N)
+        dS = self._shared("probs", B * heads * N * N, self.tdt)
+        ob = int(self.code == BF16)
+        nb = dict(nbatch=B * heads, nb1=heads)
+        # dV[j,d] = sum_i P[i,j] dO[i,d]
+        self._gemm(ops, self.code, OP_COL, OP_COL, A=probs.data_ptr(), B=dout.data_ptr(), C=dqkv.data_ptr() + 2 * Dm * es,
+                   lda=N, ldb=Dm, ldc=3 * Dm, M=N, N=dh, K=N, sA0=heads * N * N, sA1=N * N, sB0=N * Dm, sB1=dh,
+                   sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
+        # dP[i,j] = sum_d dO[i,d] V[j,d]
+        self._gemm(ops, self.code, OP_ROW, OP_ROW, A=dout.data_ptr(), B=qkv.data_ptr() + 2 * Dm * es, C=dP.data_ptr(),
+                   lda=Dm, ldb=3 * Dm, ldc=N, M=N, N=N, K=dh, sA0=N * Dm, sA1=dh, sB0=N * 3 * Dm, sB1=dh,
+                   sC0=heads * N * N, sC1=N * N, out_bf16=0, **nb)
+        self._op(ops, self.L.countr_softmax_bwd, probs.data_ptr(), dP.data_ptr(), dS.data_ptr(), B * heads * N, N, scale, self.code)
+        # dQ[i,d] = sum_j dS[i,j] K[j,d]
+        self._gemm(ops, self.code, OP_ROW, OP_COL, A=dS.data_ptr(), B=qkv.data_ptr() + Dm * es, C=dqkv.data_ptr(),
+                   lda=N, ldb=3 * Dm, ldc=3 * Dm, M=N, N=dh, K=N, sA0=heads * N * N, sA1=N * N, sB0=N * 3 * Dm, sB1=dh,
+                   sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
+        # dK[j,d] = sum_i dS[i,j] Q[i,d]
+        self._gemm(ops, self.code, OP_COL, OP_COL, A=dS.data_ptr(), B=qkv.data_ptr(), C=dqkv.data_ptr() + Dm * es,
+                   lda=N, ldb=3 * Dm, ldc=3 * Dm, M=N, N=dh, K=N, sA0=heads * N * N, sA1=N * N, sB0=N * 3 * Dm, sB1=dh,
+                   sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
+
+    # 3x3 conv (NHWC, pad 1) as implicit GEMM
+    def _conv_fwd(self, ops, x, w_ohwi, bias_ptr, out, Bn, H, W, Cin, Cout):
+        self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), C=out.data_ptr(), bias=bias_ptr,
+                   ldb=9 * Cin, ldc=Cout, M=Bn * H * W, N=Cout, K=9 * Cin, H=H, W=W, Cin=Cin,
+                   out_bf16=int(out.dtype == torch.bfloat16))
+
+    def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout):
+        bk = 64 if self.code == BF16 else 32
+        Kp = Bn * H * W
+        tiles = -(-Cout // 128) * -(-(9 * Cin) // 128)
+        sk = self._splitk(tiles, -(-Kp // bk))
+        part = self._shared("splitk", sk * Cout * 9 * Cin)
+        self._gemm(ops, self.code, OP_COL, OP_IM2COL, A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout,
+                   ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W, Cin=Cin, splitk=sk)
+        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, 0)
+
+    # ------------------------------------------------------------------ plan construction
+    def plan(self, B, S, train):
+        key = (B, S, bool(train))
+        if key not in self.plans:
+            self._sizing = True
+            try:
+                self._build(B, S, bool(train))
+            finally:
+                self._sizing = False
+            self._reserve()
+            self.plans[key] = self._build(B, S, bool(train))
+        return self.plans[key]
+
+    def _build(self, B, S, train):
+        L = self.L
+        p = Plan()
+        T, f32 = self.tdt, torch.float32
+        N, D, Dd, H, Hd = self.N, self.D, self.Dd, self.H, self.Hd
+        rows = B * N
+        code = self.code
+        ops = p.fwd
+        A = lambda k, shape, dt: self._alloc(p, k, shape, dt)
+
+        # ---------------- encoder (no grad): models_mae_cross.py:136-148
+        img = A("img", (B, 3, self.img, self.img), f32)
+        patches = A("patches", (rows, 3 * self.patch * self.patch), T)
+        x = A("x", (rows, D), f32)
+        xn = A("xn", (rows, D), T)
+        qkv = A("qkv", (rows, 3 * D), T)
+        att = A("att", (rows, D), T)
+        hid = A("hid", (rows, 4 * D), T)
+        latent = A("latent", (rows, D), T)
+        self._op(ops, L.countr_im2patch, img.data_ptr(), patches.data_ptr(), B, self.img, self.img, self.patch, code)
+        Kp = 3 * self.patch * self.patch
+        self._gemm(ops, code, OP_ROW, OP_ROW, A=patches.data_ptr(), B=self._wp("patch_embed.proj.weight"), C=x.data_ptr(),
+                   bias=self._pp("patch_embed.proj.bias"), resid=self._pp("pos_embed"), lda=Kp, ldb=Kp, ldc=D, ldres=D,
+                   M=rows, N=D, K=Kp, res_mod=N, out_bf16=0)
+        for i in range(self.depth):
+            b = "blocks.%d" % i
+            self._layernorm(ops, x, b + ".norm1", xn, rows, D)
+            self._linear(ops, xn, b + ".attn.qkv.weight", qkv, rows, 3 * D, D)
+            self._attention_fwd(ops, p, qkv, att, B, H, D)
+            self._linear(ops, att, b + ".attn.proj.weight", x, rows, D, D, resid=x)
+            self._layernorm(ops, x, b + ".norm2", xn, rows, D)
+            self._linear(ops, xn, b + ".mlp.fc1.weight", hid, rows, 4 * D, D, act=ACT_GELU)
+            self._linear(ops, hid, b + ".mlp.fc2.weight", x, rows, D, 4 * D, resid=x)
+        self._layernorm(ops, x, "norm", latent, rows, D)
+        p.enc_ops = len(ops)
+
+        # ---------------- decoder: models_mae_cross.py:150-199
+        Sy = max(S, 1)
+        xs = [A("dx0", (rows, Dd), f32)]
+        self._linear(ops, latent, "decoder_embed.weight", xs[0], rows, Dd, D, resid=self._pp("decoder_pos_embed"), res_mod=N)
+        ytok = A("ytok", (B * Sy, Dd), T)
+        if S == 0:
+            # y = shot_token broadcast over the batch (models_mae_cross.py:176): gemm-free broadcast via cast with ld trick
+            for b_ in range(B):
+                self._op(ops, L.countr_cast_permute, self._pp("shot_token"), ytok.data_ptr() + b_ * Dd * ytok.element_size(), Dd, 0, 0,
+                         0, 0, code)
+        else:
+            BS = B * S
+            boxes = A("boxes", (BS, 3, 64, 64), f32)
+            chans = [64, 128, 256, Dd]
+            sizes = [64, 32, 16, 8]
+            c = [A("c%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)]
+            pl = [A("p%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
+            stats = [A("instats%d" % (i + 1), (BS, chans[i], 2), f32) for i in range(4)]
+            self._op(ops, L.countr_conv3x3_c3_fwd, boxes.data_ptr(), self._pp("decoder_proj1.0.weight"), self._pp("decoder_proj1.0.bias"),
+                     c[0].data_ptr(), BS, 64, 64, code)
+            self._op(ops, L.countr_instnorm_relu_pool_fwd, c[0].data_ptr(), pl[0].data_ptr(), stats[0].data_ptr(), BS, 64, 64, 64, 0, 1e-5,
+                     code)
+            for i in (1, 2, 3):
+                wn = "decoder_proj%d.0.weight" % (i + 1)
+                self._conv_fwd(ops, pl[i - 1], self.Wf[wn], self._pp(wn[:-6] + "bias"), c[i], BS, sizes[i], sizes[i], chans[i - 1], chans[i])
+                last = i == 3
+                self._op(ops, L.countr_instnorm_relu_pool_fwd, c[i].data_ptr(), (ytok if last else pl[i]).data_ptr(), stats[i].data_ptr(),
+                         BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code)
+        blk = []
+        for i in range(self.ddepth):
+            b = "decoder_blocks.%d" % i
+            d = {}
+            xin = xs[-1]
+            d["n0"] = A(b + ".n0", (rows, Dd), T)
+            d["m0"], d["r0"] = A(b + ".m0", (rows,), f32), A(b + ".r0", (rows,), f32)
+            d["qkv"] = A(b + ".qkv", (rows, 3 * Dd), T)
+            d["probs"] = A(b + ".probs", (B * Hd * N * N,), T) if train else None
+            d["att"] = A(b + ".att", (rows, Dd), T)
+            self._layernorm(ops, xin, b + ".norm0", d["n0"], rows, Dd, d["m0"], d["r0"])
+            self._linear(ops, d["n0"], b + ".selfattn.qkv.weight", d["qkv"], rows, 3 * Dd, Dd)
+            self._attention_fwd(ops, p, d["qkv"], d["att"], B, Hd, Dd, probs=d["probs"])
+            x1 = A(b + ".x1", (rows, Dd), f32)
+            self._linear(ops, d["att"], b + ".selfattn.proj.weight", x1, rows, Dd, Dd, resid=xin)
+            d["n1"] = A(b + ".n1", (rows, Dd), T)
+            d["m1"], d["r1"] = A(b + ".m1", (rows,), f32), A(b + ".r1", (rows,), f32)
+            d["q"] = A(b + ".q", (rows, Dd), T)
+            d["k"] = A(b + ".k", (B * Sy, Dd), T)
+            d["v"] = A(b + ".v", (B * Sy, Dd), T)
+            d["xo"] = A(b + ".xo", (rows, Dd), T)
+            self._layernorm(ops, x1, b + ".norm1", d["n1"], rows, Dd, d["m1"], d["r1"])
+            self._linear(ops, d["n1"], b + ".attn.wq.weight", d["q"], rows, Dd, Dd)
+            self._linear(ops, ytok, b + ".attn.wk.weight", d["k"], B * Sy, Dd, Dd)
+            self._linear(ops, ytok, b + ".attn.wv.weight", d["v"], B * Sy, Dd, Dd)
+            self._op(ops, L.countr_xattn_fwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), d["xo"].data_ptr(), B, N, Sy, Dd,
+                     Hd, Dd, (Dd // Hd) ** -0.5, code)
+            x2 = A(b + ".x2", (rows, Dd), f32)
+            self._linear(ops, d["xo"], b + ".attn.proj.weight", x2, rows, Dd, Dd, resid=x1)
+            d["n2"] = A(b + ".n2", (rows, Dd), T)
+            d["m2"], d["r2"] = A(b + ".m2", (rows,), f32), A(b + ".r2", (rows,), f32)
+            d["hpre"] = A(b + ".hpre", (rows, 4 * Dd), T)
+            d["hact"] = A(b + ".hact", (rows, 4 * Dd), T)
+            self._layernorm(ops, x2, b + ".norm2", d["n2"], rows, Dd, d["m2"], d["r2"])
+            self._linear(ops, d["n2"], b + ".mlp.fc1.weight", d["hact"], rows, 4 * Dd, Dd, act=ACT_GELU, pre=d["hpre"])
+            x3 = A(b + ".x3", (rows, Dd), f32)
+            self._linear(ops, d["hact"], b + ".mlp.fc2.weight", x3, rows, Dd, 4 * Dd, resid=x2)
+            d["xin"], d["x1"], d["x2"] = xin, x1, x2
+            xs.append(x3)
+            blk.append(d)
+        dn = A("dn", (rows, Dd), T)
+        mN, rN = A("mN", (rows,), f32), A("rN", (rows,), f32)
+        self._layernorm(ops, xs[-1], "decoder_norm", dn, rows, Dd, mN, rN)
+        # density head on NHWC maps; tokens [B, N, Dd] already are [B, grid, grid, Dd]
+        g = self.grid
+        hs = [g, 2 * g, 4 * g, 8 * g]
+        cin = [Dd, 256, 256, 256]
+        hin = [dn]
+        hc, hstats = [], []
+        gn_ws = self._shared("gn", B * 64 * 3 * 256)
+        o1 = A("o1", (B, hs[3] * hs[3]), f32)
+        out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
+        hact_tmp = self._shared("hact_tmp", B * hs[2] * hs[2] * 256, T)
+        for i in range(4):
+            hn = "decode_head%d" % i
+            ci = A("hc%d" % i, (B, hs[i], hs[i], 256), T)
+            si = A("hstats%d" % i, (B, 8, 2), f32)
+            self._conv_fwd(ops, hin[i], self.Wf[hn + ".0.weight"], self._pp(hn + ".0.bias"), ci, B, hs[i], hs[i], cin[i], 256)
+            if i < 3:
+                self._op(ops, L.countr_groupnorm_relu_fwd, ci.data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"),
+                         hact_tmp.data_ptr(), None, None, None, si.data_ptr(), gn_ws.data_ptr(), B, hs[i] * hs[i], 256, 8, 1e-5, code)
+                up = A("hu%d" % i, (B, hs[i + 1], hs[i + 1], 256), T)
+                self._op(ops, L.countr_upsample2x_fwd, hact_tmp.data_ptr(), up.data_ptr(), B, hs[i], hs[i], 256, code)
+                hin.append(up)
+            else:
+                self._op(ops, L.countr_groupnorm_relu_fwd, ci.data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), None,
+                         self._pp(hn + ".3.weight"), self._pp(hn + ".3.bias"), o1.data_ptr(), si.data_ptr(), gn_ws.data_ptr(), B,
+                         hs[i] * hs[i], 256, 8, 1e-5, code)
+                self._op(ops, L.countr_upsample2x_fwd, o1.data_ptr(), out.data_ptr(), B, hs[3], hs[3], 1, F32)
+            hc.append(ci)
+            hstats.append(si)
+        if not train:
+            return p
+
+        # =========================== backward (decoder side only) ===========================
+        ops = p.bwd_head
+        dout = A("dout", (B, 2 * hs[3], 2 * hs[3]), f32)
+        d1 = A("d1", (B, hs[3] * hs[3]), f32)
+        self._op(ops, L.countr_upsample2x_bwd, dout.data_ptr(), d1.data_ptr(), B, hs[3], hs[3], 1, F32)
+        # gradient scratch for maps: dpre (grad of conv output), dup (grad of conv input)
+        dpre = self._shared("dpre", B * hs[3] * hs[3] * 256, T)
+        dup = self._shared("dup", B * hs[3] * hs[3] * 256, T)
+        dact = self._shared("dact", B * hs[2] * hs[2] * 256, T)
+        ddn = A("ddn", (rows, Dd), T)
+        for i in (3, 2, 1, 0):
+            hn = "decode_head%d" % i
+            HW = hs[i] * hs[i]
+            if i == 3:
+                self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), None, d1.data_ptr(), self._pp(hn + ".3.weight"),
+                         hstats[i].data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(),
+                         self._gp(hn + ".1.weight"), self._gp(hn + ".1.bias"), self._gp(hn + ".3.weight"), self._gp(hn + ".3.bias"),
+                         gn_ws.data_ptr(), B, HW, 256, 8, code, 0)
+            else:
+                self._op(ops, L.countr_upsample2x_bwd, dup.data_ptr(), dact.data_ptr(), B, hs[i], hs[i], 256, code)
+                self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), dact.data_ptr(), None, None, hstats[i].data_ptr(),
+                         self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), self._gp(hn + ".1.weight"),
+                         self._gp(hn + ".1.bias"), None, None, gn_ws.data_ptr(), B, HW, 256, 8, code, 0)
+            self._bias_grad(ops, dpre, hn + ".0.bias", B * HW, 256)
+            self._conv_wgrad(ops, dpre, hin[i], hn + ".0.weight", B, hs[i], hs[i], cin[i], 256)
+            # dgrad == forward conv of dpre with the dgrad-form weights (Cin_gemm = 256 output channels)
+            tgt = dup if i > 0 else ddn
+            self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dpre.data_ptr(), B=self.Wd[hn + ".0.weight"].data_ptr(), C=tgt.data_ptr(),
+                       ldb=9 * 256, ldc=cin[i], M=B * HW, N=cin[i], K=9 * 256, H=hs[i], W=hs[i], Cin=256,
+                       out_bf16=int(code == BF16))
+        gx = A("gx", (rows, Dd), f32)
+        gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
+        self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False)
+
+        ops = p.bwd_rest
+        dh = A("dh", (rows, 4 * Dd), T)
+        dn_t = A("dn_t", (rows, Dd), T)      # grad wrt a LayerNorm output
+        dproj_in = A("dproj_in", (rows, Dd), T)
+        dqkv = A("dqkv", (rows, 3 * Dd), T)
+        dq = A("dq", (rows, Dd), T)
+        dk = A("dk", (B * Sy, Dd), f32)
+        dv = A("dv", (B * Sy, Dd), f32)
+        dkT = A("dkT", (B * Sy, Dd), T) if code == BF16 else None
+        dvT = A("dvT", (B * Sy, Dd), T) if code == BF16 else None
+        dy_tok = A("dy_tok", (B * Sy, Dd), f32)
+        xws = self._shared("xattn", L.countr_xattn_bwd_workspace_floats(B, N, Sy, Dd))
+        first_tok = True
+        for i in reversed(range(self.ddepth)):
+            b = "decoder_blocks.%d" % i
+            d = blk[i]
+            # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))
+            g_t = self._cast(ops, gx, gxT, rows * Dd)
+            self._bias_grad(ops, g_t, b + ".mlp.fc2.bias", rows, Dd)
+            self._linear_wgrad(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd)
+            self._linear_dgrad(ops, g_t, b + ".mlp.fc2.weight", dh, rows, Dd, 4 * Dd)
+            self._op(ops, L.countr_gelu_bwd, dh.data_ptr(), d["hpre"].data_ptr(), dh.data_ptr(), rows * 4 * Dd, code)
+            self._bias_grad(ops, dh, b + ".mlp.fc1.bias", rows, 4 * Dd)
+            self._linear_wgrad(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd)
+            self._linear_dgrad(ops, dh, b + ".mlp.fc1.weight", dn_t, rows, 4 * Dd, Dd)
+            self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True)
+            # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
+            g_t = self._cast(ops, gx, gxT, rows * Dd)
+            self._bias_grad(ops, g_t, b + ".attn.proj.bias", rows, Dd)
+            self._linear_wgrad(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd)
+            self._linear_dgrad(ops, g_t, b + ".attn.proj.weight", dproj_in, rows, Dd, Dd)
+            self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
+                     dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code)
+            self._bias_grad(ops, dq, b + ".attn.wq.bias", rows, Dd)
+            self._linear_wgrad(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd)
+            self._linear_dgrad(ops, dq, b + ".attn.wq.weight", dn_t, rows, Dd, Dd)
+            self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True)
+            dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
+            dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
+            for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
+                self._bias_grad(ops, g_kv, b + ".attn.%s.bias" % nm, B * Sy, Dd)
+                self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd)
+                self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,
+                                   resid=(None if first_tok else dy_tok), out_bf16=False)
+                first_tok = False
+            # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
+            g_t = self._cast(ops, gx, gxT, rows * Dd)
+            self._bias_grad(ops, g_t, b + ".selfattn.proj.bias", rows, Dd)
+            self._linear_wgrad(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd)
+            self._linear_dgrad(ops, g_t, b + ".selfattn.proj.weight", dproj_in, rows, Dd, Dd)
+            self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
+            self._bias_grad(ops, dqkv, b + ".selfattn.qkv.bias", rows, 3 * Dd)
+            self._linear_wgrad(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd)
+            self._linear_dgrad(ops, dqkv, b + ".selfattn.qkv.weight", dn_t, rows, 3 * Dd, Dd)
+            self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True)
+        # ---- decoder_embed (no dgrad: the encoder is frozen)
+        g_t = self._cast(ops, gx, gxT, rows * Dd)
+        self._bias_grad(ops, g_t, "decoder_embed.bias", rows, Dd)
+        self._linear_wgrad(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
+        # ---- exemplar tokens
+        if S == 0:
+            ws = self._shared("colsum", 32 * 4096)
+            self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, 0)
+        else:
+            BS = B * S
+            dyt = A("dyt", (BS, Dd), T) if code == BF16 else None
+            g_y = self._cast(ops, dy_tok, dyt, BS * Dd)
+            dc = [A("dc%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)]
+            dpl = [A("dp%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
+            for i in (3, 2, 1, 0):
+                self._op(ops, L.countr_instnorm_relu_pool_bwd, c[i].data_ptr(), (g_y if i == 3 else dpl[i]).data_ptr(), stats[i].data_ptr(),
+                         dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code)
+                wn = "decoder_proj%d.0.weight" % (i + 1)
+                if i == 0:
+                    ws = self._shared("c3wgrad", L.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28)
+                    self._op(ops, L.countr_conv3x3_c3_wgrad, boxes.data_ptr(), dc[0].data_ptr(), self._gp(wn), self._gp(wn[:-6] + "bias"),
+                             ws.data_ptr(), BS, 64, 64, code, 0)
+                else:
+                    self._bias_grad(ops, dc[i], wn[:-6] + "bias", BS * sizes[i] * sizes[i], chans[i])
+                    self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i])
+                    self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dc[i].data_ptr(), B=self.Wd[wn].data_ptr(), C=dpl[i - 1].data_ptr(),
+                               ldb=9 * chans[i], ldc=chans[i - 1], M=BS * sizes[i] * sizes[i], N=chans[i - 1], K=9 * chans[i],
+                               H=sizes[i], W=sizes[i], Cin=chans[i], out_bf16=int(code == BF16))
+        return p
+
+    # ------------------------------------------------------------------ execution API
+    def _load_inputs(self, p, imgs, boxes, S):
+        p.buf["img"].copy_(imgs, non_blocking=True)
+        if S > 0:
+            B = imgs.shape[0]
+            p.buf["boxes"].view(B, S, 3, 64, 64).copy_(boxes[:, :S], non_blocking=True)
+
+    def forward(self, imgs, boxes, shot_num, train=False):
+        """SupervisedMAE.forward (models_mae_cross.py:201-207): returns the engine's output buffer [B, H, W]
+        (overwritten by the next call on the same plan)."""
+        B = imgs.shape[0]
+        p = self.plan(B, int(shot_num), train)
+        self._load_inputs(p, imgs, boxes, int(shot_num))
+        self.run(p.fwd)
+        return p.buf["out"]
+
+    def backward(self, B, shot_num, dout):
+        """Decoder-side backward for the last train-mode forward of plan (B, shot_num); fills self.G."""
+        p = self.plan(B, int(shot_num), True)
+        p.buf["dout"].copy_(dout, non_blocking=True)
+        self.run(p.bwd_head)
+        self.run(p.bwd_rest)
+
+    def adam_ranges(self, S, weight_decay):
+        """(start, end, wd) ranges of the trainable region touched when shot_num == S: parameters whose
+        gradient is None in the reference are skipped by AdamW (exemplar CNN for S == 0, shot_token otherwise)."""
+        out = []
+        for (bucket, nodecay), s, e in self.layout.segments:
+            if (bucket == 2 and S == 0) or (bucket == 3 and S > 0):
+                continue
+            out.append((s, e, 0.0 if nodecay else weight_decay))
+        return out
+
+    def adamw_step(self, S, lr, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, use_device_hyper=False):
+        """torch.optim.AdamW(betas=(0.9,0.95)) semantics (FSC_finetune_cross.py:235) fused over the flat buffers."""
+        if self.M is None:
+            self.M = torch.zeros_like(self.G)
+            self.V = torch.zeros_like(self.G)
+        self.step_count += 1
+        rng = self.adam_ranges(S, weight_decay)
+        n = len(rng)
+        starts = (C.c_int64 * n)(*[r[0] for r in rng])
+        ends = (C.c_int64 * n)(*[r[1] for r in rng])
+        wds = (C.c_float * n)(*[r[2] for r in rng])
+        lay = self.layout
+        shadow = (self.Wt.data_ptr() + 2 * lay.train_start) if self.precision == "bf16" else None
+        hyper = None
+        if use_device_hyper:
+            self._hyper_host[0] = lr
+            self._hyper_host[1] = 1.0 - betas[0] ** self.step_count
+            self._hyper_host[2] = 1.0 - betas[1] ** self.step_count
+            self._hyper_host[3] = grad_scale
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            hyper = self.hyper.data_ptr()
+        _lib.check(self.L.countr_adamw_step(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                            shadow, n, starts, ends, wds, lr, betas[0], betas[1], eps, self.step_count, grad_scale,
+                                            hyper, self._stream()), "adamw")
+        self._refresh_conv_shadows()
+
+    def _refresh_conv_shadows(self):
+        st = self._stream()
+        lay = self.layout
+        for n in self.conv_names:
+            co, ci, kh, kw = lay.shapes[n]
+            numel = co * ci * kh * kw
+            _lib.check(self.L.countr_cast_permute(self._pp(n), self.Wf[n].data_ptr(), numel, 1, co, ci, kh * kw, self.code, st), "perm")
+            _lib.check(self.L.countr_cast_permute(self._pp(n), self.Wd[n].data_ptr(), numel, 2, co, ci, kh * kw, self.code, st), "perm")

@@ -49,8 +49,8 @@ const char* countr_last_error(void);    /* thread-local message of the last fail
  *   C2 (optional) receives v + bias[n] before the activation (saved for GELU backward).
  * A is the M-side operand, B the N-side operand, each in one of the COUNTR_OP_* modes.
  * Batched when nbatch > 1: z = b0*nb1 + b1 adds b0*s?0 + b1*s?1 (in elements) to A, B, C.
- * Split-K when splitk > 1 (nbatch must be 1): block z handles a K range and stores raw fp32 sums
- * to partial[z][M][N]; finish with countr_splitk_reduce.
+ * Split-K when partial != NULL (nbatch must be 1): block z of max(splitk,1) handles a K range and stores
+ * raw fp32 sums to partial[z][M][N]; finish with countr_splitk_reduce.
  * Replaces: torch addmm/bmm behind nn.Linear (models_crossvit.py:62,65,84,92,115-127;
  * models_mae_cross.py:152), q@k^T / attn@v (models_crossvit.py:87,91,121,125), the PatchEmbed conv
  * (timm PatchEmbed, models_mae_cross.py:138) and the 3x3 convs (models_mae_cross.py:47-100) as
@@ -89,7 +89,7 @@ int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, in
  * mean/rstd (fp32 [rows]) are optional outputs kept for the backward. */
 int countr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
                          float* rstd, int rows, int D, float eps, int out_bf16, void* stream);
-/* dx (+)= LN backward of dy; dgamma[D] followed directly by dbeta[D] in memory (may be NULL).
+/* dx (+)= LN backward of dy; dgamma[D], dbeta[D] fp32 (may be NULL).
  * workspace: fp32 [countr_layernorm_bwd_nblocks()][2][D]. */
 int countr_layernorm_bwd_nblocks(void);
 int countr_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,

@@ -1,0 +1,164 @@
+"""GPU parity of the whole SupervisedMAE hot path (HIP engine, through the C ABI) against
+ (a) golden vectors produced by the reference itself (tests/golden, tools/oracle/make_golden.py) and
+ (b) the CPU oracle on fresh seeded inputs.
+north_star bar (fp32 mode): density maps within 1e-3 rel of the reference CPU forward, counts within +-0.5.
+bf16 mode bar: the reference's own bf16-autocast deviates 1.8e-2 rel / 6.4 counts from fp32 (BASELINE.md
+section 2, max-norm on one sample).  With bf16 activation storage end-to-end every intermediate stays within
+~0.8 % rms of the fp32 engine (tools/diag_buffers.py); the final 256->1 conv amplifies that by cancellation, most
+for shot_num == 0 whose map has the smallest magnitude.  Bars: <= 6e-2 max-norm rel, <= 3.5e-2 rms rel,
+counts within 6 % (1 % when shot_num > 0).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import countr_ref as R
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+MODEL = "mae_vit_base_patch16"
+
+
+def build(precision, seed=0, model=MODEL):
+    import models_mae_cross as mm
+    m = mm.__dict__[model](norm_pix_loss=False, precision=precision)
+    sd = W.make_state_dict(model, seed=seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to("cuda")
+    m.eval()
+    return m, sd
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.fixture(scope="module")
+def fp32_model():
+    return build("fp32")
+
+
+@pytest.fixture(scope="module")
+def bf16_model():
+    return build("bf16")
+
+
+CASES = ["b2_s3", "b1_s0", "b1_s1", "b1_s2", "b1_zero_empty"]
+
+
+def case_inputs(name):
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=0)
+    return {
+        "b2_s3": (imgs, boxes, 3),
+        "b1_s0": (imgs[:1], boxes[:1], 0),
+        "b1_s1": (imgs[1:2], boxes[1:2], 1),
+        "b1_s2": (imgs[:1], boxes[:1], 2),
+        "b1_zero_empty": (imgs[1:2], np.zeros((1, 0), np.float32), 0),
+    }[name]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_fp32_matches_reference_golden(fp32_model, name):
+    m, _ = fp32_model
+    g = np.load(os.path.join(G, "forward.npz"))
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    im, bx, s = case_inputs(name)
+    with torch.no_grad():
+        out = m(torch.from_numpy(im).cuda(), torch.from_numpy(bx).cuda(), s).cpu().numpy()
+    assert out.shape == g[name].shape
+    assert rel(out, g[name]) < 1e-3, rel(out, g[name])
+    cnt = out.reshape(out.shape[0], -1).sum(1) / 60
+    assert np.abs(cnt - np.array(meta["count_" + name])).max() < 0.5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_bf16_close_to_reference_golden(bf16_model, name):
+    m, _ = bf16_model
+    g = np.load(os.path.join(G, "forward.npz"))
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    im, bx, s = case_inputs(name)
+    with torch.no_grad():
+        out = m(torch.from_numpy(im).cuda(), torch.from_numpy(bx).cuda(), s).cpu().numpy()
+    assert rel(out, g[name]) < 6e-2, rel(out, g[name])
+    rms = np.sqrt(((out.astype(np.float64) - g[name]) ** 2).mean()) / np.sqrt((g[name].astype(np.float64) ** 2).mean())
+    assert rms < 3.5e-2, rms
+    cnt = out.reshape(out.shape[0], -1).sum(1) / 60
+    ref = np.array(meta["count_" + name])
+    assert (np.abs(cnt - ref) / ref).max() < (6e-2 if s == 0 else 1e-2)
+
+
+def test_tuple_unpack_and_encoder_surface(fp32_model):
+    m, sd = fp32_model
+    im, bx, s = case_inputs("b1_s1")
+    with torch.no_grad():
+        output, = m(torch.from_numpy(im).cuda(), torch.from_numpy(bx).cuda(), s)  # FSC_test_cross(few-shot).py:328
+        lat = m.forward_encoder(torch.from_numpy(im).cuda())
+    assert output.shape == (384, 384)
+    probes = {}
+    R.forward(R.Params(sd), im, bx, s, MODEL, probes=probes)
+    assert rel(lat.cpu().numpy(), probes["latent"].numpy()) < 1e-3
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 3, 384, 400).cuda(), torch.from_numpy(bx).cuda(), s)  # PatchEmbed size assert
+
+
+@pytest.mark.parametrize("tag,shots", [("s3", 3), ("s0", 0)])
+def test_gradients_fp32_match_reference_golden(fp32_model, tag, shots):
+    m, _ = fp32_model
+    g = np.load(os.path.join(G, "grads_b2.npz"))
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=0)
+    m.train()
+    m.zero_grad()
+    out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), shots)
+    loss = (out - torch.from_numpy(gt).cuda()) ** 2
+    loss = (loss * torch.from_numpy(mask).cuda() / (384 * 384)).sum() / out.shape[0]   # FSC_finetune_cross.py:294-295
+    loss.backward()
+    m.eval()
+    assert abs(loss.item() - float(g["loss_" + tag])) / float(g["loss_" + tag]) < 1e-3
+    have = sorted(k for k, p in m.named_parameters() if p.grad is not None)
+    assert have == meta["grad_tensors_" + tag]
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        gn = float(g["%s/norm/%s" % (tag, k)])
+        mine = p.grad.detach().cpu().numpy()
+        n = np.sqrt((mine.astype(np.float64) ** 2).sum())
+        assert abs(n - gn) <= 2e-3 * gn + 1e-7, (k, n, gn)
+        rms = gn / np.sqrt(mine.size)
+        fk = "%s/full/%s" % (tag, k)
+        ref = g[fk] if fk in g else g["%s/head/%s" % (tag, k)]
+        got = mine if fk in g else mine.reshape(-1)[:512]
+        err = np.abs(got - ref).max()
+        assert err <= 2e-3 * np.abs(ref).max() + 2e-2 * rms + 1e-7, (k, err)
+        worst = max(worst, err / (np.abs(ref).max() + 1e-12))
+
+
+def test_bf16_gradients_close_to_oracle(bf16_model):
+    """bf16 training mode: gradients of the large tensors within a few % (norm) of the fp32 oracle."""
+    m, sd = bf16_model
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=1)
+    m.train()
+    m.zero_grad()
+    out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3)
+    loss = R.masked_mse_loss(out, torch.from_numpy(gt).cuda(), torch.from_numpy(mask).cuda())
+    loss.backward()
+    m.eval()
+    _, rloss, rg = R.loss_and_grads(sd, imgs, boxes, gt, mask, 3, MODEL)
+    assert abs(loss.item() - rloss.item()) / rloss.item() < 5e-2
+    for k, p in m.named_parameters():
+        if p.grad is None or rg.get(k) is None:
+            continue
+        ref = rg[k].double()
+        if ref.norm() < 1e-3:
+            continue
+        got = p.grad.detach().cpu().double()
+        cos = (got * ref).sum() / (got.norm() * ref.norm())
+        # exemplar-CNN gradients arrive through the (tiny) cross-attention k/v signal: measured 0.96-0.98
+        assert cos > (0.94 if k.startswith("decoder_proj") else 0.98), (k, cos.item())
+        assert abs(got.norm() - ref.norm()) / ref.norm() < 0.1, k
