@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""FSC147 finetune-step throughput of the CounTR HIP engine (BASELINE.json metric).
+
+python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+One step = forward (frozen ViT-B/16 encoder + decoder) + masked-MSE + decoder-side backward + gradient all-reduce +
+AdamW on a synthetic batch of 8 images 384x384 with 3 exemplars per GPU (configs[1]); weak scaling.
+Prints ONE JSON line with the whole-job images/sec, the roofline of the attention core kernel (live HIP-event
+timing) and the CPU baseline (the oracle's finetune step on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GF_STEP_PER_IMG = 321.16e9   # encoder fwd + 3x decoder side
+ATT_FLOP_PER_IMG_LAYER = 4 * 576 * 576 * 64 * 12  # 4 N^2 dh H = 1.0192 GF
+MFMA_BF16_PEAK = 2.5e15
+
+
+def cpu_baseline(batch=2, steps=1, threads=None):
+    """The oracle (CPU restatement of the reference, validated against it) timed on this host's cores.
+    Threads are capped at 32: torch-CPU on all 256 hardware threads of the GPU box is ~100x slower (oversubscription)."""
+    import numpy as np
+    from oracle import countr_ref as R, weights as W
+    threads = threads or min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
+    sd = W.make_state_dict("mae_vit_base_patch16", seed=0)
+    imgs, boxes, gt, mask = W.make_inputs(batch=batch, shots=3, seed=0)
+    R.loss_and_grads(sd, imgs[:1], boxes[:1], gt[:1], mask, 3)  # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        out, loss, grads = R.loss_and_grads(sd, imgs, boxes, gt, mask, 3)
+        for k, g in grads.items():
+            if g is not None:
+                R.adamw_step(torch.from_numpy(sd[k]), g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-5)
+    dt = time.time() - t0
+    return {"value": batch * steps / dt, "unit": "images/sec", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d finetune step(s) of batch %d (fwd + decoder bwd + AdamW), fp32, torch-CPU oracle" % (steps, batch)}
+
+
+def attention_roofline(model, batch, iters=20):
+    """Times the attention core of one encoder layer (B x 12 heads, N=576, dh=64) with HIP events on the launch stream."""
+    eng = model._engine()
+    p = eng.plan(batch, 3, True)
+    ops = []
+    eng._attention_fwd(ops, p, p.buf["qkv"], p.buf["att"], batch, eng.H, eng.D)
+    for _ in range(3):
+        eng.run(ops)
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        eng.run(ops)
+    e1.record(st)
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    achieved = ATT_FLOP_PER_IMG_LAYER * batch / sec
+    return {"bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_BF16_PEAK, "traffic": None, "kernel": "encoder attention core (QK^T, softmax, PV), %d launches" % len(ops),
+            "us_per_launch": sec * 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import models_mae_cross
+    from countr_amd.trainer import FinetuneStep
+    from countr_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    model = models_mae_cross.__dict__["mae_vit_base_patch16"](norm_pix_loss=False, precision=args.precision)
+    model.to(dev).train()
+    B = args.batch
+    step = FinetuneStep(model, batch=B, lr=1e-5, weight_decay=0.05, use_graph=not args.no_graph)
+    imgs, boxes, gt, mask = make_batch(B, shots=3, seed=rank, device=dev)
+    step.load(imgs, boxes, gt, mask, 3)
+
+    for _ in range(max(args.warmup, 2)):   # the first two steps build the plan and capture the graphs
+        step.step(3)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums = step.step(3)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = sums[0].item()
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        line = {
+            "metric": "images/sec (384x384, 3 exemplars) FSC147 finetune step", "value": ips, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "FSC147 finetune ViT-B/16 (mae_vit_base_patch16), batch=%d per GPU, 384x384, shot_num=3, "
+                                   "frozen encoder fwd + decoder fwd/bwd + masked-MSE + AdamW" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
+            "final_loss": loss,
+            "step_tflops": GF_STEP_PER_IMG * ips / 1e12,
+        }
+        line["roofline"] = attention_roofline(model, B)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

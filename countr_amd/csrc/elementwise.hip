@@ -122,13 +122,16 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
   }
 }
 
-// partial [nb][64][28] -> dw [64][27] (torch OIHW order co, c, ky, kx == k) and db [64]
-__global__ void conv3x3_c3_wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                               int nb, int accumulate) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= 64 * 28) return;
+// partial [nb][64][28] -> dw [64][27] (torch OIHW order co, c, ky, kx == k) and db [64]; 4 lanes per output
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                      float* __restrict__ db, int nb, int accumulate) {
+  const int o = blockIdx.x * 64 + (threadIdx.x >> 2), l = threadIdx.x & 3;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * (64 * 28) + o];
+  if (o < 64 * 28)
+    for (int b = l; b < nb; b += 4) s += partial[(int64_t)b * (64 * 28) + o];
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (o >= 64 * 28 || l) return;
   const int co = o / 28, k = o - co * 28;
   float* dst = (k == 27) ? (db + co) : (dw + co * 27 + k);
   *dst = accumulate ? *dst + s : s;
@@ -232,16 +235,35 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ 
   }
 }
 
-// ---------------- column sums (bias gradients): partial[blockIdx.y][N] over row chunks
+// ---------------- column sums (bias gradients): partial[blockIdx.y][N] over row chunks.
+// thread = (8-column vector, row lane): 16-byte loads, CV vectors per row pass, 256/CV row lanes per block.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, int M, int N) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, int M, int N, int CV) {
+  __shared__ float sm[256 * 8];
+  const int cv = threadIdx.x % CV, rl = threadIdx.x / CV, RL = 256 / CV;
+  const int col = (blockIdx.x * CV + cv) * 8;
   const int per = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = min(M, r0 + per);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += ldf<T>(x + (int64_t)r * N + col);
-  partial[(int64_t)blockIdx.y * N + col] = s;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (col < N) {
+    for (int r = r0 + rl; r < r1; r += RL) {
+      float v[8];
+      ld8<T>(x + (int64_t)r * N + col, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sm[(rl * CV + cv) * 8 + e] = acc[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < CV * 8; i += 256) {
+    float s = 0.f;
+    for (int r = 0; r < RL; ++r) s += sm[r * CV * 8 + i];
+    const int c = blockIdx.x * CV * 8 + i;
+    if (c < N) partial[(int64_t)blockIdx.y * N + c] = s;
+  }
 }
 
 // ---------------- weight shadows
@@ -349,7 +371,7 @@ extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* d
   const int nb = 256;
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const bf16_t*)dy, workspace, S, H, W);
   else hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const float*)dy, workspace, S, H, W);
-  hipLaunchKernelGGL(conv3x3_c3_wgrad_finish_kernel, dim3((64 * 28 + 255) / 256), dim3(256), 0, STREAM(stream), workspace, dw, db, nb, accumulate);
+  hipLaunchKernelGGL(conv3x3_c3_wgrad_finish_kernel, dim3((64 * 28 + 63) / 64), dim3(256), 0, STREAM(stream), workspace, dw, db, nb, accumulate);
   COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_wgrad");
 }
 
@@ -389,8 +411,8 @@ extern "C" int countr_gelu_bwd(const void* dh, const void* pre, void* dpre, int6
   COUNTR_LAUNCH_CHECK("countr_gelu_bwd");
 }
 
-extern "C" int countr_colsum_nparts(void) { return 32; }
-// workspace: fp32 [32][N]
+extern "C" int countr_colsum_nparts(void) { return 64; }
+// workspace: fp32 [64][N]
 extern "C" int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, int accumulate, void* stream);
 
 extern "C" int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co, int Ci, int taps, int dtype,
@@ -424,10 +446,15 @@ extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, v
 }
 
 extern "C" int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, int accumulate, void* stream) {
-  if (!x || !out || !workspace) { countr_set_error("countr_colsum: null"); return -1; }
-  const int parts = 32;
-  dim3 grid((N + 255) / 256, parts);
-  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, M, N);
-  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, STREAM(stream), (const float*)x, workspace, M, N);
+  if (!x || !out || !workspace || (N & 7)) { countr_set_error("countr_colsum: N must be a multiple of 8"); return -1; }
+  int CV = N / 8; if (CV > 32) CV = 32;
+  while (256 % CV) --CV;                      // CV must divide 256 (N/8 is 64, 32, 16, ... for our shapes)
+  const int ctiles = (N / 8 + CV - 1) / CV;
+  int parts = 1024 / ctiles; if (parts > 64) parts = 64; if (parts < 1) parts = 1;
+  const int rl = 256 / CV;
+  if (parts > (M + rl - 1) / rl) parts = (M + rl - 1) / rl;
+  dim3 grid(ctiles, parts);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, M, N, CV);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, STREAM(stream), (const float*)x, workspace, M, N, CV);
   return countr_colsum_partials(workspace, out, parts, N, accumulate, stream);
 }

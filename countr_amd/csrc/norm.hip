@@ -132,24 +132,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
   }
 }
 
-// out[c] (+)= sum_p partial[p][c]
-__global__ void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts, int C,
-                                       int64_t stride, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] (+)= sum_p partial[p*stride + c]; block = 64 columns x 4 part lanes
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts,
+                                                              int C, int64_t stride, int accumulate) {
+  __shared__ float sm[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * stride + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int p = pl; p < nparts; p += 4) s += partial[(int64_t)p * stride + c];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    s = sm[threadIdx.x] + sm[64 + threadIdx.x] + sm[128 + threadIdx.x] + sm[192 + threadIdx.x];
+    out[c] = accumulate ? out[c] + s : s;
+  }
 }
 
-// out[0] (+)= sum of n floats (single block; used for tiny reductions such as the 1x1-conv bias grad)
-__global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__ in, int64_t n, float* __restrict__ out,
-                                                       int accumulate) {
-  __shared__ float sm[16];
+// partial sums of n floats: part[blockIdx.x] = sum of a strided slice (finish with colsum_partials, C = 1)
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ in, int64_t n, float* __restrict__ part) {
+  __shared__ float sm[4];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += in[i];
-  s = block_sum<16>(s, sm);
-  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += in[i];
+  s = block_sum<4>(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -594,14 +599,14 @@ extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float*
   if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
   // workspace rows are {dgamma[D], dbeta[D]} per block
-  if (dgamma) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, D, (int64_t)2 * D, accumulate_dgb);
-  if (dbeta) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, STREAM(stream), workspace + D, dbeta, nb, D, (int64_t)2 * D, accumulate_dgb);
+  if (dgamma) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, D, (int64_t)2 * D, accumulate_dgb);
+  if (dbeta) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, STREAM(stream), workspace + D, dbeta, nb, D, (int64_t)2 * D, accumulate_dgb);
   COUNTR_LAUNCH_CHECK("countr_layernorm_bwd");
 }
 
 extern "C" int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream) {
   if (!partial || !out) { countr_set_error("countr_colsum_partials: null"); return -1; }
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, STREAM(stream), partial, out, nparts, C, (int64_t)C, accumulate);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, STREAM(stream), partial, out, nparts, C, (int64_t)C, accumulate);
   COUNTR_LAUNCH_CHECK("countr_colsum_partials");
 }
 
@@ -643,11 +648,14 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   float* outs[3] = {dbeta, dgamma, dw1};
   for (int i = 0; i < 3; ++i) {
     if (!outs[i]) continue;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(1), dim3(256), 0, STREAM(stream), workspace + i * GN_C, outs[i], B * ns, GN_C,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(GN_C / 64), dim3(256), 0, STREAM(stream), workspace + i * GN_C, outs[i], B * ns, GN_C,
                        (int64_t)3 * GN_C, accumulate);
   }
-  if (db1 && d1)
-    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, STREAM(stream), d1, (int64_t)B * HW, db1, accumulate);
+  if (db1 && d1) {  // the reduce/apply kernels are done with the first 64 floats of row 0's third plane only via dw1: use the tail
+    float* part = workspace + (int64_t)B * ns * 3 * GN_C;  // 64 extra floats behind the partials
+    hipLaunchKernelGGL(sum_all_kernel, dim3(64), dim3(256), 0, STREAM(stream), d1, (int64_t)B * HW, part);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(1), dim3(256), 0, STREAM(stream), part, db1, 64, 1, (int64_t)1, accumulate);
+  }
   COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_bwd");
 }
 

@@ -137,7 +137,6 @@ class Engine:
             self.Wd[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
         self.plans = {}
         self.hyper = torch.zeros(4, device=self.device, dtype=torch.float32)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
         self.step_count = 0
         self._ws = {}
         self._need = {}
@@ -256,7 +255,7 @@ class Engine:
         self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, 0)
 
     def _bias_grad(self, ops, dy, bname, M, N):
-        ws = self._shared("colsum", 32 * 4096)
+        ws = self._shared("colsum", 64 * 4096)
         self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, 0)
 
     def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None):
@@ -468,7 +467,7 @@ class Engine:
         cin = [Dd, 256, 256, 256]
         hin = [dn]
         hc, hstats = [], []
-        gn_ws = self._shared("gn", B * 64 * 3 * 256)
+        gn_ws = self._shared("gn", B * 64 * 3 * 256 + 64)
         o1 = A("o1", (B, hs[3] * hs[3]), f32)
         out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
         hact_tmp = self._shared("hact_tmp", B * hs[2] * hs[2] * 256, T)
@@ -588,7 +587,7 @@ class Engine:
         self._linear_wgrad(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
         # ---- exemplar tokens
         if S == 0:
-            ws = self._shared("colsum", 32 * 4096)
+            ws = self._shared("colsum", 64 * 4096)
             self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, 0)
         else:
             BS = B * S
@@ -645,12 +644,12 @@ class Engine:
             out.append((s, e, 0.0 if nodecay else weight_decay))
         return out
 
-    def adamw_step(self, S, lr, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, use_device_hyper=False):
-        """torch.optim.AdamW(betas=(0.9,0.95)) semantics (FSC_finetune_cross.py:235) fused over the flat buffers."""
+    def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None):
+        """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[4] {lr, 1-b1^t, 1-b2^t, grad_scale}
+        read by the kernel at run time, so a captured launch can be replayed with new values."""
         if self.M is None:
             self.M = torch.zeros_like(self.G)
             self.V = torch.zeros_like(self.G)
-        self.step_count += 1
         rng = self.adam_ranges(S, weight_decay)
         n = len(rng)
         starts = (C.c_int64 * n)(*[r[0] for r in rng])
@@ -658,18 +657,15 @@ class Engine:
         wds = (C.c_float * n)(*[r[2] for r in rng])
         lay = self.layout
         shadow = (self.Wt.data_ptr() + 2 * lay.train_start) if self.precision == "bf16" else None
-        hyper = None
-        if use_device_hyper:
-            self._hyper_host[0] = lr
-            self._hyper_host[1] = 1.0 - betas[0] ** self.step_count
-            self._hyper_host[2] = 1.0 - betas[1] ** self.step_count
-            self._hyper_host[3] = grad_scale
-            self.hyper.copy_(self._hyper_host, non_blocking=True)
-            hyper = self.hyper.data_ptr()
         _lib.check(self.L.countr_adamw_step(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                            shadow, n, starts, ends, wds, lr, betas[0], betas[1], eps, self.step_count, grad_scale,
-                                            hyper, self._stream()), "adamw")
+                                            shadow, n, starts, ends, wds, lr, betas[0], betas[1], eps, step, grad_scale,
+                                            hyper_dev.data_ptr() if hyper_dev is not None else None, self._stream()), "adamw")
         self._refresh_conv_shadows()
+
+    def adamw_step(self, S, lr, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
+        """torch.optim.AdamW(betas=(0.9,0.95)) semantics (FSC_finetune_cross.py:235) fused over the flat buffers."""
+        self.step_count += 1
+        self.adamw_launch(S, weight_decay, betas, eps, lr=lr, step=self.step_count, grad_scale=grad_scale)
 
     def _refresh_conv_shadows(self):
         st = self._stream()

@@ -1,0 +1,125 @@
+"""Finetune step for the HIP engine: forward, masked-MSE loss, decoder-side backward, gradient all-reduce over
+RCCL (one flat fp32 buffer in two buckets, the first launched while the rest of backward runs) and fused AdamW.
+
+Mirrors the hot loop of the reference (FSC_finetune_cross.py:265-319; util/misc.py:266-280) minus its three
+per-step host syncs; bf16 needs no GradScaler.  With use_graph=True each phase is captured once per shot_num into a
+hipGraph and replayed (torch.cuda.CUDAGraph is only the capture/replay handle; every node is one of our kernels).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class FinetuneStep:
+    def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
+                 process_group=None):
+        self.model = model
+        self.eng = model._engine()
+        self.B = batch
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.comm_stream = torch.cuda.Stream(device=self.eng.device) if self.world > 1 else None
+        self.graphs = {}
+        self.sums = {}
+        lay = self.eng.layout
+        self.bucket0 = lay.bucket_range(0)
+        self.bucket_rest = (self.bucket0[1], lay.n_train)
+        self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self._ring_ev = [None] * 16
+        self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
+        self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
+
+    # ------------------------------------------------------------------ phases
+    def _phase_a(self, S):
+        """forward + loss (+ dL/dout) + backward until the head/decoder_norm gradients (bucket 0) are final."""
+        eng = self.eng
+        p = eng.plan(self.B, S, True)
+        eng.run(p.fwd)
+        sums = self.sums.setdefault(S, torch.zeros(1 + 2 * self.B, device=eng.device))
+        HW = eng.img * eng.img
+        _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
+                                           sums.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
+        eng.run(p.bwd_head)
+
+    def _phase_b(self, S):
+        p = self.eng.plan(self.B, S, True)
+        if S == 0:  # exemplar-CNN gradients are absent for this shot_num: keep the bucket well-defined
+            s, e = self.eng.layout.bucket_range(2)
+            self.eng.G[s:e].zero_()
+        else:
+            s, e = self.eng.layout.bucket_range(3)
+            self.eng.G[s:e].zero_()
+        self.eng.run(p.bwd_rest)
+
+    def _phase_c(self, S):
+        self.eng.adamw_launch(S, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper)
+
+    def _run_phase(self, name, fn, S):
+        if not self.use_graph:
+            fn(S)
+            return
+        key = (name, S)
+        g = self.graphs.get(key)
+        if g is None:
+            fn(S)  # first use: run eagerly (does the real work, triggers lazy kernel attributes and plan builds) ...
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):  # ... then capture the same launches for every later step
+                fn(S)
+            self.graphs[key] = g
+            return
+        g.replay()
+
+    def _upload_hyper(self):
+        """Step-dependent AdamW scalars go through a small device buffer so that graph replay sees new values."""
+        eng = self.eng
+        eng.step_count += 1
+        slot = eng.step_count % len(self._ring)
+        ev = self._ring_ev[slot]
+        if ev is not None:
+            ev.synchronize()  # the copy that last used this pinned slot has completed
+        h = self._ring[slot]
+        h[0] = self.lr
+        h[1] = 1.0 - self.betas[0] ** eng.step_count
+        h[2] = 1.0 - self.betas[1] ** eng.step_count
+        h[3] = 1.0 / self.world
+        eng.hyper.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_ev[slot] = ev
+
+    # ------------------------------------------------------------------ public
+    def load(self, imgs, boxes, gt, mask, S):
+        p = self.eng.plan(self.B, S, True)
+        self.eng._load_inputs(p, imgs, boxes, S)
+        self.gt.copy_(gt, non_blocking=True)
+        self.mask.copy_(mask, non_blocking=True)
+
+    def step(self, S, lr=None):
+        """One optimisation step on the inputs last given to load().  Returns the device tensor
+        [loss, pred counts (B), gt counts (B)] without synchronising."""
+        if lr is not None:
+            self.lr = lr
+        eng = self.eng
+        if self.eng.M is None:
+            eng.M = torch.zeros_like(eng.G)
+            eng.V = torch.zeros_like(eng.G)
+        self._run_phase("a", self._phase_a, S)
+        if self.world > 1:
+            main = torch.cuda.current_stream(eng.device)
+            self.comm_stream.wait_stream(main)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(eng.G[self.bucket0[0]:self.bucket0[1]], group=self.pg)
+        self._run_phase("b", self._phase_b, S)
+        if self.world > 1:
+            dist.all_reduce(eng.G[self.bucket_rest[0]:self.bucket_rest[1]], group=self.pg)
+            torch.cuda.current_stream(eng.device).wait_stream(self.comm_stream)
+        self._upload_hyper()
+        self._run_phase("c", self._phase_c, S)
+        self.model.mark_weights_synced()
+        return self.sums[S]

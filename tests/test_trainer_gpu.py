@@ -1,0 +1,75 @@
+"""GPU: the fused finetune step (forward, masked-MSE, decoder backward, AdamW; eager and hipGraph replay)
+against the CPU oracle's loss/gradients + AdamW restatement, fp32 parity mode, reduced-depth model."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import countr_ref as R
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+NAME = "tiny_test"
+
+
+def make(precision):
+    from countr_amd.models_mae_cross import SupervisedMAE
+    p, D, depth, H, Dd, ddepth, Hd = W.CONFIGS[NAME]
+    sd = W.make_state_dict(NAME, seed=3)
+    m = SupervisedMAE(patch_size=p, embed_dim=D, depth=depth, num_heads=H, decoder_embed_dim=Dd, decoder_depth=ddepth,
+                      decoder_num_heads=Hd, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda"), sd
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_finetune_steps_match_oracle(use_graph):
+    from countr_amd.trainer import FinetuneStep
+    from countr_amd.engine import no_weight_decay
+    m, sd = make("fp32")
+    # eps=1e-4 keeps AdamW's g/(|g|+eps) well conditioned for the (near-)zero gradients; with 1e-8 their sign is noise
+    step = FinetuneStep(m, batch=2, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph)
+    ref = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    t = 0
+    # shot schedule exercises both parameter subsets twice (second use of each replays the captured graphs)
+    for it, S in enumerate([3, 0, 3, 0]):
+        imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=10 + it)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+        sums = step.step(S).clone()
+        torch.cuda.synchronize()
+        cur = {k: v.float().numpy() for k, v in ref.items()}
+        out, rloss, rg = R.loss_and_grads(cur, imgs, boxes, gt, mask, S, NAME)
+        assert abs(sums[0].item() - rloss.item()) <= 2e-3 * abs(rloss.item()), (it, S)
+        assert np.abs(sums[1:3].cpu().numpy() - R.counts(out).numpy()).max() < 0.5
+        t += 1
+        for k, g in rg.items():
+            if g is None:
+                continue  # AdamW skips parameters without a gradient (exemplar CNN at S=0, shot_token at S>0)
+            wd = 0.0 if no_weight_decay(k, ref[k].shape) else 0.05
+            ref[k], m1, m2 = R.adamw_step(ref[k], g.double(), mom[k][0], mom[k][1], t, 1e-3, eps=1e-4, wd=wd)
+            mom[k] = (m1, m2)
+        for k, p in m.named_parameters():
+            got = p.detach().cpu().double()
+            # AdamW normalises the step to ~lr per element, so compare in units of lr
+            err = (got - ref[k]).abs().max().item()
+            assert err <= 0.25 * 1e-3 * (it + 1), (it, S, k, err)  # a wrong/missing AdamW step would be >= 1 lr off
+    # frozen encoder untouched
+    for k, p in m.named_parameters():
+        if not k.startswith(("decoder", "decode_head", "shot_token")):
+            assert torch.equal(p.detach().cpu(), torch.from_numpy(sd[k])), k
+
+
+def test_bf16_step_runs_and_reduces_loss():
+    from countr_amd.trainer import FinetuneStep
+    m, sd = make("bf16")
+    step = FinetuneStep(m, batch=2, lr=2e-4, use_graph=True)
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=21)
+    step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), 3)
+    losses = []
+    for _ in range(6):
+        losses.append(step.step(3)[0].item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses
