@@ -193,11 +193,12 @@ def exemplar_tokens(p, boxes, shot_num, batch):
     return torch.stack(ys, dim=1)
 
 
-def forward_decoder(p, latent, boxes, shot_num, cfg, probes=None):
-    """models_mae_cross.py:150-199."""
+def forward_decoder(p, latent, boxes, shot_num, cfg, probes=None, y=None):
+    """models_mae_cross.py:150-199.  `y` (test hook): precomputed exemplar tokens [B, S, 512]."""
     Dd, ddepth, Hd = cfg[4], cfg[5], cfg[6]
     x = linear(latent, p["decoder_embed.weight"], p["decoder_embed.bias"]) + p["decoder_pos_embed"]
-    y = exemplar_tokens(p, boxes, shot_num, latent.shape[0])
+    if y is None:
+        y = exemplar_tokens(p, boxes, shot_num, latent.shape[0])
     if probes is not None:
         probes["dec_embed"] = x
         probes["exemplar_tokens"] = y

@@ -53,9 +53,13 @@ def test_finetune_steps_match_oracle(use_graph):
             mom[k] = (m1, m2)
         for k, p in m.named_parameters():
             got = p.detach().cpu().double()
-            # AdamW normalises the step to ~lr per element, so compare in units of lr
-            err = (got - ref[k]).abs().max().item()
-            assert err <= 0.25 * 1e-3 * (it + 1), (it, S, k, err)  # a wrong/missing AdamW step would be >= 1 lr off
+            # AdamW normalises the step to ~lr per element, so compare in units of lr: rms error everywhere, max error
+            # outside the exemplar CNN (one fp32 ReLU-boundary flip, |xhat| ~ 1e-7, moves single elements there by
+            # a fraction of lr: tools/diag_exemplar.py).  A wrong or missing step would be >= 1 lr off.
+            d = (got - ref[k]).abs()
+            assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (it + 1), (it, S, k)
+            if not k.startswith("decoder_proj"):
+                assert d.max().item() <= 0.25 * 1e-3 * (it + 1), (it, S, k, d.max().item())
     # frozen encoder untouched
     for k, p in m.named_parameters():
         if not k.startswith(("decoder", "decode_head", "shot_token")):
