@@ -286,6 +286,9 @@ class Engine:
     def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None):
         N, dh = self.N, Dm // heads
         scale = dh ** -0.5
+        if self.code == BF16 and probs is None and dh in (32, 64) and self.attention != "unfused":
+            self._op(ops, self.L.countr_attn_fwd, qkv.data_ptr(), out.data_ptr(), None, B, N, heads, dh, scale)
+            return
         scores = self._shared("scores", B * heads * N * N)
         if probs is None:
             probs = self._shared("probs", B * heads * N * N, self.tdt)

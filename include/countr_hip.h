@@ -118,6 +118,11 @@ int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, i
 int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H,
                                   int W, int C, int avgpool, int dtype, void* stream);
 
+/* -------- fused self-attention forward (Attention.forward, models_crossvit.py:82-94 == timm Attention):
+ * out = softmax(q k^T * scale) v on a packed bf16 qkv [B, N, 3, H, dh] (dh = 32 or 64) -> bf16 [B, N, H*dh].
+ * lse: optional fp32 [B, H, N] log-sum-exp of the scaled scores. */
+int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream);
+
 /* -------- softmax rows for the unfused attention path (models_crossvit.py:87-88) */
 int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream);
 int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,

@@ -320,3 +320,22 @@ def test_masked_mse_and_adamw(hip):
         pr_, mr, vr = torch.cat([a, b]), torch.cat([ma, mb]), torch.cat([va, vb])
         assert relerr(p, pr_) < 1e-5
     assert relerr(shadow, pr_) < 5e-3
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(2, 576, 12, 64), (2, 576, 16, 32), (1, 200, 3, 64), (1, 64, 2, 32)])
+def test_flash_attention_fwd(hip, B, N, H, dh):
+    """Fused bf16 attention vs fp64 softmax(q k^T * scale) v on the same (bf16-representable) inputs, including a
+    spiked key that forces the online-softmax rescale branch and ragged N (not a multiple of the 64-key tile)."""
+    qkv = rnd((B, N, 3, H, dh), 50, 1.0).to(torch.bfloat16)
+    qkv[0, N // 2, 1, 0] = 6.0  # one key with large logits against every query -> running max jumps mid-sequence
+    qd = qkv.cuda()
+    out = torch.empty((B, N, H * dh), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty((B, H, N), device="cuda")
+    scale = dh ** -0.5
+    _lib.check(hip.countr_attn_fwd(P(qd), P(out), P(lse), B, N, H, dh, scale, st()))
+    q = qkv[:, :, 0].double().permute(0, 2, 1, 3); k = qkv[:, :, 1].double().permute(0, 2, 1, 3)
+    v = qkv[:, :, 2].double().permute(0, 2, 1, 3)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * dh)
+    assert relerr(out, ref) < 1.5e-2   # bf16 P and bf16 output rounding
+    assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-4
