@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcountr_hip.so")
+LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 
 F32, BF16 = 0, 1
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3

@@ -12,7 +12,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 constexpr int ROW_PITCH = 144;      // 128 B of K + 16 B pad
-constexpr int OP_BYTES = 18432;     // per operand per stage (max over layouts)
+constexpr int OP_BYTES = 18432;     // per operand per stage (max over layouts), fp32 path
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> {
@@ -175,6 +175,133 @@ template <typename T> struct Loader<T, COUNTR_OP_IM2COL> {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 path: direct-to-LDS staging (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write).
+// The DMA destination is lane-linear (wave-uniform base + lane*16), so tiles are stored unpadded and the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and again on the fragment read:
+//   row-like tile [128 rows][8 chunks]  : chunk c of row r lives in slot  c ^ ((r >> 1) & 7)
+//   col-like tile [64 k-rows][16 chunks]: chunk c of k-row k lives in slot c ^ swz_col(k)
+// Masked chunks (padding pixels, ragged edges) read a 16-byte zero page instead, so every lane always issues.
+// ---------------------------------------------------------------------------------------------
+__device__ uint4 g_zero_page[2] = {};
+
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef const __attribute__((address_space(1))) void* glb_vptr_t;
+__device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_vptr_t)g, (lds_vptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int swz_col(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+
+constexpr int DMA_OP_BYTES = 16384;  // 128 x 64 bf16, unpadded
+
+template <int MODE> struct DmaLoader;
+
+template <> struct DmaLoader<COUNTR_OP_ROW> {
+  const char* rp[4];
+  int kc;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row0 + (tid >> 3) + 32 * i;
+      rp[i] = (r < d.rows) ? d.ptr + (int64_t)r * d.ld * 2 : nullptr;
+    }
+  }
+  __device__ void issue(int k0, int kend, char* lds, int wave) {
+    const int k = k0 + kc;
+    const bool kok = (k + 8) <= kend;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const void* src = (kok && rp[i]) ? (const void*)(rp[i] + (int64_t)k * 2) : (const void*)g_zero_page;
+      dma16(src, lds + (i * 4 + wave) * 1024);
+    }
+  }
+};
+
+template <> struct DmaLoader<COUNTR_OP_COL> {
+  const char* base;
+  int64_t ldb;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    const int krow = tid >> 4;  // + 16*i, swizzle term is independent of i
+    const int r0 = row0 + ((tid & 15) ^ swz_col(krow)) * 8;
+    base = (r0 + 8 <= d.rows) ? d.ptr + (int64_t)r0 * 2 : nullptr;
+    ldb = d.ld * 2;
+  }
+  __device__ void issue(int k0, int kend, char* lds, int wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + (threadIdx.x >> 4) + 16 * i;
+      const void* src = (base && k < kend) ? (const void*)(base + (int64_t)k * ldb) : (const void*)g_zero_page;
+      dma16(src, lds + (i * 4 + wave) * 1024);
+    }
+  }
+};
+
+template <> struct DmaLoader<COUNTR_OP_IM2ROW> {
+  const char* ptr;
+  int pix[4], py[4], px[4];
+  int H, W, C, kc;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    ptr = d.ptr; H = d.H; W = d.W; C = d.C;
+    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = row0 + (tid >> 3) + 32 * i;
+      pix[i] = (m < d.rows) ? m : -1;
+      px[i] = m % W;
+      py[i] = (m / W) % H;
+    }
+  }
+  __device__ void issue(int k0, int kend, char* lds, int wave) {
+    const int tap = k0 / C;
+    const int ci = k0 - tap * C + kc;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const bool kok = (k0 + kc + 8) <= kend;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = kok && pix[i] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const void* src = ok ? (const void*)(ptr + ((int64_t)(pix[i] + dy * W + dx) * C + ci) * 2) : (const void*)g_zero_page;
+      dma16(src, lds + (i * 4 + wave) * 1024);
+    }
+  }
+};
+
+template <> struct DmaLoader<COUNTR_OP_IM2COL> {
+  const char* ptr;
+  int py[4], px[4];
+  int H, W, C, ci, dy, dx;
+  bool colok;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+    ptr = d.ptr; H = d.H; W = d.W; C = d.C;
+    const int krow = tid >> 4;
+    const int r0 = row0 + ((tid & 15) ^ swz_col(krow)) * 8;
+    colok = (r0 + 8) <= d.rows;
+    const int tap = r0 / C;
+    ci = r0 - tap * C;
+    dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = kstart + krow + 16 * i;
+      px[i] = p % W;
+      py[i] = (p / W) % H;
+    }
+  }
+  __device__ void issue(int k0, int kend, char* lds, int wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = k0 + (threadIdx.x >> 4) + 16 * i;
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = colok && p < kend && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const void* src = ok ? (const void*)(ptr + ((int64_t)(p + dy * W + dx) * C + ci) * 2) : (const void*)g_zero_page;
+      dma16(src, lds + (i * 4 + wave) * 1024);
+      px[i] += 64;
+      while (px[i] >= W) { px[i] -= W; py[i] = (py[i] + 1 == H) ? 0 : py[i] + 1; }
+    }
+  }
+};
+
 constexpr bool is_rowlike(int mode) { return mode == COUNTR_OP_ROW || mode == COUNTR_OP_IM2ROW; }
 
 // ---------------------------------------------------------------------------------------------
@@ -186,13 +313,15 @@ template <int MODE>
 __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row, int row4, int kk, int lane) {
   const int g = lane >> 4, i = lane & 15;
   if constexpr (is_rowlike(MODE)) {
-    return *reinterpret_cast<const bf16x8_t*>(lds + row * ROW_PITCH + (kk * 32 + g * 8) * 2);
+    return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + (((kk * 4 + g) ^ ((row >> 1) & 7)) << 4));
   } else {
     // K-major image [k][row]: two hardware-transposing reads of a [4 k][16 rows] block each.
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
-    const char* p0 = lds + (kk * 32 + g * 8 + (i >> 2)) * Cfg<bf16_t>::COL_PITCH + row4 * 2;
+    const int k0 = kk * 32 + g * 8 + (i >> 2), k1 = k0 + 4;
+    const char* p0 = lds + k0 * 256 + (((row4 >> 3) ^ swz_col(k0)) << 4) + (row4 & 7) * 2;
+    const char* p1 = lds + k1 * 256 + (((row4 >> 3) ^ swz_col(k1)) << 4) + (row4 & 7) * 2;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p0));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p0 + 4 * Cfg<bf16_t>::COL_PITCH));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p1));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     s16x8_t r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
@@ -218,7 +347,7 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
   }
 }
 
-template <typename T, int MA, int MB>
+template <typename T, int MA, int MB, int STAGES>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g) {
   constexpr int BK = Cfg<T>::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -249,10 +378,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
 
   OpDesc dA{reinterpret_cast<const char*>(g.A) + offA * (int64_t)sizeof(T), g.lda, g.M, g.H, g.W, g.Cin};
   OpDesc dB{reinterpret_cast<const char*>(g.B) + offB * (int64_t)sizeof(T), g.ldb, g.N, g.H, g.W, g.Cin};
-  Loader<T, MA> la;
-  Loader<T, MB> lb;
-  la.init(dA, m0, kstart, tid);
-  lb.init(dB, n0, kstart, tid);
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -266,27 +391,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   // so that a lane ends up holding 16 consecutive output columns (vector stores in the epilogue).
   const int nrow_base = wn0 + (li >> 2) * 16 + (li & 3);
   const int nrow4_base = wn0 + (li & 3) * 16;
-
-  uint4 va[4], vb[4];
   const int ntiles = (kend > kstart) ? (kend - kstart + BK - 1) / BK : 0;
-  if (ntiles > 0) {
-    la.load(kstart, kend, va);
-    lb.load(kstart, kend, vb);
-    la.store(smem, tid, va);
-    lb.store(smem + OP_BYTES, tid, vb);
-  }
-  __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const bool more = (t + 1) < ntiles;
-    if (more) {
-      la.load(kstart + (t + 1) * BK, kend, va);
-      lb.load(kstart + (t + 1) * BK, kend, vb);
-    }
-    const char* sa = smem + cur * 2 * OP_BYTES;
-    const char* sb = sa + OP_BYTES;
-    if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2) {
+    // ---------------- bf16: LDS-DMA staging, two stages, tile t+1 in flight while tile t is multiplied
+    DmaLoader<MA> la;
+    DmaLoader<MB> lb;
+    la.init(dA, m0, kstart, tid);
+    lb.init(dB, n0, kstart, tid);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto mma_tile = [&](const char* sa, const char* sb) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8_t xf[4], wf[4];
@@ -302,7 +416,61 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
           for (int tn = 0; tn < 4; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
       }
+    };
+    if constexpr (STAGES == 1) {
+      // Single LDS stage (32 KB): up to 5 workgroups stay resident per CU and hide each other's DMA latency.
+      // Chosen by the host for big grids (>= ~3 workgroups per CU), where it beats per-workgroup double buffering.
+      for (int t = 0; t < ntiles; ++t) {
+        la.issue(kstart + t * BK, kend, smem, wv);
+        lb.issue(kstart + t * BK, kend, smem + DMA_OP_BYTES, wv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma_tile(smem, smem + DMA_OP_BYTES);
+        __builtin_amdgcn_s_barrier();  // all fragment reads of this tile are consumed before it is overwritten
+      }
     } else {
+      // Two stages (64 KB, 2 workgroups per CU): tile t+1 streams in while tile t is multiplied.
+      if (ntiles > 0) {
+        la.issue(kstart, kend, smem, wv);
+        lb.issue(kstart, kend, smem + DMA_OP_BYTES, wv);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) {
+          char* nxt = smem + (cur ^ 1) * 2 * DMA_OP_BYTES;
+          la.issue(kstart + (t + 1) * BK, kend, nxt, wv);
+          lb.issue(kstart + (t + 1) * BK, kend, nxt + DMA_OP_BYTES, wv);
+        }
+        mma_tile(smem + cur * 2 * DMA_OP_BYTES, smem + cur * 2 * DMA_OP_BYTES + DMA_OP_BYTES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  } else {
+    // ---------------- fp32 parity path: register-staged, padded tiles
+    Loader<T, MA> la;
+    Loader<T, MB> lb;
+    la.init(dA, m0, kstart, tid);
+    lb.init(dB, n0, kstart, tid);
+    uint4 va[4], vb[4];
+    if (ntiles > 0) {
+      la.load(kstart, kend, va);
+      lb.load(kstart, kend, vb);
+      la.store(smem, tid, va);
+      lb.store(smem + OP_BYTES, tid, vb);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      const int cur = t & 1;
+      const bool more = (t + 1) < ntiles;
+      if (more) {
+        la.load(kstart + (t + 1) * BK, kend, va);
+        lb.load(kstart + (t + 1) * BK, kend, vb);
+      }
+      const char* sa = smem + cur * 2 * OP_BYTES;
+      const char* sb = sa + OP_BYTES;
 #pragma unroll
       for (int c16 = 0; c16 < 2; ++c16) {
         float4 xf[4], wf[4];
@@ -320,12 +488,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn].w, xf[tm].w, acc[tm][tn], 0, 0, 0);
           }
       }
+      if (more) {
+        la.store(smem + (cur ^ 1) * 2 * OP_BYTES, tid, va);
+        lb.store(smem + (cur ^ 1) * 2 * OP_BYTES + OP_BYTES, tid, vb);
+      }
+      __syncthreads();
     }
-    if (more) {
-      la.store(smem + (cur ^ 1) * 2 * OP_BYTES, tid, va);
-      lb.store(smem + (cur ^ 1) * 2 * OP_BYTES + OP_BYTES, tid, vb);
-    }
-    __syncthreads();
   }
 
   // ---------------- epilogue: lane (j = lane&15, gq = lane>>4) owns, per tm, row m and the 16
@@ -382,19 +550,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   }
 }
 
+template <typename T, int MA, int MB, int STAGES>
+int launch_variant(const countr_gemm_args& a, dim3 grid, hipStream_t s) {
+  constexpr int lds_bytes = sizeof(T) == 2 ? STAGES * 2 * 16384 : 4 * OP_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES>), grid, dim3(NTHREADS), lds_bytes, s, a);
+  COUNTR_LAUNCH_CHECK("countr_gemm");
+}
+
 template <typename T, int MA, int MB>
 int launch(const countr_gemm_args& a, hipStream_t s) {
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
   const int zdim = a.partial ? (a.splitk > 1 ? a.splitk : 1) : (a.nbatch > 1 ? a.nbatch : 1);
   dim3 grid(tilesM * tilesN, 1, zdim);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * OP_BYTES);
-    attr_set = true;
+  if constexpr (sizeof(T) == 2) {
+    // deep-K launches on big grids: single stage + high occupancy; otherwise double-buffered
+    // (measured crossover on MI355X / 256 CUs with tools/bench_gemm.py)
+    const int ksplit = a.partial ? (a.splitk > 1 ? a.splitk : 1) : 1;
+    const int ktiles = (a.K / ksplit + 63) / 64;
+    if ((long)tilesM * tilesN * zdim >= 512 && ktiles >= 24) return launch_variant<T, MA, MB, 1>(a, grid, s);
   }
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB>), grid, dim3(NTHREADS), 4 * OP_BYTES, s, a);
-  COUNTR_LAUNCH_CHECK("countr_gemm");
+  return launch_variant<T, MA, MB, 2>(a, grid, s);
 }
 
 template <typename T>
