@@ -78,6 +78,16 @@ class ParamLayout:
         segs = [s for s in self.segments if s[0][0] == bucket]
         return (segs[0][1], segs[-1][2]) if segs else (0, 0)
 
+    def adam_ranges(self, S, weight_decay):
+        """(start, end, wd) ranges of the trainable region touched when shot_num == S: parameters whose gradient is
+        None in the reference are skipped by torch AdamW (exemplar CNN for S == 0, shot_token otherwise)."""
+        out = []
+        for (bucket, nodecay), s, e in self.segments:
+            if (bucket == 2 and S == 0) or (bucket == 3 and S > 0):
+                continue
+            out.append((s, e, 0.0 if nodecay else weight_decay))
+        return out
+
 
 class _Fake:
     """Stand-in tensor used by the sizing pass of a plan build (no memory is touched)."""
@@ -638,14 +648,7 @@ class Engine:
         self.run(p.bwd_rest)
 
     def adam_ranges(self, S, weight_decay):
-        """(start, end, wd) ranges of the trainable region touched when shot_num == S: parameters whose
-        gradient is None in the reference are skipped by AdamW (exemplar CNN for S == 0, shot_token otherwise)."""
-        out = []
-        for (bucket, nodecay), s, e in self.layout.segments:
-            if (bucket == 2 and S == 0) or (bucket == 3 and S > 0):
-                continue
-            out.append((s, e, 0.0 if nodecay else weight_decay))
-        return out
+        return self.layout.adam_ranges(S, weight_decay)
 
     def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None):
         """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[4] {lr, 1-b1^t, 1-b2^t, grad_scale}

@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .parallel import GradSync
 
 
 class FinetuneStep:
@@ -22,13 +23,13 @@ class FinetuneStep:
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.use_graph = use_graph
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.comm_stream = torch.cuda.Stream(device=self.eng.device) if self.world > 1 else None
         self.graphs = {}
         self.sums = {}
         lay = self.eng.layout
         self.bucket0 = lay.bucket_range(0)
         self.bucket_rest = (self.bucket0[1], lay.n_train)
+        self.sync = GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
+        self.world = self.sync.world
         self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._ring_ev = [None] * 16
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
@@ -110,15 +111,9 @@ class FinetuneStep:
             eng.M = torch.zeros_like(eng.G)
             eng.V = torch.zeros_like(eng.G)
         self._run_phase("a", self._phase_a, S)
-        if self.world > 1:
-            main = torch.cuda.current_stream(eng.device)
-            self.comm_stream.wait_stream(main)
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(eng.G[self.bucket0[0]:self.bucket0[1]], group=self.pg)
+        self.sync.start_bucket0()          # overlaps with the rest of backward
         self._run_phase("b", self._phase_b, S)
-        if self.world > 1:
-            dist.all_reduce(eng.G[self.bucket_rest[0]:self.bucket_rest[1]], group=self.pg)
-            torch.cuda.current_stream(eng.device).wait_stream(self.comm_stream)
+        self.sync.finish()
         self._upload_hyper()
         self._run_phase("c", self._phase_c, S)
         self.model.mark_weights_synced()

@@ -1,0 +1,96 @@
+"""CPU / gloo, world_size 2: the N > 1 path of the finetune step -- two-bucket gradient all-reduce over the flat buffer,
+1/world folded into AdamW, identical shot_num on every rank, identical parameters after the step, and equality with the
+single-process large-batch gradient (DDP semantics, FSC_finetune_cross.py:230)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from countr_amd.engine import ParamLayout
+        from countr_amd.parallel import GradSync, shared_shot_num
+        from oracle import countr_ref as R
+        meta = json.load(open(os.path.join(G, "meta.json")))
+        lay = ParamLayout([(a, tuple(b)) for a, b in meta["schema"]])
+        n = lay.n_train
+        gen = torch.Generator().manual_seed(100 + rank)
+        g_local = torch.randn(n, generator=gen, dtype=torch.float64)
+        S = shared_shot_num(step=7, seed=0)
+        # grad-less parameters for this shot_num are zero-filled so the bucket is well defined on every rank
+        s0, e0 = lay.bucket_range(2 if S == 0 else 3)
+        g_local[s0:e0] = 0
+        flat = g_local.clone()
+        sync = GradSync(flat, lay.bucket_range(0), (lay.bucket_range(0)[1], n))
+        sync.start_bucket0()
+        sync.finish()
+        # reference: explicit sum of both ranks' gradients
+        other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)), dtype=torch.float64)
+        other[s0:e0] = 0
+        assert torch.allclose(flat, g_local + other, atol=1e-12)
+        # AdamW with grad_scale = 1/world == AdamW on the averaged gradient, only on the ranges with gradients
+        p = torch.zeros(n, dtype=torch.float64) + 0.1
+        m = torch.zeros(n, dtype=torch.float64); v = torch.zeros(n, dtype=torch.float64)
+        p_ref = p.clone()
+        for s, e, wd in lay.adam_ranges(S, 0.05):
+            p[s:e], m[s:e], v[s:e] = R.adamw_step(p[s:e], flat[s:e] * sync.grad_scale, m[s:e], v[s:e], 1, 1e-3, wd=wd)
+            p_ref[s:e], _, _ = R.adamw_step(p_ref[s:e], (g_local[s:e] + other[s:e]) / world, torch.zeros(e - s, dtype=torch.float64),
+                                             torch.zeros(e - s, dtype=torch.float64), 1, 1e-3, wd=wd)
+        assert torch.equal(p, p_ref)
+        assert torch.all(p[s0:e0] == 0.1)  # skipped (no gradient), like torch AdamW with grad None
+        # every rank holds identical parameters and the same shot_num
+        gather = [torch.zeros_like(p) for _ in range(world)]
+        dist.all_gather(gather, p)
+        assert torch.equal(gather[0], gather[1])
+        shots = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(shots, torch.tensor([S]))
+        assert int(shots[0]) == int(shots[1])
+        out.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        out.put((rank, "FAIL: %r" % (e,)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_sync_and_adamw():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_data_parallel_gradient_equals_large_batch_gradient():
+    """Sharding a batch over 2 ranks and averaging gradients == the single-process gradient of the whole batch
+    (the loss divides by the local batch, FSC_finetune_cross.py:295), checked with the CPU oracle on the reduced model."""
+    from oracle import countr_ref as R, weights as W
+    name = "tiny_test"
+    sd = W.make_state_dict(name, seed=3)
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=4)
+    _, _, g_all = R.loss_and_grads(sd, imgs, boxes, gt, mask, 3, name, dtype=torch.float64)
+    parts = [R.loss_and_grads(sd, imgs[i:i + 1], boxes[i:i + 1], gt[i:i + 1], mask, 3, name, dtype=torch.float64)[2] for i in range(2)]
+    for k, g in g_all.items():
+        if g is None:
+            continue
+        avg = (parts[0][k] + parts[1][k]) / 2
+        assert (avg - g).abs().max() <= 1e-9 * max(g.abs().max().item(), 1e-12) + 1e-15, k
