@@ -35,7 +35,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
