@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Few-/zero-shot evaluation CLI with the reference's flags (FSC_test_cross(few-shot).py:26-78), running the MI355X engine.
+
+`--box_bound 0` = zero-shot.  With the FSC147 files present (--data_path/--anno_file/--data_split_file/--im_dir) images are
+loaded with PIL exactly as TestData does (:134-190: height 384, width 16*int(W/H*384/16), exemplar crops resized to 64x64).
+Without a dataset (none is available offline) `--synthetic N` evaluates N synthetic wide images through the same
+sliding-window / stitching / normalisation code (countr_amd/inference.py)."""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+import models_mae_cross
+from countr_amd import inference
+from countr_amd.util import misc
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("CounTR testing (MI355X engine)", add_help=True)
+    p.add_argument("--model", default="mae_vit_base_patch16", type=str)
+    p.add_argument("--mask_ratio", default=0.5, type=float)
+    p.add_argument("--norm_pix_loss", action="store_true")
+    p.add_argument("--data_path", default="./data/FSC147/", type=str)
+    p.add_argument("--anno_file", default="annotation_FSC147_384.json", type=str)
+    p.add_argument("--data_split_file", default="Train_Test_Val_FSC_147.json", type=str)
+    p.add_argument("--im_dir", default="images_384_VarV2", type=str)
+    p.add_argument("--output_dir", default="./Image")
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--resume", default="./output_fim6_dir/checkpoint-0.pth")
+    p.add_argument("--external", action="store_true")
+    p.add_argument("--box_bound", default=-1, type=int)
+    p.add_argument("--split", default="test", type=str)
+    p.add_argument("--max_s_cnt", default=1, type=int)
+    p.add_argument("--num_workers", default=0, type=int)
+    p.add_argument("--pin_mem", action="store_true")
+    p.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
+    p.set_defaults(pin_mem=True)
+    p.add_argument("--normalization", default=True)
+    p.add_argument("--world_size", default=1, type=int)
+    p.add_argument("--local_rank", default=-1, type=int)
+    p.add_argument("--dist_on_itp", action="store_true")
+    p.add_argument("--dist_url", default="env://")
+    # additions
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="the reference tests in fp32")
+    p.add_argument("--synthetic", default=0, type=int, help="evaluate N synthetic images instead of FSC147")
+    return p
+
+
+def load_fsc147_item(args, annotations, im_id):
+    """TestData.__getitem__ (FSC_test_cross(few-shot).py:134-190) with PIL only."""
+    from PIL import Image
+    anno = annotations[im_id]
+    bboxes = anno["box_examples_coordinates"] if args.box_bound < 0 else anno["box_examples_coordinates"][:args.box_bound]
+    dots = np.array(anno["points"])
+    image = Image.open(os.path.join(args.data_path, args.im_dir, im_id)).convert("RGB")
+    W, H = image.size
+    new_H, new_W = 384, 16 * int((W / H * 384) / 16)
+    sh, sw = new_H / H, new_W / W
+    image = image.resize((new_W, new_H), Image.BILINEAR)
+    img = torch.from_numpy(np.asarray(image, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    boxes, pos = [], []
+    for bbox in bboxes:
+        x1, y1, x2, y2 = int(bbox[0][0] * sw), int(bbox[0][1] * sh), int(bbox[2][0] * sw), int(bbox[2][1] * sh)
+        crop = img[:, y1:y2 + 1, x1:x2 + 1].unsqueeze(0)
+        boxes.append(torch.nn.functional.interpolate(crop, size=(64, 64), mode="bilinear", align_corners=False)[0])
+        pos.append((y1, x1, y2, x2))
+    boxes = torch.stack(boxes) if boxes else torch.zeros(0)
+    return img, boxes, pos, dots.shape[0]
+
+
+def main(args):
+    misc.init_distributed_mode(args)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    device = torch.device(args.device)
+    model = models_mae_cross.__dict__[args.model](norm_pix_loss=args.norm_pix_loss, precision=args.precision)
+    misc.load_model_FSC(args, model)
+    model.to(device).eval()
+    items = []
+    if args.synthetic:
+        rs = np.random.RandomState(args.seed)
+        for i in range(args.synthetic):
+            w = 16 * int(rs.randint(24, 60))
+            img = torch.from_numpy(rs.uniform(0, 1, size=(3, 384, w)).astype(np.float32))
+            k = 3 if args.box_bound < 0 else min(args.box_bound, 3)
+            boxes = torch.from_numpy(rs.uniform(0, 1, size=(k, 3, 64, 64)).astype(np.float32)) if k else torch.zeros(0)
+            pos = [(10 * j, 10 * j, 10 * j + 40, 10 * j + 40) for j in range(k)]
+            items.append(("synthetic_%d" % i, img, boxes, pos, int(rs.randint(5, 200))))
+    else:
+        annotations = json.load(open(os.path.join(args.data_path, args.anno_file)))
+        split = json.load(open(os.path.join(args.data_path, args.data_split_file)))[args.split]
+        for im_id in split:
+            img, boxes, pos, gt = load_fsc147_item(args, annotations, im_id)
+            items.append((im_id, img, boxes, pos, gt))
+    from countr_amd.parallel import shard_batch
+    lo, hi = shard_batch(len(items), misc.get_rank(), misc.get_world_size())   # replicas only: images sharded, no collective
+    mae = rmse = nae = 0.0
+    t_inf = 0.0
+    for name, img, boxes, pos, gt_cnt in items[lo:hi]:
+        samples = img.unsqueeze(0).to(device)
+        bx = boxes.unsqueeze(0).to(device)
+        num_boxes = bx.shape[1] if bx.nelement() > 0 else 0
+        t0 = time.time()
+        pred, _ = inference.count_image(model, samples, bx, num_boxes, pos=pos, normalization=bool(args.normalization),
+                                        max_s_cnt=args.max_s_cnt)
+        torch.cuda.synchronize()
+        t_inf += time.time() - t0
+        err = abs(pred - gt_cnt)
+        mae += err; rmse += err ** 2; nae += err / gt_cnt if gt_cnt > 0 else 0
+        print("%s: pred_cnt: %5.3f, gt_cnt: %5.3f, error: %5.3f" % (name, pred, gt_cnt, err))
+    n = max(hi - lo, 1)
+    print(json.dumps({"MAE": mae / n, "RMSE": (rmse / n) ** 0.5, "NAE": nae / n, "images": hi - lo, "mean_infer_time_s": t_inf / n}))
+
+
+if __name__ == "__main__":
+    main(get_args_parser().parse_args())

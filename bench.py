@@ -24,7 +24,7 @@ ATT_FLOP_PER_IMG_LAYER = 4 * 576 * 576 * 64 * 12  # 4 N^2 dh H = 1.0192 GF
 MFMA_BF16_PEAK = 2.5e15
 
 
-def cpu_baseline(batch=2, steps=1, threads=None):
+def cpu_baseline(batch=4, steps=4, threads=None):
     """The oracle (CPU restatement of the reference, validated against it) timed on this host's cores.
     Threads are capped at 32: torch-CPU on all 256 hardware threads of the GPU box is ~100x slower (oversubscription)."""
     import numpy as np
@@ -62,8 +62,15 @@ def attention_roofline(model, batch, iters=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     achieved = ATT_FLOP_PER_IMG_LAYER * batch / sec
+    traffic = None
+    try:  # HBM/fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md)
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1_attention_traffic.json")))
+        if batch == 8:
+            traffic = t["after_xcd_mapping"]["bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
     return {"bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_BF16_PEAK, "traffic": None, "kernel": "encoder attention core (QK^T, softmax, PV), %d launches" % len(ops),
+            "frac": achieved / MFMA_BF16_PEAK, "traffic": traffic, "algorithmic_bytes": 28311552 * batch // 8, "kernel": "encoder attention core (QK^T, softmax, PV), %d launches" % len(ops),
             "us_per_launch": sec * 1e6}
 
 

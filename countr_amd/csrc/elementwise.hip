@@ -287,10 +287,13 @@ __global__ void cast_permute_kernel(const float* __restrict__ src, T* __restrict
 
 // ---------------- masked MSE loss + its gradient + counts (FSC_finetune_cross.py:290-303)
 // loss = sum((pred-gt)^2 * mask / HW) / B ; dpred = 2 (pred-gt) mask / (HW * B) * grad_scale
-// sums[0] = loss, sums[1 + b] = sum(pred[b]) / 60, sums[1 + B + b] = sum(gt[b]) / 60   (must be zeroed before)
+// sums[0] = loss, sums[1 + b] = sum(pred[b]) / 60, sums[1 + B + b] = sum(gt[b]) / 60
+// Two deterministic stages (no atomics, no memset: safe under graph replay): per-block partials, then one finisher.
+constexpr int MSE_BLOCKS = 64;
 __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                          const float* __restrict__ mask, float* __restrict__ dpred,
-                                                         float* __restrict__ sums, int B, int HW, float grad_scale) {
+                                                         float* __restrict__ partial /* [B][MSE_BLOCKS][3] */, int B, int HW,
+                                                         float grad_scale) {
   __shared__ float sm[4];
   const int b = blockIdx.y;
   float l = 0.f, sp = 0.f, sg = 0.f;
@@ -306,10 +309,25 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict
   sp = block_sum<4>(sp, sm);
   sg = block_sum<4>(sg, sm);
   if (threadIdx.x == 0) {
-    atomicAdd(sums, l * inv);
-    atomicAdd(sums + 1 + b, sp / 60.f);
-    atomicAdd(sums + 1 + B + b, sg / 60.f);
+    float* o = partial + ((int64_t)b * gridDim.x + blockIdx.x) * 3;
+    o[0] = l * inv; o[1] = sp / 60.f; o[2] = sg / 60.f;
   }
+}
+__global__ __launch_bounds__(64) void masked_mse_finish_kernel(const float* __restrict__ partial, float* __restrict__ sums, int B,
+                                                               int nblk) {
+  // one wave; lane = block partial index
+  float loss = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float l = 0.f, sp = 0.f, sg = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+      const float* o = partial + ((int64_t)b * nblk + i) * 3;
+      l += o[0]; sp += o[1]; sg += o[2];
+    }
+    l = wave_sum(l); sp = wave_sum(sp); sg = wave_sum(sg);
+    loss += l;
+    if (threadIdx.x == 0) { sums[1 + b] = sp; sums[1 + B + b] = sg; }
+  }
+  if (threadIdx.x == 0) sums[0] = loss;
 }
 
 // ---------------- fused AdamW over flat fp32 buffers, with an optional low-precision shadow of the params
@@ -424,11 +442,12 @@ extern "C" int countr_cast_permute(const float* src, void* dst, int64_t n, int m
   COUNTR_LAUNCH_CHECK("countr_cast_permute");
 }
 
-extern "C" int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums, int B,
-                                 int HW, float grad_scale, void* stream) {
-  if (!pred || !gt || !mask || !sums) { countr_set_error("countr_masked_mse: null"); return -1; }
-  (void)hipMemsetAsync(sums, 0, sizeof(float) * (1 + 2 * B), STREAM(stream));
-  hipLaunchKernelGGL(masked_mse_kernel, dim3(nblocks(HW, 256, 64), B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, sums, B, HW, grad_scale);
+extern "C" int countr_masked_mse_workspace_floats(int B) { return B * MSE_BLOCKS * 3; }
+extern "C" int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
+                                 float* workspace, int B, int HW, float grad_scale, void* stream) {
+  if (!pred || !gt || !mask || !sums || !workspace) { countr_set_error("countr_masked_mse: null"); return -1; }
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(MSE_BLOCKS, B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, workspace, B, HW, grad_scale);
+  hipLaunchKernelGGL(masked_mse_finish_kernel, dim3(1), dim3(64), 0, STREAM(stream), workspace, sums, B, MSE_BLOCKS);
   COUNTR_LAUNCH_CHECK("countr_masked_mse");
 }
 

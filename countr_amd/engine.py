@@ -151,6 +151,7 @@ class Engine:
         self._ws = {}
         self._need = {}
         self._sizing = False
+        self.generation = 0
 
     # ------------------------------------------------------------------ parameter views
     def pview(self, name):
@@ -215,8 +216,9 @@ class Engine:
             if cur is None or cur.numel() < numel or cur.dtype != dtype:
                 self._ws[key] = torch.empty(max(numel, 1), device=self.device, dtype=dtype)
                 grew = True
-        if grew:
+        if grew and self.plans:
             self.plans.clear()  # launch lists of older plans hold pointers into the replaced scratch
+            self.generation += 1  # captured graphs built on those plans must be dropped too (see FinetuneStep)
 
     def _gemm(self, ops, dtype_code, ma, mb, **kw):
         a = GemmArgs()
@@ -358,9 +360,13 @@ class Engine:
     def plan(self, B, S, train):
         key = (B, S, bool(train))
         if key not in self.plans:
+            # size the shared scratch for EVERY shot count and both modes of this batch size at once, so that building
+            # another plan later never moves scratch that launch lists (and captured graphs) already point to
             self._sizing = True
             try:
-                self._build(B, S, bool(train))
+                for s_ in sorted({0, 1, 2, 3, S}):
+                    for tr in (False, True):
+                        self._build(B, s_, tr)
             finally:
                 self._sizing = False
             self._reserve()

@@ -24,6 +24,12 @@ class FinetuneStep:
         self.use_graph = use_graph
         self.pg = process_group
         self.graphs = {}
+        # all work of the step (input copies, graph replays, collectives' producers) runs on ONE dedicated non-default
+        # stream; sources are record_stream()'ed so the caching allocator cannot recycle them under a pending copy.
+        # (Captured regions contain kernels only: a hipMemsetAsync node + float atomics gave wrong sums under graph
+        # replay on ROCm 7.2 -- tools/dbg_ft3.py -- so the loss reduction is a deterministic two-stage kernel pair.)
+        self.stream = torch.cuda.Stream(device=self.eng.device)
+        self._gen = self.eng.generation
         self.sums = {}
         lay = self.eng.layout
         self.bucket0 = lay.bucket_range(0)
@@ -32,6 +38,7 @@ class FinetuneStep:
         self.world = self.sync.world
         self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._ring_ev = [None] * 16
+        self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
         self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
 
@@ -41,10 +48,12 @@ class FinetuneStep:
         eng = self.eng
         p = eng.plan(self.B, S, True)
         eng.run(p.fwd)
-        sums = self.sums.setdefault(S, torch.zeros(1 + 2 * self.B, device=eng.device))
+        if S not in self.sums:
+            self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
+        sums = self.sums[S]
         HW = eng.img * eng.img
         _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
-                                           sums.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
+                                           sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
         eng.run(p.bwd_head)
 
     def _phase_b(self, S):
@@ -64,6 +73,9 @@ class FinetuneStep:
         if not self.use_graph:
             fn(S)
             return
+        if self._gen != self.eng.generation:   # the engine re-planned (bigger batch elsewhere): old graphs are stale
+            self.graphs.clear()
+            self._gen = self.eng.generation
         key = (name, S)
         g = self.graphs.get(key)
         if g is None:
@@ -96,25 +108,34 @@ class FinetuneStep:
 
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
-        p = self.eng.plan(self.B, S, True)
-        self.eng._load_inputs(p, imgs, boxes, S)
-        self.gt.copy_(gt, non_blocking=True)
-        self.mask.copy_(mask, non_blocking=True)
+        """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream."""
+        cur = torch.cuda.current_stream(self.eng.device)
+        self.stream.wait_stream(cur)           # producers of the inputs ran on the caller's stream
+        with torch.cuda.stream(self.stream):
+            p = self.eng.plan(self.B, S, True)
+            self.eng._load_inputs(p, imgs, boxes, S)
+            self.gt.copy_(gt, non_blocking=True)
+            self.mask.copy_(mask, non_blocking=True)
+        for t in (imgs, boxes, gt, mask):      # their memory must not be recycled before our copies have run
+            if t.is_cuda:
+                t.record_stream(self.stream)
 
     def step(self, S, lr=None):
         """One optimisation step on the inputs last given to load().  Returns the device tensor
-        [loss, pred counts (B), gt counts (B)] without synchronising."""
+        [loss, pred counts (B), gt counts (B)] without synchronising the host."""
         if lr is not None:
             self.lr = lr
         eng = self.eng
-        if self.eng.M is None:
-            eng.M = torch.zeros_like(eng.G)
-            eng.V = torch.zeros_like(eng.G)
-        self._run_phase("a", self._phase_a, S)
-        self.sync.start_bucket0()          # overlaps with the rest of backward
-        self._run_phase("b", self._phase_b, S)
-        self.sync.finish()
-        self._upload_hyper()
-        self._run_phase("c", self._phase_c, S)
+        with torch.cuda.stream(self.stream):
+            if eng.M is None:
+                eng.M = torch.zeros_like(eng.G)
+                eng.V = torch.zeros_like(eng.G)
+            self._run_phase("a", self._phase_a, S)
+            self.sync.start_bucket0()          # overlaps with the rest of backward
+            self._run_phase("b", self._phase_b, S)
+            self.sync.finish()
+            self._upload_hyper()
+            self._run_phase("c", self._phase_c, S)
+        torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
         self.model.mark_weights_synced()
         return self.sums[S]

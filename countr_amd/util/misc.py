@@ -1,0 +1,72 @@
+"""Minimal harness helpers with the reference's behaviour (util/misc.py:225-257, 304-328, 363-421, 424-432)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def init_distributed_mode(args):
+    """Env-driven init (RANK / WORLD_SIZE / LOCAL_RANK as set by torch.distributed.run), backend nccl == RCCL."""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.gpu = int(os.environ.get("LOCAL_RANK", 0))
+        args.distributed = True
+        torch.cuda.set_device(args.gpu)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size,
+                                rank=args.rank)
+        dist.barrier()
+    else:
+        args.distributed = False
+        args.rank, args.world_size, args.gpu = 0, 1, 0
+
+
+def all_reduce_mean(x):
+    if get_world_size() > 1:
+        t = torch.tensor(float(x), device="cuda")
+        dist.all_reduce(t)
+        return (t / get_world_size()).item()
+    return float(x)
+
+
+def save_model(args, epoch, model_without_ddp, optimizer_state, suffix=""):
+    """Checkpoint dict {'model','optimizer','epoch','scaler','args'} named checkpoint__<suffix>.pth (util/misc.py:304-328).
+    bf16 needs no GradScaler; the key is kept (empty) so reference tooling can read the file."""
+    if not is_main_process() or not args.output_dir:
+        return None
+    os.makedirs(args.output_dir, exist_ok=True)
+    path = os.path.join(args.output_dir, "checkpoint%s.pth" % ("__" + suffix if suffix else ""))
+    torch.save({"model": {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+                "optimizer": optimizer_state, "epoch": epoch, "scaler": {}, "args": vars(args)}, path)
+    return path
+
+
+def load_model_FSC(args, model_without_ddp):
+    """util/misc.py:363-376: strict=False, pos_embed dropped on shape mismatch."""
+    if not args.resume or not os.path.exists(args.resume):
+        return None
+    ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
+    sd = ckpt["model"] if "model" in ckpt else ckpt
+    if "pos_embed" in sd and sd["pos_embed"].shape != model_without_ddp.state_dict()["pos_embed"].shape:
+        print("Removing key pos_embed from pretrained checkpoint")
+        del sd["pos_embed"]
+    model_without_ddp.load_state_dict(sd, strict=False)
+    print("Resume checkpoint %s" % args.resume)
+    return ckpt

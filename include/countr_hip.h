@@ -160,9 +160,11 @@ int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co
                         void* stream);
 
 /* -------- loss + optimizer (FSC_finetune_cross.py:290-303, :235) */
-/* sums (fp32 [1+2B]) = {loss, pred counts[B], gt counts[B]}; dpred optional (= dloss/dpred * grad_scale) */
-int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums, int B,
-                      int HW, float grad_scale, void* stream);
+/* sums (fp32 [1+2B]) = {loss, pred counts[B], gt counts[B]}; dpred optional (= dloss/dpred * grad_scale);
+ * workspace: fp32 [countr_masked_mse_workspace_floats(B)].  Deterministic two-stage reduction. */
+int countr_masked_mse_workspace_floats(int B);
+int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
+                      float* workspace, int B, int HW, float grad_scale, void* stream);
 /* fused AdamW over flat fp32 buffers; up to 8 [start,end) ranges each with its weight decay.
  * hyper_dev (optional, device fp32[4] = {lr, 1-beta1^t, 1-beta2^t, grad_scale}) overrides the scalars so a
  * captured graph can be replayed with new values.  shadow_bf16 (optional) receives bf16(p). */

@@ -289,7 +289,8 @@ def test_masked_mse_and_adamw(hip):
     pd, gd, md = pred.cuda(), gt.cuda(), mask.cuda()
     dp = torch.empty_like(pd)
     sums = torch.empty(1 + 2 * B, device="cuda")
-    _lib.check(hip.countr_masked_mse(P(pd), P(gd), P(md), P(dp), P(sums), B, HW, 1.0, st()))
+    ws = torch.empty(hip.countr_masked_mse_workspace_floats(B), device="cuda")
+    _lib.check(hip.countr_masked_mse(P(pd), P(gd), P(md), P(dp), P(sums), P(ws), B, HW, 1.0, st()))
     pr = pred.double().requires_grad_(True)
     loss = R.masked_mse_loss(pr.reshape(B, 384, 384), gt.double().reshape(B, 384, 384), mask.double().reshape(384, 384))
     loss.backward()

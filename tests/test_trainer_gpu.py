@@ -77,3 +77,20 @@ def test_bf16_step_runs_and_reduces_loss():
         losses.append(step.step(3)[0].item())
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0], losses
+
+
+def test_all_shot_counts_interleaved_with_graphs():
+    """Every shot_num in {0,1,2,3} interleaved (new plans are built while older graphs already exist): the loss of each
+    step must equal an eager single-use engine run on the same weights/inputs."""
+    from countr_amd.trainer import FinetuneStep
+    m, sd = make("fp32")
+    step = FinetuneStep(m, batch=2, lr=1e-4, use_graph=True)
+    losses = {}
+    order = [3, 0, 1, 2, 3, 1, 0, 2]
+    for it, S in enumerate(order):
+        imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=30 + it)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+        cur = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+        loss = step.step(S)[0].item()
+        _, rloss, _ = R.loss_and_grads(cur, imgs, boxes, gt, mask, S, NAME)
+        assert abs(loss - rloss.item()) <= 2e-3 * abs(rloss.item()), (it, S, loss, rloss.item())
