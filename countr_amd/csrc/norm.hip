@@ -132,18 +132,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
   }
 }
 
-// out[c] (+)= sum_p partial[p*stride + c]; block = 64 columns x 4 part lanes
+// out[c] (+)= sum_p partial[p*stride + c]; block = 16 columns x 16 part lanes (short dependent chains: these
+// finishers are latency-bound, not bandwidth-bound)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts,
                                                               int C, int64_t stride, int accumulate) {
   __shared__ float sm[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
   if (c < C)
-    for (int p = pl; p < nparts; p += 4) s += partial[(int64_t)p * stride + c];
+    for (int p = pl; p < nparts; p += 16) s += partial[(int64_t)p * stride + c];
   sm[threadIdx.x] = s;
   __syncthreads();
   if (pl == 0 && c < C) {
-    s = sm[threadIdx.x] + sm[64 + threadIdx.x] + sm[128 + threadIdx.x] + sm[192 + threadIdx.x];
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k * 16 + cl];
     out[c] = accumulate ? out[c] + s : s;
   }
 }
@@ -187,11 +191,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const T* xb = x + (int64_t)b * HW * GN_C;
   float s = 0.f, q = 0.f;
-  for (int p = p0 + slot; p < p1; p += 8) {
-    float v[8];
-    ld8<T>(xb + (int64_t)p * GN_C + cv * 8, v);
+  constexpr int U = 4;
+  for (int pb = p0 + slot; pb < p1; pb += 8 * U) {
+    float v[U][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s += v[e]; q += v[e] * v[e]; }
+    for (int u = 0; u < U; ++u)
+      if (pb + 8 * u < p1) ld8<T>(xb + (int64_t)(pb + 8 * u) * GN_C + cv * 8, v[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (pb + 8 * u >= p1) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s += v[u][e]; q += v[u][e] * v[u][e]; }
+    }
   }
   s = reduce_same_chanvec(s, sm);
   q = reduce_same_chanvec(q, sm);
@@ -260,20 +271,31 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
   if (w1) ld8<float>(w1 + cv * 8, w);
   const float bias1 = w1 ? b1[0] : 0.f;
   const T* xb = x + (int64_t)b * HW * GN_C;
-  for (int p = blockIdx.x * 8 + slot; p < HW; p += gridDim.x * 8) {
-    float v[8];
-    ld8<T>(xb + (int64_t)p * GN_C + cv * 8, v);
-    float dot = 0.f;
+  constexpr int U = 4;
+  const int stride = gridDim.x * 8;
+  for (int p0 = blockIdx.x * 8 + slot; p0 < HW; p0 += stride * U) {
+    float v[U][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e] = fmaxf((v[e] - mu) * rs * ga[e] + be[e], 0.f);
-      if (w1) dot += v[e] * w[e];
-    }
-    if (y) st8<T>(y + ((int64_t)b * HW + p) * GN_C + cv * 8, v);
-    if (w1) {
+    for (int u = 0; u < U; ++u)
+      if (p0 + u * stride < HW) ld8<T>(xb + (int64_t)(p0 + u * stride) * GN_C + cv * 8, v[u]);
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-      if (cv == 0) out1[(int64_t)b * HW + p] = dot + bias1;
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * stride;
+      float dot = 0.f;
+      const bool ok = p < HW;   // keep the shuffles below wave-uniform
+      if (ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[u][e] = fmaxf((v[u][e] - mu) * rs * ga[e] + be[e], 0.f);
+          if (w1) dot += v[u][e] * w[e];
+        }
+        if (y) st8<T>(y + ((int64_t)b * HW + p) * GN_C + cv * 8, v[u]);
+      }
+      if (w1) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (ok && cv == 0) out1[(int64_t)b * HW + p] = dot + bias1;
+      }
     }
   }
 }
@@ -302,20 +324,31 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sgx[e] = 0.f; sw[e] = 0.f; }
   const int64_t base = (int64_t)b * HW * GN_C;
-  for (int p = p0 + slot; p < p1; p += 8) {
-    float v[8], d[8];
-    ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v);
-    float dd = 0.f;
-    if (w1) dd = d1[(int64_t)b * HW + p];
-    else ld8<T>(dy + base + (int64_t)p * GN_C + cv * 8, d);
+  constexpr int U = 4;
+  for (int pb = p0 + slot; pb < p1; pb += 8 * U) {
+    float v[U][8], d[U][8], dd[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float xh = (v[e] - mu) * rs;
-      const float yv = xh * ga[e] + be[e];
-      const float gg = (yv > 0.f) ? (w1 ? dd * w[e] : d[e]) : 0.f;
-      sg[e] += gg;
-      sgx[e] += gg * xh;
-      if (w1) sw[e] += dd * fmaxf(yv, 0.f);
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + 8 * u;
+      dd[u] = 0.f;
+      if (p < p1) {
+        ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v[u]);
+        if (w1) dd[u] = d1[(int64_t)b * HW + p];
+        else ld8<T>(dy + base + (int64_t)p * GN_C + cv * 8, d[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (pb + 8 * u >= p1) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[u][e] - mu) * rs;
+        const float yv = xh * ga[e] + be[e];
+        const float gg = (yv > 0.f) ? (w1 ? dd[u] * w[e] : d[u][e]) : 0.f;
+        sg[e] += gg;
+        sgx[e] += gg * xh;
+        if (w1) sw[e] += dd[u] * fmaxf(yv, 0.f);
+      }
     }
   }
   float* o = partial + ((int64_t)b * ns + split) * 3 * GN_C;
@@ -365,20 +398,34 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restr
   ld8<float>(beta + cv * 8, be);
   if (w1) ld8<float>(w1 + cv * 8, w);
   const int64_t base = (int64_t)b * HW * GN_C;
-  for (int p = blockIdx.x * 8 + slot; p < HW; p += gridDim.x * 8) {
-    float v[8], d[8], o[8];
-    ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v);
-    float dd = 0.f;
-    if (w1) dd = d1[(int64_t)b * HW + p];
-    else ld8<T>(dy + base + (int64_t)p * GN_C + cv * 8, d);
+  constexpr int U = 4;  // pixels in flight per thread (memory-level parallelism; the kernel is HBM-bound)
+  const int stride = gridDim.x * 8;
+  for (int p0 = blockIdx.x * 8 + slot; p0 < HW; p0 += stride * U) {
+    float v[U][8], d[U][8], dd[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float xh = (v[e] - mu) * rs;
-      const float yv = xh * ga[e] + be[e];
-      const float gg = (yv > 0.f) ? (w1 ? dd * w[e] : d[e]) : 0.f;
-      o[e] = rs * (gg * ga[e] - m1 - xh * m2);
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * stride;
+      dd[u] = 0.f;
+      if (p < HW) {
+        ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v[u]);
+        if (w1) dd[u] = d1[(int64_t)b * HW + p];
+        else ld8<T>(dy + base + (int64_t)p * GN_C + cv * 8, d[u]);
+      }
     }
-    st8<T>(dx + base + (int64_t)p * GN_C + cv * 8, o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * stride;
+      if (p >= HW) continue;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[u][e] - mu) * rs;
+        const float yv = xh * ga[e] + be[e];
+        const float gg = (yv > 0.f) ? (w1 ? dd[u] * w[e] : d[u][e]) : 0.f;
+        o[e] = rs * (gg * ga[e] - m1 - xh * m2);
+      }
+      st8<T>(dx + base + (int64_t)p * GN_C + cv * 8, o);
+    }
   }
 }
 
@@ -599,14 +646,14 @@ extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float*
   if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
   // workspace rows are {dgamma[D], dbeta[D]} per block
-  if (dgamma) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, D, (int64_t)2 * D, accumulate_dgb);
-  if (dbeta) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, STREAM(stream), workspace + D, dbeta, nb, D, (int64_t)2 * D, accumulate_dgb);
+  if (dgamma) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, D, (int64_t)2 * D, accumulate_dgb);
+  if (dbeta) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, STREAM(stream), workspace + D, dbeta, nb, D, (int64_t)2 * D, accumulate_dgb);
   COUNTR_LAUNCH_CHECK("countr_layernorm_bwd");
 }
 
 extern "C" int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream) {
   if (!partial || !out) { countr_set_error("countr_colsum_partials: null"); return -1; }
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, STREAM(stream), partial, out, nparts, C, (int64_t)C, accumulate);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, STREAM(stream), partial, out, nparts, C, (int64_t)C, accumulate);
   COUNTR_LAUNCH_CHECK("countr_colsum_partials");
 }
 
@@ -648,7 +695,7 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   float* outs[3] = {dbeta, dgamma, dw1};
   for (int i = 0; i < 3; ++i) {
     if (!outs[i]) continue;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(GN_C / 64), dim3(256), 0, STREAM(stream), workspace + i * GN_C, outs[i], B * ns, GN_C,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(GN_C / 16), dim3(256), 0, STREAM(stream), workspace + i * GN_C, outs[i], B * ns, GN_C,
                        (int64_t)3 * GN_C, accumulate);
   }
   if (db1 && d1) {  // the reduce/apply kernels are done with the first 64 floats of row 0's third plane only via dw1: use the tail
