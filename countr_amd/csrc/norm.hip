@@ -365,34 +365,39 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
   }
 }
 
+// Backward pass 1b (one block per image): per-(image, group) means of g*gamma and g*gamma*xhat from the split partials.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                              float* __restrict__ gm /* [B][G][2] */, int HW, int G, int ns) {
+  const int b = blockIdx.x, c = threadIdx.x;  // 256 channels
+  float a = 0.f, q = 0.f;
+  for (int s = 0; s < ns; ++s) {
+    const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
+    a += o[c];
+    q += o[GN_C + c];
+  }
+  const float ga = gamma[c];
+  a *= ga; q *= ga;
+  const int cpg = GN_C / G;  // 32 channels per group: reduce inside each 32-lane half wave
+  for (int off = cpg >> 1; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
+  if ((c % cpg) == 0) {
+    const float n = (float)HW * cpg;
+    gm[((int64_t)b * G + c / cpg) * 2] = a / n;
+    gm[((int64_t)b * G + c / cpg) * 2 + 1] = q / n;
+  }
+}
+
 // Backward pass 2: dx = rstd * (g*gamma - m1 - xhat*m2), m1/m2 = group means of g*gamma, g*gamma*xhat.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 const float* __restrict__ d1, const float* __restrict__ w1,
                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, const float* __restrict__ partial,
+                                                                const float* __restrict__ beta, const float* __restrict__ gm,
                                                                 T* __restrict__ dx, int HW, int G, int ns) {
-  __shared__ float sm_m1[32], sm_m2[32];
   const int b = blockIdx.y;
-  if (threadIdx.x < G) {
-    const int cpg = GN_C / G;
-    float a = 0.f, c = 0.f;
-    for (int s = 0; s < ns; ++s) {
-      const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
-      for (int ch = threadIdx.x * cpg; ch < (threadIdx.x + 1) * cpg; ++ch) {
-        a += o[ch] * gamma[ch];
-        c += o[GN_C + ch] * gamma[ch];
-      }
-    }
-    const float n = (float)HW * cpg;
-    sm_m1[threadIdx.x] = a / n;
-    sm_m2[threadIdx.x] = c / n;
-  }
-  __syncthreads();
   const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int g = (cv * 8) / (GN_C / G);
   const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
-  const float m1 = sm_m1[g], m2 = sm_m2[g];
+  const float m1 = gm[((int64_t)b * G + g) * 2], m2 = gm[((int64_t)b * G + g) * 2 + 1];  // from gn_bwd_finalize_kernel
   float ga[8], be[8], w[8];
   ld8<float>(gamma + cv * 8, ga);
   ld8<float>(beta + cv * 8, be);
@@ -684,12 +689,16 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   if (!x || !stats || !gamma || !beta || !dx || !workspace || C != GN_C || (!dy && !(d1 && w1))) { countr_set_error("countr_groupnorm_relu_bwd: bad args"); return -1; }
   const int ns = gn_splits(HW);
   const int nblk = min((HW + 7) / 8, 512);
+  float* gmean = workspace + (int64_t)B * ns * 3 * GN_C + 64;  // [B][G][2] behind the partials and the d1 sums
+  if (G != 8) { countr_set_error("countr_groupnorm_relu_bwd: G must be 8"); return -1; }
   if (dtype == COUNTR_BF16) {
     hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
-    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, (bf16_t*)dx, HW, G, ns);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, HW, G, ns);
+    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);
   } else {
     hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
-    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, (float*)dx, HW, G, ns);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, HW, G, ns);
+    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, gmean, (float*)dx, HW, G, ns);
   }
   // parameter gradients: partial[p] = {sum g (dbeta) [C], sum g*xhat (dgamma) [C], sum d1*y (dw1) [C]}
   float* outs[3] = {dbeta, dgamma, dw1};

@@ -486,7 +486,7 @@ class Engine:
         cin = [Dd, 256, 256, 256]
         hin = [dn]
         hc, hstats = [], []
-        gn_ws = self._shared("gn", B * 64 * 3 * 256 + 64)
+        gn_ws = self._shared("gn", B * 64 * 3 * 256 + 64 + 16 * B)
         o1 = A("o1", (B, hs[3] * hs[3]), f32)
         out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
         hact_tmp = self._shared("hact_tmp", B * hs[2] * hs[2] * 256, T)
