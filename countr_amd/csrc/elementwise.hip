@@ -429,8 +429,8 @@ extern "C" int countr_gelu_bwd(const void* dh, const void* pre, void* dpre, int6
   COUNTR_LAUNCH_CHECK("countr_gelu_bwd");
 }
 
-extern "C" int countr_colsum_nparts(void) { return 64; }
-// workspace: fp32 [64][N]
+extern "C" int countr_colsum_nparts(void) { return 256; }
+// workspace: fp32 [256][N]
 extern "C" int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, int accumulate, void* stream);
 
 extern "C" int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co, int Ci, int taps, int dtype,
@@ -469,7 +469,7 @@ extern "C" int countr_colsum(const void* x, float* out, float* workspace, int M,
   int CV = N / 8; if (CV > 32) CV = 32;
   while (256 % CV) --CV;                      // CV must divide 256 (N/8 is 64, 32, 16, ... for our shapes)
   const int ctiles = (N / 8 + CV - 1) / CV;
-  int parts = 1024 / ctiles; if (parts > 64) parts = 64; if (parts < 1) parts = 1;
+  int parts = 2048 / ctiles; if (parts > 256) parts = 256; if (parts < 1) parts = 1;   // >= ~2k workgroups on 256 CUs
   const int rl = 256 / CV;
   if (parts > (M + rl - 1) / rl) parts = (M + rl - 1) / rl;
   dim3 grid(ctiles, parts);

@@ -180,7 +180,7 @@ template <typename T> struct Loader<T, COUNTR_OP_IM2COL> {
 // bf16 path: direct-to-LDS staging (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write).
 // The DMA destination is lane-linear (wave-uniform base + lane*16), so tiles are stored unpadded and the
 // bank-conflict swizzle is applied to the per-lane SOURCE address and again on the fragment read:
-//   row-like tile [128 rows][8 chunks]  : chunk c of row r lives in slot  c ^ ((r >> 1) & 7)
+//   row-like tile [128 rows][8 chunks]  : chunk c of row r lives in slot  c ^ swz_row(r)
 //   col-like tile [64 k-rows][16 chunks]: chunk c of k-row k lives in slot c ^ swz_col(k)
 // Masked chunks (padding pixels, ragged edges) read a 16-byte zero page instead, so every lane always issues.
 // ---------------------------------------------------------------------------------------------
@@ -192,6 +192,10 @@ __device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((glb_vptr_t)g, (lds_vptr_t)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ int swz_col(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+// row-like tiles: a 16-lane fragment group reads rows  base + (i>>2)*16 + (i&3)  (i = 0..15), i.e. row bits {0,1,4,5}
+// vary.  Bit 0 selects the half of the 256-B bank row (rows are 128 B); bits {1,4,5} feed the 3-bit chunk swizzle, so the
+// 16 lanes hit 16 distinct 16-byte slots (conflict-free ds_read_b128).
+__device__ __forceinline__ int swz_row(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
 
 constexpr int DMA_OP_BYTES = 16384;  // 128 x 64 bf16, unpadded
 
@@ -199,21 +203,21 @@ template <int MODE> struct DmaLoader;
 
 template <> struct DmaLoader<COUNTR_OP_ROW> {
   const char* rp[4];
-  int kc;
+  int kc[2];  // swizzled k-chunk (elements) for even / odd i (row bit 5 = i & 1)
   __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
-    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = row0 + (tid >> 3) + 32 * i;
+      const int rl = (tid >> 3) + 32 * i;
+      if (i < 2) kc[i] = ((tid & 7) ^ swz_row(rl)) * 8;
+      const int r = row0 + rl;
       rp[i] = (r < d.rows) ? d.ptr + (int64_t)r * d.ld * 2 : nullptr;
     }
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
-    const int k = k0 + kc;
-    const bool kok = (k + 8) <= kend;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const void* src = (kok && rp[i]) ? (const void*)(rp[i] + (int64_t)k * 2) : (const void*)g_zero_page;
+      const int k = k0 + kc[i & 1];
+      const void* src = ((k + 8) <= kend && rp[i]) ? (const void*)(rp[i] + (int64_t)k * 2) : (const void*)g_zero_page;
       dma16(src, lds + (i * 4 + wave) * 1024);
     }
   }
@@ -241,13 +245,14 @@ template <> struct DmaLoader<COUNTR_OP_COL> {
 template <> struct DmaLoader<COUNTR_OP_IM2ROW> {
   const char* ptr;
   int pix[4], py[4], px[4];
-  int H, W, C, kc;
+  int H, W, C, kc[2];
   __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
     ptr = d.ptr; H = d.H; W = d.W; C = d.C;
-    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = row0 + (tid >> 3) + 32 * i;
+      const int rl = (tid >> 3) + 32 * i;
+      if (i < 2) kc[i] = ((tid & 7) ^ swz_row(rl)) * 8;
+      const int m = row0 + rl;
       pix[i] = (m < d.rows) ? m : -1;
       px[i] = m % W;
       py[i] = (m / W) % H;
@@ -255,14 +260,14 @@ template <> struct DmaLoader<COUNTR_OP_IM2ROW> {
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
     const int tap = k0 / C;
-    const int ci = k0 - tap * C + kc;
+    const int cbase = k0 - tap * C;
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const bool kok = (k0 + kc + 8) <= kend;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = kok && pix[i] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      const void* src = ok ? (const void*)(ptr + ((int64_t)(pix[i] + dy * W + dx) * C + ci) * 2) : (const void*)g_zero_page;
+      const int kcs = kc[i & 1];
+      const bool ok = (k0 + kcs + 8) <= kend && pix[i] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const void* src = ok ? (const void*)(ptr + ((int64_t)(pix[i] + dy * W + dx) * C + cbase + kcs) * 2) : (const void*)g_zero_page;
       dma16(src, lds + (i * 4 + wave) * 1024);
     }
   }
@@ -313,7 +318,7 @@ template <int MODE>
 __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row, int row4, int kk, int lane) {
   const int g = lane >> 4, i = lane & 15;
   if constexpr (is_rowlike(MODE)) {
-    return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + (((kk * 4 + g) ^ ((row >> 1) & 7)) << 4));
+    return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + (((kk * 4 + g) ^ swz_row(row)) << 4));
   } else {
     // K-major image [k][row]: two hardware-transposing reads of a [4 k][16 rows] block each.
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
@@ -391,6 +396,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   // so that a lane ends up holding 16 consecutive output columns (vector stores in the epilogue).
   const int nrow_base = wn0 + (li >> 2) * 16 + (li & 3);
   const int nrow4_base = wn0 + (li & 3) * 16;
+  // M-side: row-like bf16 operands use the same permuted row order as the N side (conflict-free swizzle, see swz_row);
+  // the lane's output row for tile tm follows.  K-strided / fp32 operands keep consecutive rows.
+  constexpr bool MPERM = (sizeof(T) == 2) && is_rowlike(MA);
+  auto mrow = [&](int tm) { return MPERM ? (wm0 + (li >> 2) * 16 + tm * 4 + (li & 3)) : (wm0 + tm * 16 + li); };
   const int ntiles = (kend > kstart) ? (kend - kstart + BK - 1) / BK : 0;
 
   if constexpr (sizeof(T) == 2) {
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
         bf16x8_t xf[4], wf[4];
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
-          xf[tm] = frag_bf16<MA>(sa, wm0 + tm * 16 + li, wm0 + tm * 16 + (li & 3) * 4, kk, lane);
+          xf[tm] = frag_bf16<MA>(sa, mrow(tm), wm0 + tm * 16 + (li & 3) * 4, kk, lane);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
           wf[tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   const int nb = n0 + wn0 + gq * 16;
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm0 + tm * 16 + li;
+    const int m = m0 + mrow(tm);
     if (m >= g.M) continue;
     if (split) {
       float* dst = g.partial + ((int64_t)z * g.M + m) * g.N + nb;

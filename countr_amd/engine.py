@@ -152,6 +152,8 @@ class Engine:
         self._need = {}
         self._sizing = False
         self.generation = 0
+        self._sides = None
+        self.parallel_lanes = False  # measured on MI355X: fork/join of the small backward branches is a wash (9.62 vs 9.56 ms)
 
     # ------------------------------------------------------------------ parameter views
     def pview(self, name):
@@ -233,9 +235,55 @@ class Engine:
     def _op(self, ops, fn, *args):
         ops.append((fn, args, None))
 
+    # ---- parallel branches: ops between FORK and JOIN are distributed over up to 3 stream "lanes" (lane 0 = the caller's
+    # stream).  Under graph capture the event fork/join becomes parallel branches of the hipGraph, so independent small
+    # kernels (bias-grad, wgrad, dgrad of one layer) share the GPU instead of running back to back.
+    FORK, JOIN = ("fork",), ("join",)
+
+    def _fork(self, ops):
+        ops.append((None, self.FORK, None))
+
+    def _lane(self, ops, k):
+        ops.append((None, ("lane", k), None))
+
+    def _join(self, ops):
+        ops.append((None, self.JOIN, None))
+
+    def _side_streams(self):
+        if self._sides is None:
+            self._sides = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            self._fork_ev = torch.cuda.Event()
+            self._join_ev = [torch.cuda.Event() for _ in range(2)]
+        return self._sides
+
     def run(self, ops, stream=None):
-        st = self._stream() if stream is None else stream
+        main = torch.cuda.current_stream(self.device)
+        st_main = C.c_void_p(main.cuda_stream) if stream is None else stream
+        st = st_main
+        used = set()
         for fn, args, _keep in ops:
+            if fn is None:
+                if not self.parallel_lanes:
+                    continue
+                sides = self._side_streams()
+                if args is self.FORK:
+                    self._fork_ev.record(main)
+                    for sd in sides:
+                        sd.wait_event(self._fork_ev)
+                    used = set()
+                elif args is self.JOIN:
+                    for k in sorted(used):
+                        self._join_ev[k].record(sides[k])
+                        main.wait_event(self._join_ev[k])
+                    st = st_main
+                else:
+                    k = args[1]
+                    if k == 0:
+                        st = st_main
+                    else:
+                        st = C.c_void_p(sides[k - 1].cuda_stream)
+                        used.add(k - 1)
+                continue
             rc = fn(*args, st)
             if rc != 0:
                 _lib.check(rc, getattr(fn, "__name__", "countr op"))
@@ -267,7 +315,7 @@ class Engine:
         self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, 0)
 
     def _bias_grad(self, ops, dy, bname, M, N):
-        ws = self._shared("colsum", 64 * 4096)
+        ws = self._shared("colsum", 256 * 4096)
         self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, 0)
 
     def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None):
@@ -276,6 +324,18 @@ class Engine:
         self._gemm(ops, self.code, OP_ROW, OP_COL, A=dy.data_ptr(), B=self._wp(wname), C=dx.data_ptr(),
                    resid=(resid.data_ptr() if resid is not None else None), lda=N, ldb=K, ldc=K, ldres=K, M=M, N=K, K=N,
                    out_bf16=int(out_bf16))
+
+    def _linear_bwd(self, ops, dy, x, wname, M, N, K, dx=None, resid=None, dx_bf16=None):
+        """bias grad | weight grad | input grad of one nn.Linear: three independent branches."""
+        self._fork(ops)
+        self._lane(ops, 1)
+        self._bias_grad(ops, dy, wname[:-6] + "bias", M, N)
+        self._lane(ops, 2)
+        self._linear_wgrad(ops, dy, x, wname, M, N, K)
+        if dx is not None:
+            self._lane(ops, 0)
+            self._linear_dgrad(ops, dy, wname, dx, M, N, K, resid=resid, out_bf16=dx_bf16)
+        self._join(ops)
 
     def _cast(self, ops, src_f32, dst_t, n):
         if self.code == F32:
@@ -322,23 +382,31 @@ class Engine:
         dS = self._shared("probs", B * heads * N * N, self.tdt)
         ob = int(self.code == BF16)
         nb = dict(nbatch=B * heads, nb1=heads)
+        self._fork(ops)
+        self._lane(ops, 1)
         # dV[j,d] = sum_i P[i,j] dO[i,d]
         self._gemm(ops, self.code, OP_COL, OP_COL, A=probs.data_ptr(), B=dout.data_ptr(), C=dqkv.data_ptr() + 2 * Dm * es,
                    lda=N, ldb=Dm, ldc=3 * Dm, M=N, N=dh, K=N, sA0=heads * N * N, sA1=N * N, sB0=N * Dm, sB1=dh,
                    sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
+        self._lane(ops, 0)
         # dP[i,j] = sum_d dO[i,d] V[j,d]
         self._gemm(ops, self.code, OP_ROW, OP_ROW, A=dout.data_ptr(), B=qkv.data_ptr() + 2 * Dm * es, C=dP.data_ptr(),
                    lda=Dm, ldb=3 * Dm, ldc=N, M=N, N=N, K=dh, sA0=N * Dm, sA1=dh, sB0=N * 3 * Dm, sB1=dh,
                    sC0=heads * N * N, sC1=N * N, out_bf16=0, **nb)
         self._op(ops, self.L.countr_softmax_bwd, probs.data_ptr(), dP.data_ptr(), dS.data_ptr(), B * heads * N, N, scale, self.code)
+        self._join(ops)
+        self._fork(ops)
+        self._lane(ops, 1)
         # dQ[i,d] = sum_j dS[i,j] K[j,d]
         self._gemm(ops, self.code, OP_ROW, OP_COL, A=dS.data_ptr(), B=qkv.data_ptr() + Dm * es, C=dqkv.data_ptr(),
                    lda=N, ldb=3 * Dm, ldc=3 * Dm, M=N, N=dh, K=N, sA0=heads * N * N, sA1=N * N, sB0=N * 3 * Dm, sB1=dh,
                    sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
+        self._lane(ops, 0)
         # dK[j,d] = sum_i dS[i,j] Q[i,d]
         self._gemm(ops, self.code, OP_COL, OP_COL, A=dS.data_ptr(), B=qkv.data_ptr(), C=dqkv.data_ptr() + Dm * es,
                    lda=N, ldb=3 * Dm, ldc=3 * Dm, M=N, N=dh, K=N, sA0=heads * N * N, sA1=N * N, sB0=N * 3 * Dm, sB1=dh,
                    sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
+        self._join(ops)
 
     # 3x3 conv (NHWC, pad 1) as implicit GEMM
     def _conv_fwd(self, ops, x, w_ohwi, bias_ptr, out, Bn, H, W, Cin, Cout):
@@ -534,13 +602,23 @@ class Engine:
                 self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), dact.data_ptr(), None, None, hstats[i].data_ptr(),
                          self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), self._gp(hn + ".1.weight"),
                          self._gp(hn + ".1.bias"), None, None, gn_ws.data_ptr(), B, HW, 256, 8, code, 0)
+            big = hs[i] >= 96   # each of these kernels fills the GPU on its own: forking only adds contention
+            if not big:
+                self._fork(ops)
+                self._lane(ops, 1)
             self._bias_grad(ops, dpre, hn + ".0.bias", B * HW, 256)
+            if not big:
+                self._lane(ops, 2)
             self._conv_wgrad(ops, dpre, hin[i], hn + ".0.weight", B, hs[i], hs[i], cin[i], 256)
             # dgrad == forward conv of dpre with the dgrad-form weights (Cin_gemm = 256 output channels)
+            if not big:
+                self._lane(ops, 0)
             tgt = dup if i > 0 else ddn
             self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dpre.data_ptr(), B=self.Wd[hn + ".0.weight"].data_ptr(), C=tgt.data_ptr(),
                        ldb=9 * 256, ldc=cin[i], M=B * HW, N=cin[i], K=9 * 256, H=hs[i], W=hs[i], Cin=256,
                        out_bf16=int(code == BF16))
+            if not big:
+                self._join(ops)
         gx = A("gx", (rows, Dd), f32)
         gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
         self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False)
@@ -563,24 +641,16 @@ class Engine:
             d = blk[i]
             # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))
             g_t = self._cast(ops, gx, gxT, rows * Dd)
-            self._bias_grad(ops, g_t, b + ".mlp.fc2.bias", rows, Dd)
-            self._linear_wgrad(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd)
-            self._linear_dgrad(ops, g_t, b + ".mlp.fc2.weight", dh, rows, Dd, 4 * Dd)
+            self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh)
             self._op(ops, L.countr_gelu_bwd, dh.data_ptr(), d["hpre"].data_ptr(), dh.data_ptr(), rows * 4 * Dd, code)
-            self._bias_grad(ops, dh, b + ".mlp.fc1.bias", rows, 4 * Dd)
-            self._linear_wgrad(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd)
-            self._linear_dgrad(ops, dh, b + ".mlp.fc1.weight", dn_t, rows, 4 * Dd, Dd)
+            self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t)
             self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True)
             # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
             g_t = self._cast(ops, gx, gxT, rows * Dd)
-            self._bias_grad(ops, g_t, b + ".attn.proj.bias", rows, Dd)
-            self._linear_wgrad(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd)
-            self._linear_dgrad(ops, g_t, b + ".attn.proj.weight", dproj_in, rows, Dd, Dd)
+            self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
             self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
                      dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code)
-            self._bias_grad(ops, dq, b + ".attn.wq.bias", rows, Dd)
-            self._linear_wgrad(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd)
-            self._linear_dgrad(ops, dq, b + ".attn.wq.weight", dn_t, rows, Dd, Dd)
+            self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
             self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True)
             dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
             dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
@@ -592,21 +662,16 @@ class Engine:
                 first_tok = False
             # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
             g_t = self._cast(ops, gx, gxT, rows * Dd)
-            self._bias_grad(ops, g_t, b + ".selfattn.proj.bias", rows, Dd)
-            self._linear_wgrad(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd)
-            self._linear_dgrad(ops, g_t, b + ".selfattn.proj.weight", dproj_in, rows, Dd, Dd)
+            self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
             self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
-            self._bias_grad(ops, dqkv, b + ".selfattn.qkv.bias", rows, 3 * Dd)
-            self._linear_wgrad(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd)
-            self._linear_dgrad(ops, dqkv, b + ".selfattn.qkv.weight", dn_t, rows, 3 * Dd, Dd)
+            self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t)
             self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True)
         # ---- decoder_embed (no dgrad: the encoder is frozen)
         g_t = self._cast(ops, gx, gxT, rows * Dd)
-        self._bias_grad(ops, g_t, "decoder_embed.bias", rows, Dd)
-        self._linear_wgrad(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
+        self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
         # ---- exemplar tokens
         if S == 0:
-            ws = self._shared("colsum", 64 * 4096)
+            ws = self._shared("colsum", 256 * 4096)
             self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, 0)
         else:
             BS = B * S
