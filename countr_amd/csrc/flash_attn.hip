@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     f32x4_t s[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4_t{0, 0, 0, 0}; s[kt][1] = f32x4_t{0, 0, 0, 0}; }
+
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
         s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
         s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
       }
+
     if ((t + 1) * FA_BKV > N) {  // ragged last tile: keys >= N do not exist
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -135,23 +137,31 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(m[qt], mx * c);
-      const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
-      m[qt] = mnew;
+      // deferred rescale: while the running max grows by <= 8 (log2 units) keep the old reference max -- P stays
+      // <= 2^8, exact in the fp32 row sum and well inside bf16 range -- and skip the O / l rescale for this tile.
+      const float mloc = mx * c;
+      float mref = m[qt];
+      if (!__all(mloc - mref <= 8.0f)) {
+        const float mnew = fmaxf(mref, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(mref - mnew);
+        m[qt] = mnew;
+        mref = mnew;
+        l[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          o[dt][qt][0] *= alpha; o[dt][qt][1] *= alpha; o[dt][qt][2] *= alpha; o[dt][qt][3] *= alpha;
+        }
+      }
       float rsum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c, -mnew));
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c, -mref));
           s[kt][qt][r] = p;
           rsum += p;
         }
-      l[qt] = l[qt] * alpha + rsum;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        o[dt][qt][0] *= alpha; o[dt][qt][1] *= alpha; o[dt][qt][2] *= alpha; o[dt][qt][3] *= alpha;
-      }
+      l[qt] += rsum;
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const uint4 pk = make_uint4(pack2bf(s[2 * ps][qt][0], s[2 * ps][qt][1]), pack2bf(s[2 * ps][qt][2], s[2 * ps][qt][3]),
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 
     // ---- O^T[dt][qt] += V^T P^T  (k-slot order kappa(g,e) = {4g+e, 16+4g+e})
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
         o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][ps], o[dt][0], 0, 0, 0);
         o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ps], o[dt][1], 0, 0, 0);
       }
+
 
     if (more) lstore((t + 1) & 1);
     __syncthreads();
