@@ -73,6 +73,7 @@ _SIGS = {
     "countr_instnorm_relu_pool_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "countr_instnorm_relu_pool_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "countr_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "countr_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "countr_softmax_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "countr_softmax_bwd": [_vp, _vp, _vp, _i64, _i, _f, _i, _vp],
     "countr_xattn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],

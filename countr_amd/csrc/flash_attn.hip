@@ -234,3 +234,276 @@ extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   }
   COUNTR_LAUNCH_CHECK("countr_attn_fwd");
 }
+
+// =====================================================================================================
+// Fused attention backward (autograd of Attention.forward, models_crossvit.py:84-91) without materialising P.
+//   P_ij = exp2(s_ij * c - lse2_i),  dV_j = sum_i P_ij dO_i,  dP_ij = dO_i . V_j,  delta_i = dO_i . O_i,
+//   dS_ij = P_ij (dP_ij - delta_i),  dQ_i = scale * sum_j dS_ij K_j,  dK_j = scale * sum_i dS_ij Q_i.
+// One template, two passes (no atomics, deterministic):
+//   MODE 0 (dQ)    : a workgroup owns 128 query rows (Q, dO fragments resident in VGPRs), streams K/V tiles through LDS;
+//                    also emits delta[b,h,i] for the second pass.
+//   MODE 1 (dK,dV) : a workgroup owns 128 keys (K, V fragments resident), streams Q/dO tiles (+ lse, delta) through LDS.
+// Both passes use the forward kernel's layouts: "S-type" products X[streamed][resident] = T R^T with the streamed tile as
+// the MFMA A operand (ds_read_b128) and the resident fragment as B; "PV-type" accumulations acc^T += T^T Y with T^T read by
+// ds_read_b64_tr_b16 in the k-slot order kappa(g,e) = {4g+e, 16+4g+e}, so Y (P or dS) is packed from the lane's own registers.
+// =====================================================================================================
+namespace {
+
+template <int DH, int MODE>
+__global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
+                                                             float scale) {
+  constexpr int KS = DH / 32, DT = DH / 16, PITCH = DH * 2 + 16, TILE = FA_BKV * PITCH, CPR = DH / 8;
+  constexpr int PASSES = (FA_BKV * CPR) / 256;
+  constexpr int STAGE = 2 * TILE + 512;  // two streamed tiles + (MODE 1) 64 lse2 + 64 delta floats
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float c = scale * 1.4426950408889634f;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rblocks = (N + FA_BQ - 1) / FA_BQ;
+  int bh, rb;
+  const int nbh = gridDim.x / rblocks;
+  if ((nbh & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    bh = xcd * (nbh >> 3) + j / rblocks;
+    rb = j - (j / rblocks) * rblocks;
+  } else {
+    bh = blockIdx.x / rblocks;
+    rb = blockIdx.x - bh * rblocks;
+  }
+  const int b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH, ro = (int64_t)H * DH;
+  const bf16_t* qp = qkv + (int64_t)b * N * rs + h * DH;
+  const bf16_t* kp = qp + H * DH;
+  const bf16_t* vp = kp + H * DH;
+  const bf16_t* dop = dout + (int64_t)b * N * ro + h * DH;
+  const bf16_t* op = outp + (int64_t)b * N * ro + h * DH;
+  const float* lsep = lse + (int64_t)bh * N;
+  float* delp = delta + (int64_t)bh * N;
+  const int r0 = rb * FA_BQ + wave * 32;  // first resident row (query for MODE 0, key for MODE 1) of this wave
+
+  // ---- resident fragments: R1 (Q | K) and R2 (dO | V), MFMA B-operand layout: lane (li, g) holds row r0 + rt*16 + li
+  const bf16_t* r1p = (MODE == 0) ? qp : kp;
+  const int64_t r1s = rs;
+  const bf16_t* r2p = (MODE == 0) ? dop : vp;
+  const int64_t r2s = (MODE == 0) ? ro : rs;
+  bf16x8_t r1[2][KS], r2[2][KS];
+  float lse2[2] = {0.f, 0.f}, dl[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int r = r0 + rt * 16 + li;
+    float dot = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 a = make_uint4(0, 0, 0, 0), bq = make_uint4(0, 0, 0, 0);
+      if (r < N) {
+        a = *reinterpret_cast<const uint4*>(r1p + (int64_t)r * r1s + ks * 32 + g * 8);
+        bq = *reinterpret_cast<const uint4*>(r2p + (int64_t)r * r2s + ks * 32 + g * 8);
+        if (MODE == 0) {  // delta_i = dO_i . O_i
+          float dv[8], ov[8];
+          ld8<bf16_t>(dop + (int64_t)r * ro + ks * 32 + g * 8, dv);
+          ld8<bf16_t>(op + (int64_t)r * ro + ks * 32 + g * 8, ov);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dot += dv[e] * ov[e];
+        }
+      }
+      r1[rt][ks] = __builtin_bit_cast(bf16x8_t, a);
+      r2[rt][ks] = __builtin_bit_cast(bf16x8_t, bq);
+    }
+    if (MODE == 0) {
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+      dl[rt] = dot;
+      lse2[rt] = (r < N) ? lsep[r] * 1.4426950408889634f : 0.f;
+      if (g == 0 && r < N) delp[r] = dot;
+    }
+  }
+
+  constexpr int NACC = (MODE == 0) ? 1 : 2;
+  f32x4_t acc[NACC][DT][2];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { acc[a][dt][0] = f32x4_t{0, 0, 0, 0}; acc[a][dt][1] = f32x4_t{0, 0, 0, 0}; }
+
+  // ---- streamed tiles: T1 (K | Q), T2 (V | dO)
+  const bf16_t* t1p = (MODE == 0) ? kp : qp;
+  const bf16_t* t2p = (MODE == 0) ? vp : dop;
+  const int64_t t2s = (MODE == 0) ? rs : ro;
+  const int ntiles = (N + FA_BKV - 1) / FA_BKV;
+  uint4 t1reg[PASSES], t2reg[PASSES];
+  float streg = 0.f;
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int cidx = tid + 256 * ps;
+      const int row = t * FA_BKV + cidx / CPR, cc = cidx % CPR;
+      t1reg[ps] = make_uint4(0, 0, 0, 0);
+      t2reg[ps] = make_uint4(0, 0, 0, 0);
+      if (row < N) {
+        t1reg[ps] = *reinterpret_cast<const uint4*>(t1p + (int64_t)row * rs + cc * 8);
+        t2reg[ps] = *reinterpret_cast<const uint4*>(t2p + (int64_t)row * t2s + cc * 8);
+      }
+    }
+    if (MODE == 1 && tid < 128) {
+      const int row = t * FA_BKV + (tid & 63);
+      streg = 0.f;
+      if (row < N) streg = (tid < 64) ? lsep[row] * 1.4426950408889634f : delp[row];
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int cidx = tid + 256 * ps;
+      const int off = (cidx / CPR) * PITCH + (cidx % CPR) * 16;
+      *reinterpret_cast<uint4*>(base + off) = t1reg[ps];
+      *reinterpret_cast<uint4*>(base + TILE + off) = t2reg[ps];
+    }
+    if (MODE == 1 && tid < 128) reinterpret_cast<float*>(base + 2 * TILE)[tid] = streg;
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) gload(t + 1);
+    const char* T1 = smem + (t & 1) * STAGE;
+    const char* T2 = T1 + TILE;
+    const float* ST = reinterpret_cast<const float*>(T1 + 2 * TILE);
+
+    // ---- S-type products: x1 = T1 R1^T (scores), x2 = T2 R2^T (dP)
+    f32x4_t x1[4][2], x2[4][2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) { x1[st][0] = x1[st][1] = x2[st][0] = x2[st][1] = f32x4_t{0, 0, 0, 0}; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(T1 + (st * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
+        const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(T2 + (st * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
+        x1[st][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, r1[0][ks], x1[st][0], 0, 0, 0);
+        x1[st][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, r1[1][ks], x1[st][1], 0, 0, 0);
+        x2[st][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, r2[0][ks], x2[st][0], 0, 0, 0);
+        x2[st][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, r2[1][ks], x2[st][1], 0, 0, 0);
+      }
+
+    // ---- P and dS (x1 <- P, x2 <- dS); streamed index of element (st, reg) is t*64 + st*16 + g*4 + reg
+    const bool ragged = (t + 1) * FA_BKV > N;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float sl[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 1) {
+        ld4<float>(ST + st * 16 + g * 4, sl);
+        ld4<float>(ST + 64 + st * 16 + g * 4, sd);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float l2 = (MODE == 0) ? lse2[rt] : sl[r];
+          const float dd = (MODE == 0) ? dl[rt] : sd[r];
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x1[st][rt][r], c, -l2));
+          if (ragged && (t * FA_BKV + st * 16 + g * 4 + r >= N)) p = 0.f;
+          x1[st][rt][r] = p;
+          x2[st][rt][r] = p * (x2[st][rt][r] - dd);
+        }
+    }
+    bf16x8_t pf[2][2], dsf[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const uint4 pk = make_uint4(pack2bf(x2[2 * ps][rt][0], x2[2 * ps][rt][1]), pack2bf(x2[2 * ps][rt][2], x2[2 * ps][rt][3]),
+                                    pack2bf(x2[2 * ps + 1][rt][0], x2[2 * ps + 1][rt][1]),
+                                    pack2bf(x2[2 * ps + 1][rt][2], x2[2 * ps + 1][rt][3]));
+        dsf[rt][ps] = __builtin_bit_cast(bf16x8_t, pk);
+        if (MODE == 1) {
+          const uint4 pp = make_uint4(pack2bf(x1[2 * ps][rt][0], x1[2 * ps][rt][1]), pack2bf(x1[2 * ps][rt][2], x1[2 * ps][rt][3]),
+                                      pack2bf(x1[2 * ps + 1][rt][0], x1[2 * ps + 1][rt][1]),
+                                      pack2bf(x1[2 * ps + 1][rt][2], x1[2 * ps + 1][rt][3]));
+          pf[rt][ps] = __builtin_bit_cast(bf16x8_t, pp);
+        }
+      }
+
+    // ---- PV-type accumulations: acc0^T += T1^T dS  (dQ^T | dK^T),  MODE 1 also acc1^T += T2^T P (dV^T)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (ps * 32 + 4 * g + (li >> 2)) * PITCH + (dt * 16 + (li & 3) * 4) * 2;
+        {
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(T1 + off));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(T1 + off + 16 * PITCH));
+          s16x8_t vv;
+          vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3]; vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+          const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, vv);
+          acc[0][dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf[0][ps], acc[0][dt][0], 0, 0, 0);
+          acc[0][dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf[1][ps], acc[0][dt][1], 0, 0, 0);
+        }
+        if (MODE == 1) {
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(T2 + off));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(T2 + off + 16 * PITCH));
+          s16x8_t vv;
+          vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3]; vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+          const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, vv);
+          acc[NACC - 1][dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, pf[0][ps], acc[NACC - 1][dt][0], 0, 0, 0);
+          acc[NACC - 1][dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, pf[1][ps], acc[NACC - 1][dt][1], 0, 0, 0);
+        }
+      }
+
+    if (more) lstore((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (li, g) owns resident row r0 + rt*16 + li and channels dt*16 + 4g .. +3
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int r = r0 + rt * 16 + li;
+    if (r >= N) continue;
+    bf16_t* drow = dqkv + ((int64_t)b * N + r) * rs + h * DH;  // q slot
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const float v0[4] = {acc[0][dt][rt][0] * scale, acc[0][dt][rt][1] * scale, acc[0][dt][rt][2] * scale, acc[0][dt][rt][3] * scale};
+      if (MODE == 0) {
+        st4<bf16_t>(drow + dt * 16 + g * 4, v0);
+      } else {
+        st4<bf16_t>(drow + H * DH + dt * 16 + g * 4, v0);  // dK
+        const float v1[4] = {acc[NACC - 1][dt][rt][0], acc[NACC - 1][dt][rt][1], acc[NACC - 1][dt][rt][2], acc[NACC - 1][dt][rt][3]};
+        st4<bf16_t>(drow + 2 * H * DH + dt * 16 + g * 4, v1);  // dV
+      }
+    }
+  }
+}
+
+template <int DH>
+int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int N,
+                    int H, float scale, hipStream_t s) {
+  const int rblocks = (N + FA_BQ - 1) / FA_BQ;
+  dim3 grid(B * H * rblocks), block(256);
+  const size_t lds = 2 * (2 * FA_BKV * (DH * 2 + 16) + 512);
+  hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                     delta, (bf16_t*)dqkv, N, H, scale);
+  hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 1>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                     delta, (bf16_t*)dqkv, N, H, scale);
+  COUNTR_LAUNCH_CHECK("countr_attn_bwd");
+}
+
+}  // namespace
+
+// Backward of countr_attn_fwd.  qkv, out, lse as given to / produced by the forward; dout bf16 [B, N, H*dh];
+// delta: fp32 workspace [B, H, N]; dqkv: bf16 [B, N, 3, H, dh] (fully overwritten).
+extern "C" int countr_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                               int B, int N, int H, int dh, float scale, void* stream) {
+  if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0) { countr_set_error("countr_attn_bwd: bad args"); return -1; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dh == 64) return launch_attn_bwd<64>(qkv, out, dout, lse, delta, dqkv, B, N, H, scale, s);
+  if (dh == 32) return launch_attn_bwd<32>(qkv, out, dout, lse, delta, dqkv, B, N, H, scale, s);
+  countr_set_error("countr_attn_bwd: head_dim must be 32 or 64");
+  return -1;
+}

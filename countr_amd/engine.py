@@ -355,11 +355,15 @@ class Engine:
                  int(dy.dtype == torch.bfloat16), int(accumulate), 0)
 
     # unfused self-attention forward on a packed qkv [rows, 3*Dm]
-    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None):
+    def _fused_attention(self, dh):
+        return self.code == BF16 and dh in (32, 64) and self.attention != "unfused"
+
+    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None, lse=None):
         N, dh = self.N, Dm // heads
         scale = dh ** -0.5
-        if self.code == BF16 and probs is None and dh in (32, 64) and self.attention != "unfused":
-            self._op(ops, self.L.countr_attn_fwd, qkv.data_ptr(), out.data_ptr(), None, B, N, heads, dh, scale)
+        if self._fused_attention(dh) and probs is None:
+            self._op(ops, self.L.countr_attn_fwd, qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None, B, N,
+                     heads, dh, scale)
             return
         scores = self._shared("scores", B * heads * N * N)
         if probs is None:
@@ -513,11 +517,13 @@ class Engine:
             d["n0"] = A(b + ".n0", (rows, Dd), T)
             d["m0"], d["r0"] = A(b + ".m0", (rows,), f32), A(b + ".r0", (rows,), f32)
             d["qkv"] = A(b + ".qkv", (rows, 3 * Dd), T)
-            d["probs"] = A(b + ".probs", (B * Hd * N * N,), T) if train else None
+            fused = self._fused_attention(Dd // Hd)
+            d["probs"] = A(b + ".probs", (B * Hd * N * N,), T) if (train and not fused) else None
+            d["lse"] = A(b + ".lse", (B * Hd * N,), f32) if (train and fused) else None
             d["att"] = A(b + ".att", (rows, Dd), T)
             self._layernorm(ops, xin, b + ".norm0", d["n0"], rows, Dd, d["m0"], d["r0"])
             self._linear(ops, d["n0"], b + ".selfattn.qkv.weight", d["qkv"], rows, 3 * Dd, Dd)
-            self._attention_fwd(ops, p, d["qkv"], d["att"], B, Hd, Dd, probs=d["probs"])
+            self._attention_fwd(ops, p, d["qkv"], d["att"], B, Hd, Dd, probs=d["probs"], lse=d["lse"])
             x1 = A(b + ".x1", (rows, Dd), f32)
             self._linear(ops, d["att"], b + ".selfattn.proj.weight", x1, rows, Dd, Dd, resid=xin)
             d["n1"] = A(b + ".n1", (rows, Dd), T)
@@ -663,7 +669,12 @@ class Engine:
             # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
             g_t = self._cast(ops, gx, gxT, rows * Dd)
             self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
-            self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
+            if d["lse"] is not None:
+                dlt = self._shared("attn_delta", B * Hd * N)
+                self._op(ops, L.countr_attn_bwd, d["qkv"].data_ptr(), d["att"].data_ptr(), dproj_in.data_ptr(), d["lse"].data_ptr(),
+                         dlt.data_ptr(), dqkv.data_ptr(), B, N, Hd, Dd // Hd, (Dd // Hd) ** -0.5)
+            else:
+                self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
             self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t)
             self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True)
         # ---- decoder_embed (no dgrad: the encoder is frozen)

@@ -123,6 +123,11 @@ int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* s
  * lse: optional fp32 [B, H, N] log-sum-exp of the scaled scores. */
 int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream);
 
+/* Backward of countr_attn_fwd (autograd of models_crossvit.py:84-91), two fused passes, no P materialised, no atomics.
+ * out/lse: the forward's outputs; dout bf16 [B, N, H*dh]; delta: fp32 workspace [B, H, N]; dqkv bf16 [B, N, 3, H, dh]. */
+int countr_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                    int B, int N, int H, int dh, float scale, void* stream);
+
 /* -------- softmax rows for the unfused attention path (models_crossvit.py:87-88) */
 int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream);
 int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,

@@ -340,3 +340,26 @@ def test_flash_attention_fwd(hip, B, N, H, dh):
     ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * dh)
     assert relerr(out, ref) < 1.5e-2   # bf16 P and bf16 output rounding
     assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-4
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(2, 576, 16, 32), (1, 576, 12, 64), (1, 200, 3, 32), (2, 64, 2, 64)])
+def test_flash_attention_bwd(hip, B, N, H, dh):
+    """Fused attention backward (dq, dk, dv in one packed tensor) vs fp64 autograd of softmax(q k^T * scale) v."""
+    qkv = (rnd((B, N, 3, H, dh), 60, 1.0)).to(torch.bfloat16)
+    qkv[0, N // 3, 1, 0] = 5.0
+    do = rnd((B, N, H * dh), 61, 1.0).to(torch.bfloat16)
+    qd, dod = qkv.cuda(), do.cuda()
+    out = torch.empty((B, N, H * dh), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty((B, H, N), device="cuda")
+    delta = torch.empty((B, H, N), device="cuda")
+    dqkv = torch.full((B, N, 3, H, dh), float("nan"), device="cuda", dtype=torch.bfloat16)
+    scale = dh ** -0.5
+    _lib.check(hip.countr_attn_fwd(P(qd), P(out), P(lse), B, N, H, dh, scale, st()))
+    _lib.check(hip.countr_attn_bwd(P(qd), P(out), P(dod), P(lse), P(delta), P(dqkv), B, N, H, dh, scale, st()))
+    x = qkv.double().requires_grad_(True)
+    q = x[:, :, 0].permute(0, 2, 1, 3); k = x[:, :, 1].permute(0, 2, 1, 3); v = x[:, :, 2].permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * dh)
+    ref.backward(do.double())
+    assert torch.isfinite(dqkv.float()).all()
+    for slot, name in enumerate(("dq", "dk", "dv")):
+        assert relerr(dqkv[:, :, slot], x.grad[:, :, slot]) < 2.5e-2, name   # bf16 P/dS operands and bf16 outputs
