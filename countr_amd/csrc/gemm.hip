@@ -360,7 +360,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tilesN = (g.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tilesN, tile_n = blockIdx.x - tile_m * tilesN;
+  // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed; speed only).  Give every XCD one contiguous range
+  // of the (tile_m, tile_n) space so the tiles sharing an A row-panel / B panel sit behind the same L2 instead of being
+  // re-fetched over the fabric by all 8 XCDs (fc2 4608x768x3072: ~208 MB -> ~66 MB per launch).  Bijective for any count.
+  int lt;
+  {
+    const int nt_ = gridDim.x, q = nt_ >> 3, r = nt_ & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tile_m = lt / tilesN, tile_n = lt - tile_m * tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // batch / split-K decode
@@ -409,21 +417,41 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
     la.init(dA, m0, kstart, tid);
     lb.init(dB, n0, kstart, tid);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+#ifndef COUNTR_ABL
+#define COUNTR_ABL 0   // ablation builds (tools/ablate_gemm.sh): 1 = no MFMA, 2 = no fragment reads, 3 = DMA only for tile 0
+#endif
     auto mma_tile = [&](const char* sa, const char* sb) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8_t xf[4], wf[4];
+#if COUNTR_ABL == 2
+        if (kk == 0 && acc[0][0][0] == 12345.f) {
+#endif
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
           xf[tm] = frag_bf16<MA>(sa, mrow(tm), wm0 + tm * 16 + (li & 3) * 4, kk, lane);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
           wf[tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
+#if COUNTR_ABL == 2
+        } else {
+          for (int q = 0; q < 4; ++q) { xf[q] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, q, kk, 1)); wf[q] = xf[q]; }
+        }
+#endif
+#if COUNTR_ABL == 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 a = __builtin_bit_cast(uint4, xf[q]), b = __builtin_bit_cast(uint4, wf[q]);
+          acc[q][0][0] += __uint_as_float(a.x ^ b.x); acc[q][1][1] += __uint_as_float(a.y ^ b.y);
+          acc[q][2][2] += __uint_as_float(a.z ^ b.z); acc[q][3][3] += __uint_as_float(a.w ^ b.w);
+        }
+#else
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
+#endif
       }
     };
     if constexpr (STAGES == 1) {
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
       __builtin_amdgcn_s_barrier();
       for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && (COUNTR_ABL != 3)) {
           char* nxt = smem + (cur ^ 1) * 2 * DMA_OP_BYTES;
           la.issue(kstart + (t + 1) * BK, kend, nxt, wv);
           lb.issue(kstart + (t + 1) * BK, kend, nxt + DMA_OP_BYTES, wv);
