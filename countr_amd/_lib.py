@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("nbatch", C.c_int32), ("nb1", C.c_int32), ("splitk", C.c_int32),
         ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
         ("alpha", C.c_float),
+        ("rowsum_partial", C.c_void_p),
     ]
 
 
@@ -54,7 +55,7 @@ def _declare(L):
     L.countr_init.argtypes = [i32]
     L.countr_version.argtypes = []
     L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
-    L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     for name, sig in _SIGS.items():
         fn = getattr(L, name)  # AttributeError here means the .so is stale: rebuild
         fn.argtypes = sig

@@ -420,6 +420,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
 #ifndef COUNTR_ABL
 #define COUNTR_ABL 0   // ablation builds (tools/ablate_gemm.sh): 1 = no MFMA, 2 = no fragment reads, 3 = DMA only for tile 0
 #endif
+    // optional fused bias gradient: sum_k A(m, k), accumulated by the waves of the first N-tile column only
+    const bool do_rowsum = g.rowsum_partial != nullptr && tile_n == 0 && (wave & 1) == 0;
+    f32x4_t accb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accb[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     auto mma_tile = [&](const char* sa, const char* sb) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -452,6 +457,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
           for (int tn = 0; tn < 4; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
 #endif
+        if (do_rowsum) {  // wave-uniform: row sums of the M-side operand = bias gradient of a wgrad GEMM
+          const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[tm], accb[tm], 0, 0, 0);
+        }
       }
     };
     if constexpr (STAGES == 1) {
@@ -483,6 +493,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
         mma_tile(smem + cur * 2 * DMA_OP_BYTES, smem + cur * 2 * DMA_OP_BYTES + DMA_OP_BYTES);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (do_rowsum && (lane >> 4) == 0) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + mrow(tm);
+        if (m < g.M) g.rowsum_partial[(int64_t)blockIdx.z * g.M + m] = accb[tm][0];
       }
     }
   } else {
@@ -628,8 +645,14 @@ int dispatch(const countr_gemm_args& a, int ma, int mb, hipStream_t s) {
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int splitk,
-                                     int64_t MN, int N, int taps, int accumulate) {
+                                     int64_t MN, int N, int taps, int accumulate, const float* __restrict__ rowsum_partial,
+                                     float* __restrict__ rowsum_out, int M) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rowsum_partial && i < M) {  // fused bias gradient: out_b[m] = sum_z rowsum_partial[z][m]
+    float b = 0.f;
+    for (int z = 0; z < splitk; ++z) b += rowsum_partial[(int64_t)z * M + i];
+    rowsum_out[i] = accumulate ? rowsum_out[i] + b : b;
+  }
   if (i >= MN) return;
   float s = 0.f;
   for (int z = 0; z < splitk; ++z) s += partial[(int64_t)z * MN + i];
@@ -649,6 +672,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
   if ((a->splitk > 1 && !a->partial) || (a->partial && a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
+  if (a->rowsum_partial && (dtype != COUNTR_BF16 || !a->partial)) { countr_set_error("countr_gemm: rowsum_partial needs the bf16 split-K path"); return -1; }
   const int epc = dtype == COUNTR_BF16 ? 8 : 4;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->N & 3)) { countr_set_error("countr_gemm: bad shape (need N % 4 == 0)"); return -1; }
   if ((modeA == COUNTR_OP_ROW || modeB == COUNTR_OP_ROW) && (a->K % epc)) { countr_set_error("countr_gemm: K must be a multiple of the 16-byte chunk"); return -1; }
@@ -663,10 +687,11 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
 }
 
 extern "C" int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, int N, int perm_taps,
-                                    int accumulate, void* stream) {
-  if (!partial || !out || splitk < 1) { countr_set_error("countr_splitk_reduce: bad args"); return -1; }
+                                    int accumulate, const float* rowsum_partial, float* rowsum_out, void* stream) {
+  if (!partial || !out || splitk < 1 || (rowsum_partial && !rowsum_out)) { countr_set_error("countr_splitk_reduce: bad args"); return -1; }
   const int64_t MN = (int64_t)M * N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), partial, out, splitk, MN, N, perm_taps, accumulate);
+                     reinterpret_cast<hipStream_t>(stream), partial, out, splitk, MN, N, perm_taps, accumulate, rowsum_partial,
+                     rowsum_out, M);
   COUNTR_LAUNCH_CHECK("countr_splitk_reduce");
 }

@@ -302,17 +302,24 @@ class Engine:
         return sk
 
     # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
-    def _linear_wgrad(self, ops, dy, x, wname, M, N, K, lddy=None, ldx=None):
+    def _linear_wgrad(self, ops, dy, x, wname, M, N, K, lddy=None, ldx=None, bias_name=None):
+        """dW[N,K] = dy^T x (split-K slabs + deterministic reduce).  bias_name: also produce db = column sums of dy,
+        fused into the GEMM as one extra MFMA per tile against a ones fragment (bf16 mode)."""
         lddy = N if lddy is None else lddy
         ldx = K if ldx is None else ldx
         bk = 64 if self.code == BF16 else 32
         tiles = -(-N // 128) * -(-K // 128)
         sk = self._splitk(tiles, -(-M // bk))
         part = self._shared("splitk", sk * N * K)
+        fuse_bias = bias_name is not None and self.code == BF16
+        rs = self._shared("rowsum", 64 * 4096) if fuse_bias else None
         self._gemm(ops, self.code, OP_COL, OP_COL, A=dy.data_ptr() if not isinstance(dy, int) else dy,
                    B=x.data_ptr() if not isinstance(x, int) else x, partial=part.data_ptr(), lda=lddy, ldb=ldx, ldc=K,
-                   M=N, N=K, K=M, splitk=sk)
-        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, 0)
+                   M=N, N=K, K=M, splitk=sk, rowsum_partial=(rs.data_ptr() if fuse_bias else None))
+        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, 0,
+                 rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
+        if bias_name is not None and not fuse_bias:
+            self._bias_grad(ops, dy, bias_name, M, N)
 
     def _bias_grad(self, ops, dy, bname, M, N):
         ws = self._shared("colsum", 256 * 4096)
@@ -328,10 +335,8 @@ class Engine:
     def _linear_bwd(self, ops, dy, x, wname, M, N, K, dx=None, resid=None, dx_bf16=None):
         """bias grad | weight grad | input grad of one nn.Linear: three independent branches."""
         self._fork(ops)
-        self._lane(ops, 1)
-        self._bias_grad(ops, dy, wname[:-6] + "bias", M, N)
         self._lane(ops, 2)
-        self._linear_wgrad(ops, dy, x, wname, M, N, K)
+        self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=wname[:-6] + "bias")
         if dx is not None:
             self._lane(ops, 0)
             self._linear_dgrad(ops, dy, wname, dx, M, N, K, resid=resid, out_bf16=dx_bf16)
@@ -418,15 +423,21 @@ class Engine:
                    ldb=9 * Cin, ldc=Cout, M=Bn * H * W, N=Cout, K=9 * Cin, H=H, W=W, Cin=Cin,
                    out_bf16=int(out.dtype == torch.bfloat16))
 
-    def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout):
+    def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout, bias_name=None):
         bk = 64 if self.code == BF16 else 32
         Kp = Bn * H * W
         tiles = -(-Cout // 128) * -(-(9 * Cin) // 128)
         sk = self._splitk(tiles, -(-Kp // bk))
         part = self._shared("splitk", sk * Cout * 9 * Cin)
+        fuse_bias = bias_name is not None and self.code == BF16
+        rs = self._shared("rowsum", 64 * 4096) if fuse_bias else None
         self._gemm(ops, self.code, OP_COL, OP_IM2COL, A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout,
-                   ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W, Cin=Cin, splitk=sk)
-        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, 0)
+                   ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W, Cin=Cin, splitk=sk,
+                   rowsum_partial=(rs.data_ptr() if fuse_bias else None))
+        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, 0,
+                 rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
+        if bias_name is not None and not fuse_bias:
+            self._bias_grad(ops, dy, bias_name, Kp, Cout)
 
     # ------------------------------------------------------------------ plan construction
     def plan(self, B, S, train):
@@ -612,10 +623,7 @@ class Engine:
             if not big:
                 self._fork(ops)
                 self._lane(ops, 1)
-            self._bias_grad(ops, dpre, hn + ".0.bias", B * HW, 256)
-            if not big:
-                self._lane(ops, 2)
-            self._conv_wgrad(ops, dpre, hin[i], hn + ".0.weight", B, hs[i], hs[i], cin[i], 256)
+            self._conv_wgrad(ops, dpre, hin[i], hn + ".0.weight", B, hs[i], hs[i], cin[i], 256, bias_name=hn + ".0.bias")
             # dgrad == forward conv of dpre with the dgrad-form weights (Cin_gemm = 256 output channels)
             if not big:
                 self._lane(ops, 0)
@@ -661,8 +669,7 @@ class Engine:
             dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
             dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
             for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
-                self._bias_grad(ops, g_kv, b + ".attn.%s.bias" % nm, B * Sy, Dd)
-                self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd)
+                self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
                 self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,
                                    resid=(None if first_tok else dy_tok), out_bf16=False)
                 first_tok = False
@@ -699,8 +706,7 @@ class Engine:
                     self._op(ops, L.countr_conv3x3_c3_wgrad, boxes.data_ptr(), dc[0].data_ptr(), self._gp(wn), self._gp(wn[:-6] + "bias"),
                              ws.data_ptr(), BS, 64, 64, code, 0)
                 else:
-                    self._bias_grad(ops, dc[i], wn[:-6] + "bias", BS * sizes[i] * sizes[i], chans[i])
-                    self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i])
+                    self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i], bias_name=wn[:-6] + "bias")
                     self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dc[i].data_ptr(), B=self.Wd[wn].data_ptr(), C=dpl[i - 1].data_ptr(),
                                ldb=9 * chans[i], ldc=chans[i - 1], M=BS * sizes[i] * sizes[i], N=chans[i - 1], K=9 * chans[i],
                                H=sizes[i], W=sizes[i], Cin=chans[i], out_bf16=int(code == BF16))

@@ -74,14 +74,17 @@ typedef struct countr_gemm_args {
   int32_t splitk;
   int32_t H, W, Cin; /* conv geometry for IM2ROW / IM2COL                                     */
   float alpha;
+  float* rowsum_partial; /* optional (bf16 split-K only): fp32 [max(splitk,1)][M] receives sum_k A(m,k) per
+                            K split -- the bias gradient of a wgrad GEMM, fused as one extra MFMA per tile    */
 } countr_gemm_args;
 
 int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream);
 
 /* out[M,N] (+)= sum_z partial[z][M][N]; optional permute for conv weights:
- * perm_taps > 0: partial is [Cout][taps][Cin] (OHWI) and out is torch OIHW [Cout][Cin][taps]. */
+ * perm_taps > 0: partial is [Cout][taps][Cin] (OHWI) and out is torch OIHW [Cout][Cin][taps].
+ * rowsum_partial/rowsum_out (optional): also reduces the fused bias-gradient partials [splitk][M] -> [M]. */
 int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, int N, int perm_taps,
-                         int accumulate, void* stream);
+                         int accumulate, const float* rowsum_partial, float* rowsum_out, void* stream);
 
 
 /* -------- LayerNorm (nn.LayerNorm eps=1e-6: models_mae_cross.py:146,182; models_crossvit.py:153-155;

@@ -121,7 +121,7 @@ def test_gemm_batched_and_splitk(hip, dt):
     a.nbatch = 1; a.nb1 = 1; a.splitk = splitk
     a.alpha = 1.0
     _lib.check(hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 1, 1, _stream()), "gemm")
-    _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dW.data_ptr(), splitk, N, K, 0, 1, _stream()), "reduce")
+    _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dW.data_ptr(), splitk, N, K, 0, 1, None, None, _stream()), "reduce")
     torch.cuda.synchronize()
     ref = dY.double().t() @ X.double() + 1.0
     assert (dW.double() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
@@ -165,7 +165,7 @@ def test_conv3x3_implicit_gemm(hip, dt, Bsz, H, W, Cin, Cout):
     a.nbatch = 1; a.nb1 = 1; a.splitk = splitk
     a.alpha = 1.0
     _lib.check(hip.countr_gemm(C.byref(a), code, 1, 3, _stream()), "conv wgrad")
-    _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dw.data_ptr(), splitk, Cout, 9 * Cin, 9, 0, _stream()), "reduce")
+    _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dw.data_ptr(), splitk, Cout, 9 * Cin, 9, 0, None, None, _stream()), "reduce")
     torch.cuda.synchronize()
     xd = x.double().requires_grad_(False)
     wd = w.double().clone().requires_grad_(True)
@@ -173,3 +173,25 @@ def test_conv3x3_implicit_gemm(hip, dt, Bsz, H, W, Cin, Cout):
     gy = dy.double().reshape(Bsz, H, W, Cout).permute(0, 3, 1, 2)
     (gw,) = torch.autograd.grad(y, wd, gy)
     assert (dw.double() - gw).abs().max().item() <= 2e-4 * gw.abs().max().item()
+
+
+def test_wgrad_with_fused_bias_gradient(hip):
+    """bf16 split-K wgrad with rowsum_partial: db[n] = sum_m dY[m, n] comes out of the same GEMM (ones-fragment MFMA)."""
+    M, N, K = 4608, 384, 256
+    dY = _mk((M, N), torch.bfloat16, 21)
+    X = _mk((M, K), torch.bfloat16, 22)
+    for splitk in (1, 5):
+        part = torch.empty((splitk, N, K), device="cuda", dtype=torch.float32)
+        rs = torch.full((splitk, N), float("nan"), device="cuda", dtype=torch.float32)
+        dW = torch.zeros((N, K), device="cuda"); db = torch.zeros(N, device="cuda")
+        a = _lib.GemmArgs()
+        a.A, a.B, a.partial, a.rowsum_partial = dY.data_ptr(), X.data_ptr(), part.data_ptr(), rs.data_ptr()
+        a.lda, a.ldb, a.ldc = N, K, K
+        a.M, a.N, a.K = N, K, M
+        a.nbatch = 1; a.nb1 = 1; a.splitk = splitk; a.alpha = 1.0
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 1, 1, _stream()), "gemm")
+        _lib.check(hip.countr_splitk_reduce(part.data_ptr(), dW.data_ptr(), splitk, N, K, 0, 0, rs.data_ptr(), db.data_ptr(), _stream()), "reduce")
+        torch.cuda.synchronize()
+        assert (dW.double() - dY.double().t() @ X.double()).abs().max().item() <= 2e-4 * (dY.double().t() @ X.double()).abs().max().item()
+        ref_b = dY.double().sum(0)
+        assert (db.double() - ref_b).abs().max().item() <= 1e-4 * ref_b.abs().max().item() + 1e-4
