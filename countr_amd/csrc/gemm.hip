@@ -7,6 +7,7 @@
 // Reference call sites: models_crossvit.py:62,65,84-92,115-127; models_mae_cross.py:47-100,138,152.
 #include "common.cuh"
 #include "../../include/countr_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -625,6 +626,9 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // deep-K launches on big grids: single stage + high occupancy; otherwise double-buffered
     // (measured crossover on MI355X / 256 CUs with tools/bench_gemm.py)
+    static const int force = [] { const char* e = getenv("COUNTR_GEMM_STAGES"); return e ? atoi(e) : 0; }();  // tuning aid
+    if (force == 1) return launch_variant<T, MA, MB, 1>(a, grid, s);
+    if (force == 2) return launch_variant<T, MA, MB, 2>(a, grid, s);
     const int ksplit = a.partial ? (a.splitk > 1 ? a.splitk : 1) : 1;
     const int ktiles = (a.K / ksplit + 63) / 64;
     if ((long)tilesM * tilesN * zdim >= 512 && ktiles >= 24) return launch_variant<T, MA, MB, 1>(a, grid, s);
