@@ -298,7 +298,7 @@ class Engine:
                    lda=K, ldb=K, ldc=N, ldres=N, M=M, N=N, K=K, res_mod=res_mod, act=act, out_bf16=int(out_bf16))
 
     def _splitk(self, tiles, ktiles):
-        sk = max(1, min(64, ktiles, int(round(768.0 / max(tiles, 1)))))
+        sk = max(1, min(64, ktiles, int(round(512.0 / max(tiles, 1)))))
         return sk
 
     # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
