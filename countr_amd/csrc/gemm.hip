@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int BM = 128, BN = 128, NTHREADS = 256;  // fp32 path / default tile
 constexpr int ROW_PITCH = 144;      // 128 B of K + 16 B pad
 constexpr int OP_BYTES = 18432;     // per operand per stage (max over layouts), fp32 path
 
@@ -198,61 +198,70 @@ __device__ __forceinline__ int swz_col(int k) { return ((k & 3) << 1) | (((k >> 
 // 16 lanes hit 16 distinct 16-byte slots (conflict-free ds_read_b128).
 __device__ __forceinline__ int swz_row(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
 
-constexpr int DMA_OP_BYTES = 16384;  // 128 x 64 bf16, unpadded
 
-template <int MODE> struct DmaLoader;
+// ROWS = tile rows of this operand (128 or 256), NW = waves in the workgroup.  A wave-instruction moves one 1-KiB group:
+// row-like tiles: 8 rows x 128 B; col-like tiles (ROWS == 128 only): 4 k-rows x 256 B.  Group index = pass * NW + wave.
+template <int MODE, int ROWS, int NW> struct DmaLoader;
 
-template <> struct DmaLoader<COUNTR_OP_ROW> {
-  const char* rp[4];
-  int kc[2];  // swizzled k-chunk (elements) for even / odd i (row bit 5 = i & 1)
-  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_ROW, ROWS, NW> {
+  static constexpr int PASSES = ROWS / (8 * NW);
+  const char* rp[PASSES];
+  int kc[PASSES];  // swizzled k-chunk (elements)
+  __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rl = (tid >> 3) + 32 * i;
-      if (i < 2) kc[i] = ((tid & 7) ^ swz_row(rl)) * 8;
+    for (int i = 0; i < PASSES; ++i) {
+      const int rl = (i * NW + wave) * 8 + (lane >> 3);
+      kc[i] = ((lane & 7) ^ swz_row(rl)) * 8;
       const int r = row0 + rl;
       rp[i] = (r < d.rows) ? d.ptr + (int64_t)r * d.ld * 2 : nullptr;
     }
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + kc[i & 1];
+    for (int i = 0; i < PASSES; ++i) {
+      const int k = k0 + kc[i];
       const void* src = ((k + 8) <= kend && rp[i]) ? (const void*)(rp[i] + (int64_t)k * 2) : (const void*)g_zero_page;
-      dma16(src, lds + (i * 4 + wave) * 1024);
+      dma16(src, lds + (i * NW + wave) * 1024);
     }
   }
 };
 
-template <> struct DmaLoader<COUNTR_OP_COL> {
-  const char* base;
+template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_COL, ROWS, NW> {
+  static_assert(ROWS == 128, "K-strided operands are only staged as 128-row tiles");
+  static constexpr int PASSES = 16 / NW;
+  const char* base[PASSES];
+  int krow[PASSES];
   int64_t ldb;
-  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
-    const int krow = tid >> 4;  // + 16*i, swizzle term is independent of i
-    const int r0 = row0 + ((tid & 15) ^ swz_col(krow)) * 8;
-    base = (r0 + 8 <= d.rows) ? d.ptr + (int64_t)r0 * 2 : nullptr;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ldb = d.ld * 2;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      krow[i] = (i * NW + wave) * 4 + (lane >> 4);
+      const int r0 = row0 + ((lane & 15) ^ swz_col(krow[i])) * 8;
+      base[i] = (r0 + 8 <= d.rows) ? d.ptr + (int64_t)r0 * 2 : nullptr;
+    }
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + (threadIdx.x >> 4) + 16 * i;
-      const void* src = (base && k < kend) ? (const void*)(base + (int64_t)k * ldb) : (const void*)g_zero_page;
-      dma16(src, lds + (i * 4 + wave) * 1024);
+    for (int i = 0; i < PASSES; ++i) {
+      const int k = k0 + krow[i];
+      const void* src = (base[i] && k < kend) ? (const void*)(base[i] + (int64_t)k * ldb) : (const void*)g_zero_page;
+      dma16(src, lds + (i * NW + wave) * 1024);
     }
   }
 };
 
-template <> struct DmaLoader<COUNTR_OP_IM2ROW> {
+template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2ROW, ROWS, NW> {
+  static constexpr int PASSES = ROWS / (8 * NW);
   const char* ptr;
-  int pix[4], py[4], px[4];
-  int H, W, C, kc[2];
-  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+  int pix[PASSES], py[PASSES], px[PASSES], kc[PASSES];
+  int H, W, C;
+  __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ptr = d.ptr; H = d.H; W = d.W; C = d.C;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rl = (tid >> 3) + 32 * i;
-      if (i < 2) kc[i] = ((tid & 7) ^ swz_row(rl)) * 8;
+    for (int i = 0; i < PASSES; ++i) {
+      const int rl = (i * NW + wave) * 8 + (lane >> 3);
+      kc[i] = ((lane & 7) ^ swz_row(rl)) * 8;
       const int m = row0 + rl;
       pix[i] = (m < d.rows) ? m : -1;
       px[i] = m % W;
@@ -264,44 +273,45 @@ template <> struct DmaLoader<COUNTR_OP_IM2ROW> {
     const int cbase = k0 - tap * C;
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PASSES; ++i) {
       const int yy = py[i] + dy, xx = px[i] + dx;
-      const int kcs = kc[i & 1];
-      const bool ok = (k0 + kcs + 8) <= kend && pix[i] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      const void* src = ok ? (const void*)(ptr + ((int64_t)(pix[i] + dy * W + dx) * C + cbase + kcs) * 2) : (const void*)g_zero_page;
-      dma16(src, lds + (i * 4 + wave) * 1024);
+      const bool ok = (k0 + kc[i] + 8) <= kend && pix[i] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const void* src = ok ? (const void*)(ptr + ((int64_t)(pix[i] + dy * W + dx) * C + cbase + kc[i]) * 2) : (const void*)g_zero_page;
+      dma16(src, lds + (i * NW + wave) * 1024);
     }
   }
 };
 
-template <> struct DmaLoader<COUNTR_OP_IM2COL> {
+template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2COL, ROWS, NW> {
+  static_assert(ROWS == 128, "K-strided operands are only staged as 128-row tiles");
+  static constexpr int PASSES = 16 / NW;
   const char* ptr;
-  int py[4], px[4];
-  int H, W, C, ci, dy, dx;
-  bool colok;
-  __device__ void init(const OpDesc& d, int row0, int kstart, int tid) {
+  int py[PASSES], px[PASSES], krow[PASSES], ci[PASSES], dy[PASSES], dx[PASSES];
+  int H, W, C;
+  bool colok[PASSES];
+  __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ptr = d.ptr; H = d.H; W = d.W; C = d.C;
-    const int krow = tid >> 4;
-    const int r0 = row0 + ((tid & 15) ^ swz_col(krow)) * 8;
-    colok = (r0 + 8) <= d.rows;
-    const int tap = r0 / C;
-    ci = r0 - tap * C;
-    dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = kstart + krow + 16 * i;
+    for (int i = 0; i < PASSES; ++i) {
+      krow[i] = (i * NW + wave) * 4 + (lane >> 4);
+      const int r0 = row0 + ((lane & 15) ^ swz_col(krow[i])) * 8;
+      colok[i] = (r0 + 8) <= d.rows;
+      const int tap = r0 / C;
+      ci[i] = r0 - tap * C;
+      dy[i] = tap / 3 - 1; dx[i] = tap - (tap / 3) * 3 - 1;
+      const int p = kstart + krow[i];
       px[i] = p % W;
       py[i] = (p / W) % H;
     }
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = k0 + (threadIdx.x >> 4) + 16 * i;
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = colok && p < kend && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      const void* src = ok ? (const void*)(ptr + ((int64_t)(p + dy * W + dx) * C + ci) * 2) : (const void*)g_zero_page;
-      dma16(src, lds + (i * 4 + wave) * 1024);
+    for (int i = 0; i < PASSES; ++i) {
+      const int p = k0 + krow[i];
+      const int yy = py[i] + dy[i], xx = px[i] + dx[i];
+      const bool ok = colok[i] && p < kend && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const void* src = ok ? (const void*)(ptr + ((int64_t)(p + dy[i] * W + dx[i]) * C + ci[i]) * 2) : (const void*)g_zero_page;
+      dma16(src, lds + (i * NW + wave) * 1024);
       px[i] += 64;
       while (px[i] >= W) { px[i] -= W; py[i] = (py[i] + 1 == H) ? 0 : py[i] + 1; }
     }
@@ -353,14 +363,16 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
   }
 }
 
-template <typename T, int MA, int MB, int STAGES>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g) {
+template <typename T, int MA, int MB, int STAGES, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g) {
+  constexpr int BMt = 64 * WM, BNt = 64 * WN, NW = WM * WN;
+  constexpr int SA = BMt * 128, SB = BNt * 128;  // bf16 stage bytes per operand
   constexpr int BK = Cfg<T>::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // stage s: A tile at smem + 2*s*OP_BYTES, B tile right behind it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tilesN = (g.N + BN - 1) / BN;
+  const int tilesN = (g.N + BNt - 1) / BNt;
   // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed; speed only).  Give every XCD one contiguous range
   // of the (tile_m, tile_n) space so the tiles sharing an A row-panel / B panel sit behind the same L2 instead of being
   // re-fetched over the fabric by all 8 XCDs (fc2 4608x768x3072: ~208 MB -> ~66 MB per launch).  Bijective for any count.
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
     lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
   const int tile_m = lt / tilesN, tile_n = lt - tile_m * tilesN;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BMt, n0 = tile_n * BNt;
 
   // batch / split-K decode
   int kstart = 0, kend = g.K;
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
   const int li = lane & 15;
   // N-side row permutation: MFMA output row i of tile tn is column wn0 + (i>>2)*16 + tn*4 + (i&3),
   // so that a lane ends up holding 16 consecutive output columns (vector stores in the epilogue).
@@ -413,16 +425,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
 
   if constexpr (sizeof(T) == 2) {
     // ---------------- bf16: LDS-DMA staging, two stages, tile t+1 in flight while tile t is multiplied
-    DmaLoader<MA> la;
-    DmaLoader<MB> lb;
-    la.init(dA, m0, kstart, tid);
-    lb.init(dB, n0, kstart, tid);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    DmaLoader<MA, BMt, NW> la;
+    DmaLoader<MB, BNt, NW> lb;
+    la.init(dA, m0, kstart, wv, lane);
+    lb.init(dB, n0, kstart, wv, lane);
 #ifndef COUNTR_ABL
 #define COUNTR_ABL 0   // ablation builds (tools/ablate_gemm.sh): 1 = no MFMA, 2 = no fragment reads, 3 = DMA only for tile 0
 #endif
     // optional fused bias gradient: sum_k A(m, k), accumulated by the waves of the first N-tile column only
-    const bool do_rowsum = g.rowsum_partial != nullptr && tile_n == 0 && (wave & 1) == 0;
+    const bool do_rowsum = g.rowsum_partial != nullptr && tile_n == 0 && (wave % WN) == 0;
     f32x4_t accb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) accb[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -470,28 +482,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
       // Chosen by the host for big grids (>= ~3 workgroups per CU), where it beats per-workgroup double buffering.
       for (int t = 0; t < ntiles; ++t) {
         la.issue(kstart + t * BK, kend, smem, wv);
-        lb.issue(kstart + t * BK, kend, smem + DMA_OP_BYTES, wv);
+        lb.issue(kstart + t * BK, kend, smem + SA, wv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma_tile(smem, smem + DMA_OP_BYTES);
+        mma_tile(smem, smem + SA);
         __builtin_amdgcn_s_barrier();  // all fragment reads of this tile are consumed before it is overwritten
       }
     } else {
       // Two stages (64 KB, 2 workgroups per CU): tile t+1 streams in while tile t is multiplied.
       if (ntiles > 0) {
         la.issue(kstart, kend, smem, wv);
-        lb.issue(kstart, kend, smem + DMA_OP_BYTES, wv);
+        lb.issue(kstart, kend, smem + SA, wv);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntiles && (COUNTR_ABL != 3)) {
-          char* nxt = smem + (cur ^ 1) * 2 * DMA_OP_BYTES;
+          char* nxt = smem + (cur ^ 1) * (SA + SB);
           la.issue(kstart + (t + 1) * BK, kend, nxt, wv);
-          lb.issue(kstart + (t + 1) * BK, kend, nxt + DMA_OP_BYTES, wv);
+          lb.issue(kstart + (t + 1) * BK, kend, nxt + SA, wv);
         }
-        mma_tile(smem + cur * 2 * DMA_OP_BYTES, smem + cur * 2 * DMA_OP_BYTES + DMA_OP_BYTES);
+        mma_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
@@ -504,7 +516,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
       }
     }
   } else {
-    // ---------------- fp32 parity path: register-staged, padded tiles
+    // ---------------- fp32 parity path: register-staged, padded tiles (2x2 waves only)
+    static_assert(sizeof(T) == 2 || (WM == 2 && WN == 2), "fp32 path is 128x128 only");
     Loader<T, MA> la;
     Loader<T, MB> lb;
     la.init(dA, m0, kstart, tid);
@@ -605,35 +618,53 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const countr_gemm_args g
   }
 }
 
-template <typename T, int MA, int MB, int STAGES>
-int launch_variant(const countr_gemm_args& a, dim3 grid, hipStream_t s) {
-  constexpr int lds_bytes = sizeof(T) == 2 ? STAGES * 2 * 16384 : 4 * OP_BYTES;
+template <typename T, int MA, int MB, int STAGES, int WM, int WN>
+int launch_variant(const countr_gemm_args& a, hipStream_t s) {
+  constexpr int BMt = 64 * WM, BNt = 64 * WN;
+  constexpr int lds_bytes = sizeof(T) == 2 ? STAGES * (BMt + BNt) * 128 : 4 * OP_BYTES;
+  const int tilesM = (a.M + BMt - 1) / BMt, tilesN = (a.N + BNt - 1) / BNt;
+  const int zdim = a.partial ? (a.splitk > 1 ? a.splitk : 1) : (a.nbatch > 1 ? a.nbatch : 1);
+  dim3 grid(tilesM * tilesN, 1, zdim);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES>), grid, dim3(NTHREADS), lds_bytes, s, a);
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN>), grid, dim3(64 * WM * WN), lds_bytes, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
+// Tile-shape / stage selection (bf16).  Bigger workgroup tiles re-use each staged operand for more MFMAs (the kernel is
+// bound by the global->LDS path, see the ablation in DESIGN.md) but need enough tiles to fill 256 CUs.
 template <typename T, int MA, int MB>
 int launch(const countr_gemm_args& a, hipStream_t s) {
-  const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
-  const int zdim = a.partial ? (a.splitk > 1 ? a.splitk : 1) : (a.nbatch > 1 ? a.nbatch : 1);
-  dim3 grid(tilesM * tilesN, 1, zdim);
   if constexpr (sizeof(T) == 2) {
-    // deep-K launches on big grids: single stage + high occupancy; otherwise double-buffered
-    // (measured crossover on MI355X / 256 CUs with tools/bench_gemm.py)
-    static const int force = [] { const char* e = getenv("COUNTR_GEMM_STAGES"); return e ? atoi(e) : 0; }();  // tuning aid
-    if (force == 1) return launch_variant<T, MA, MB, 1>(a, grid, s);
-    if (force == 2) return launch_variant<T, MA, MB, 2>(a, grid, s);
+    static const int force = [] { const char* e = getenv("COUNTR_GEMM_STAGES"); return e ? atoi(e) : 0; }();  // tuning aids
+    static const int ftile = [] { const char* e = getenv("COUNTR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const int zdim = a.partial ? (a.splitk > 1 ? a.splitk : 1) : (a.nbatch > 1 ? a.nbatch : 1);
     const int ksplit = a.partial ? (a.splitk > 1 ? a.splitk : 1) : 1;
     const int ktiles = (a.K / ksplit + 63) / 64;
-    if ((long)tilesM * tilesN * zdim >= 512 && ktiles >= 24) return launch_variant<T, MA, MB, 1>(a, grid, s);
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * zdim;
+    if constexpr (is_rowlike(MA) && is_rowlike(MB)) {
+      const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * zdim;
+      const long t128x256 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256) * zdim;
+      int tile = ftile;
+      // measured (tools/bench_gemm.py, COUNTR_GEMM_TILE=22|24|42|44): 256-wide tiles lose to 128x128 with this loop
+      // structure (8-wave variants drop to one workgroup per CU, the 16-wave 256x256 one spills), so 22 stays the default
+      (void)t256; (void)t128x256;
+      if (!tile) tile = 22;
+      if (tile == 44) return launch_variant<T, MA, MB, 2, 4, 4>(a, s);
+      if (tile == 24) return launch_variant<T, MA, MB, 1, 2, 4>(a, s);
+      if (tile == 42) return launch_variant<T, MA, MB, 1, 4, 2>(a, s);
+    }
+    if (force == 1) return launch_variant<T, MA, MB, 1, 2, 2>(a, s);
+    if (force == 2) return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
+    // deep-K launches on big grids: single stage + high occupancy; otherwise double-buffered
+    // (measured crossover on MI355X / 256 CUs with tools/bench_gemm.py)
+    if (t128 >= 512 && ktiles >= 24) return launch_variant<T, MA, MB, 1, 2, 2>(a, s);
   }
-  return launch_variant<T, MA, MB, 2>(a, grid, s);
+  return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
 }
 
 template <typename T>
