@@ -163,6 +163,18 @@ class SupervisedMAE(nn.Module):
         eng.run(p.fwd[:p.enc_ops])
         return p.buf["latent"].float().view(B, -1, self.cfg[1]).clone()
 
+    def forward_decoder(self, x, y_, shot_num=3):
+        """models_mae_cross.py:150-199 on a given latent [B, N, embed_dim] (inference path; gradients flow through
+        forward(), whose single autograd node covers the whole decoder side)."""
+        eng = self._engine()
+        B, S = x.shape[0], int(shot_num)
+        p = eng.plan(B, S, False)
+        p.buf["latent"].copy_(x.reshape(p.buf["latent"].shape))
+        if S > 0:
+            p.buf["boxes"].view(B, S, 3, 64, 64).copy_(y_[:, :S].float())
+        eng.run(p.fwd[p.enc_ops:])
+        return p.buf["out"].clone()
+
     def forward(self, imgs, boxes, shot_num):
         """models_mae_cross.py:201-207."""
         assert imgs.shape[-2] == self.img_size and imgs.shape[-1] == self.img_size, \

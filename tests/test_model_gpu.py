@@ -104,6 +104,10 @@ def test_tuple_unpack_and_encoder_surface(fp32_model):
     assert rel(lat.cpu().numpy(), probes["latent"].numpy()) < 1e-3
     with pytest.raises(AssertionError):
         m(torch.zeros(1, 3, 384, 400).cuda(), torch.from_numpy(bx).cuda(), s)  # PatchEmbed size assert
+    with torch.no_grad():   # forward_decoder(forward_encoder(x)) == forward(x)  (models_mae_cross.py:204-206)
+        two = m.forward_decoder(lat, torch.from_numpy(bx).cuda(), s)
+        one = m(torch.from_numpy(im).cuda(), torch.from_numpy(bx).cuda(), s)
+    assert rel(two.cpu().numpy(), one.cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("tag,shots", [("s3", 3), ("s0", 0)])
