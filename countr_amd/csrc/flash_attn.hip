@@ -12,21 +12,24 @@
 //     read in the same key order with ds_read_b64_tr_b16 from the row-major V tile: no cross-lane traffic for P.
 #include "common.cuh"
 #include "../../include/countr_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int FA_BQ = 128;   // query rows per workgroup
 constexpr int FA_BKV = 64;   // keys per tile
 
-template <int DH>
+template <int DH, int BKV, bool RAGGED>
 __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                              float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
   constexpr int KS = DH / 32;          // k-steps over head dim for QK^T
   constexpr int DT = DH / 16;          // 16-wide tiles of the head dim for O
   constexpr int PITCH = DH * 2 + 16;   // bytes per LDS row
-  constexpr int TILE = FA_BKV * PITCH;
+  constexpr int TILE = BKV * PITCH;
+  constexpr int KT = BKV / 16;         // 16-key MFMA tiles per staged KV tile
+  constexpr int PS = BKV / 32;         // 32-key PV k-steps
   constexpr int CPR = DH / 8;          // 16-byte chunks per row
-  constexpr int PASSES = (FA_BKV * CPR) / 256;  // staging passes (2 for dh=64, 1 for dh=32)
+  constexpr int PASSES = (BKV * CPR) / 256;  // staging passes
   extern __shared__ __attribute__((aligned(16))) char smem[];  // stage s: K at s*2*TILE, V behind it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
@@ -68,13 +71,13 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
   for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4_t{0, 0, 0, 0}; o[dt][1] = f32x4_t{0, 0, 0, 0}; }
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
 
-  const int ntiles = (N + FA_BKV - 1) / FA_BKV;
+  const int ntiles = (N + BKV - 1) / BKV;
   uint4 kreg[PASSES], vreg[PASSES];
   auto gload = [&](int t) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int cidx = tid + 256 * ps;
-      const int key = t * FA_BKV + cidx / CPR, cc = cidx % CPR;
+      const int key = t * BKV + cidx / CPR, cc = cidx % CPR;
       kreg[ps] = make_uint4(0, 0, 0, 0);
       vreg[ps] = make_uint4(0, 0, 0, 0);
       if (key < N) {
@@ -105,34 +108,34 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     const char* Vs = Ks + TILE;
 
     // ---- S^T[kt][qt] : 16 keys x 16 queries per MFMA tile
-    f32x4_t s[4][2];
+    f32x4_t s[KT][2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4_t{0, 0, 0, 0}; s[kt][1] = f32x4_t{0, 0, 0, 0}; }
+    for (int kt = 0; kt < KT; ++kt) { s[kt][0] = f32x4_t{0, 0, 0, 0}; s[kt][1] = f32x4_t{0, 0, 0, 0}; }
 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
+      for (int kt = 0; kt < KT; ++kt) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
         s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
         s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
       }
 
-    if ((t + 1) * FA_BKV > N) {  // ragged last tile: keys >= N do not exist
+    if (RAGGED && (t + 1) * BKV > N) {  // ragged last tile: keys >= N do not exist (variant only built for N % BKV != 0)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (t * FA_BKV + kt * 16 + g * 4 + r >= N) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+          if (t * BKV + kt * 16 + g * 4 + r >= N) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
     }
 
     // ---- online softmax (exp2 domain), P packed straight into PV operands
-    bf16x8_t pf[2][2];
+    bf16x8_t pf[2][PS];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
       }
       float rsum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c, -mref));
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
         }
       l[qt] += rsum;
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
+      for (int ps = 0; ps < PS; ++ps) {
         const uint4 pk = make_uint4(pack2bf(s[2 * ps][qt][0], s[2 * ps][qt][1]), pack2bf(s[2 * ps][qt][2], s[2 * ps][qt][3]),
                                     pack2bf(s[2 * ps + 1][qt][0], s[2 * ps + 1][qt][1]),
                                     pack2bf(s[2 * ps + 1][qt][2], s[2 * ps + 1][qt][3]));
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
 
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
+    for (int ps = 0; ps < PS; ++ps)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const char* a0 = Vs + (ps * 32 + 4 * g + (li >> 2)) * PITCH + (dt * 16 + (li & 3) * 4) * 2;
@@ -224,10 +227,15 @@ extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   const int qblocks = (N + FA_BQ - 1) / FA_BQ;
   dim3 grid(B * H * qblocks), block(256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool ragged = (N % 64) != 0;
+#define COUNTR_FA_LAUNCH(DHV, RG)                                                                                              \
+  hipLaunchKernelGGL((flash_attn_fwd_kernel<DHV, 64, RG>), grid, block, 4 * 64 * (DHV * 2 + 16), s, (const bf16_t*)qkv, (bf16_t*)out, \
+                     lse, N, H, c)
   if (dh == 64) {
-    hipLaunchKernelGGL(flash_attn_fwd_kernel<64>, grid, block, 4 * FA_BKV * (64 * 2 + 16), s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+    if (ragged) COUNTR_FA_LAUNCH(64, true); else COUNTR_FA_LAUNCH(64, false);
   } else if (dh == 32) {
-    hipLaunchKernelGGL(flash_attn_fwd_kernel<32>, grid, block, 4 * FA_BKV * (32 * 2 + 16), s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+    if (ragged) COUNTR_FA_LAUNCH(32, true); else COUNTR_FA_LAUNCH(32, false);
+#undef COUNTR_FA_LAUNCH
   } else {
     countr_set_error("countr_attn_fwd: head_dim must be 32 or 64");
     return -1;
@@ -249,7 +257,7 @@ extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, in
 // =====================================================================================================
 namespace {
 
-template <int DH, int MODE>
+template <int DH, int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
       }
 
     // ---- P and dS (x1 <- P, x2 <- dS); streamed index of element (st, reg) is t*64 + st*16 + g*4 + reg
-    const bool ragged = (t + 1) * FA_BKV > N;
+    const bool ragged = RAGGED && (t + 1) * FA_BKV > N;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       float sl[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -487,10 +495,17 @@ int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const fl
   const int rblocks = (N + FA_BQ - 1) / FA_BQ;
   dim3 grid(B * H * rblocks), block(256);
   const size_t lds = 2 * (2 * FA_BKV * (DH * 2 + 16) + 512);
-  hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                     delta, (bf16_t*)dqkv, N, H, scale);
-  hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 1>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                     delta, (bf16_t*)dqkv, N, H, scale);
+  if (N % FA_BKV) {
+    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
+                       lse, delta, (bf16_t*)dqkv, N, H, scale);
+    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 1, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
+                       lse, delta, (bf16_t*)dqkv, N, H, scale);
+  } else {
+    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
+                       lse, delta, (bf16_t*)dqkv, N, H, scale);
+    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 1, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
+                       lse, delta, (bf16_t*)dqkv, N, H, scale);
+  }
   COUNTR_LAUNCH_CHECK("countr_attn_bwd");
 }
 
