@@ -153,3 +153,79 @@ def make_inputs(batch, shots=3, seed=0, img_size=384):
         gt[b] = gaussian_filter(gt[b], sigma=(1, 1), order=0) * 60.0  # util/FSC147.py:275-278
     mask = rs.binomial(1, 0.8, size=(img_size, img_size)).astype(np.float32)  # FSC_finetune_cross.py:290
     return imgs, boxes, gt, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MAE pretraining model (reference models_mae_noct.py:11-235): schema + deterministic weights
+# ---------------------------------------------------------------------------------------------------------------
+MAE_CONFIGS = {
+    # name: (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads)     models_mae_noct.py:207-235
+    "mae_vit_base_patch16": (16, 768, 12, 12, 512, 8, 16),
+    "mae_vit_large_patch16": (16, 1024, 24, 16, 512, 8, 16),
+    "tiny_test": (16, 768, 2, 12, 512, 2, 16),
+}
+
+
+def schema_mae(model="mae_vit_base_patch16", img_size=384):
+    p, D, depth, H, Dd, ddepth, Hd = MAE_CONFIGS[model]
+    N = (img_size // p) ** 2
+    S = [("pos_embed", (1, N, D), "pos"), ("mask_token", (1, 1, Dd), "token"), ("decoder_pos_embed", (1, N, Dd), "pos"),
+         ("patch_embed.proj.weight", (D, 3, p, p), "patch_w"), ("patch_embed.proj.bias", (D,), "bias")]
+
+    def lin(prefix, out_f, in_f):
+        S.append((prefix + ".weight", (out_f, in_f), "linear_w"))
+        S.append((prefix + ".bias", (out_f,), "bias"))
+
+    def norm(prefix, d):
+        S.append((prefix + ".weight", (d,), "norm_w"))
+        S.append((prefix + ".bias", (d,), "norm_b"))
+
+    def blocks(prefix, n, d):
+        for i in range(n):
+            b = "%s.%d" % (prefix, i)
+            norm(b + ".norm1", d)
+            lin(b + ".attn.qkv", 3 * d, d)
+            lin(b + ".attn.proj", d, d)
+            norm(b + ".norm2", d)
+            lin(b + ".mlp.fc1", 4 * d, d)
+            lin(b + ".mlp.fc2", d, 4 * d)
+    blocks("blocks", depth, D)
+    norm("norm", D)
+    lin("decoder_embed", Dd, D)
+    blocks("decoder_blocks", ddepth, Dd)
+    norm("decoder_norm", Dd)
+    lin("decoder_pred", p * p * 3, Dd)
+    return S
+
+
+def make_state_dict_mae(model="mae_vit_base_patch16", seed=0, img_size=384):
+    grid = img_size // MAE_CONFIGS[model][0]
+    sd = OrderedDict()
+    for name, shape, kind in schema_mae(model, img_size):
+        rs = np.random.RandomState((zlib.crc32(("mae/" + name).encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        if kind == "pos":
+            a = sincos_2d(shape[-1], grid)[None]
+        elif kind == "token":
+            a = rs.normal(0.0, 0.02, size=shape)
+        elif kind in ("linear_w", "patch_w"):
+            bound = np.sqrt(6.0 / (int(np.prod(shape[1:])) + shape[0]))
+            a = rs.uniform(-bound, bound, size=shape)
+        elif kind == "bias":
+            a = rs.uniform(-0.02, 0.02, size=shape)
+        elif kind == "norm_w":
+            a = 1.0 + rs.uniform(-0.1, 0.1, size=shape)
+        else:
+            a = rs.uniform(-0.05, 0.05, size=shape)
+        sd[name] = np.ascontiguousarray(a, dtype=np.float32)
+    return sd
+
+
+def make_mae_inputs(batch, seed=0, img_size=384, patch=16, mask_ratio=0.5):
+    """imgs ~ U[0,1) and a per-sample random permutation (ids_shuffle) standing in for argsort(rand) of
+    models_mae_noct.py:110-135; returns imgs, ids_shuffle, ids_restore, len_keep."""
+    rs = np.random.RandomState(2000 + seed)
+    imgs = rs.uniform(0, 1, size=(batch, 3, img_size, img_size)).astype(np.float32)
+    L = (img_size // patch) ** 2
+    ids_shuffle = np.stack([rs.permutation(L) for _ in range(batch)]).astype(np.int64)
+    ids_restore = np.argsort(ids_shuffle, axis=1).astype(np.int64)
+    return imgs, ids_shuffle, ids_restore, int(L * (1 - mask_ratio))
