@@ -47,10 +47,12 @@ def _bucket(name):
 class ParamLayout:
     """Offsets of every state-dict tensor inside the flat buffers."""
 
-    def __init__(self, named_shapes):
+    def __init__(self, named_shapes, trainable=None, bucket=None):
+        trainable = is_trainable if trainable is None else trainable
+        _bucket = globals()["_bucket"] if bucket is None else bucket
         self.shapes = dict(named_shapes)
-        frozen = [n for n, _ in named_shapes if not is_trainable(n)]
-        train = [n for n, _ in named_shapes if is_trainable(n)]
+        frozen = [n for n, _ in named_shapes if not trainable(n)]
+        train = [n for n, _ in named_shapes if trainable(n)]
         train.sort(key=lambda n: (_bucket(n), 0 if no_weight_decay(n, self.shapes[n]) else 1))
         self.order = frozen + train
         self.off = {}
@@ -131,7 +133,7 @@ class Engine:
         self.code = BF16 if precision == "bf16" else F32
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self.attention = attention
-        self.layout = ParamLayout(named_shapes)
+        self.layout = self._make_layout(named_shapes)
         lay = self.layout
         self.P = torch.zeros(lay.total, device=self.device, dtype=torch.float32)
         self.G = torch.zeros(lay.n_train, device=self.device, dtype=torch.float32)
@@ -139,7 +141,7 @@ class Engine:
         self.V = None
         self.Wt = self.P if precision == "fp32" else torch.zeros(lay.total, device=self.device, dtype=torch.bfloat16)
         # permuted conv-weight shadows: OHWI for the forward/wgrad implicit GEMM, "dgrad form" for dgrad
-        self.conv_names = ["decoder_proj%d.0.weight" % i for i in (2, 3, 4)] + ["decode_head%d.0.weight" % i for i in range(4)]
+        self.conv_names = self._conv_names()
         self.Wf, self.Wd = {}, {}
         for n in self.conv_names:
             numel = math.prod(lay.shapes[n])
@@ -154,6 +156,12 @@ class Engine:
         self.generation = 0
         self._sides = None
         self.parallel_lanes = False  # measured on MI355X: fork/join of the small backward branches is a wash (9.62 vs 9.56 ms)
+
+    def _make_layout(self, named_shapes):
+        return ParamLayout(named_shapes)
+
+    def _conv_names(self):
+        return ["decoder_proj%d.0.weight" % i for i in (2, 3, 4)] + ["decode_head%d.0.weight" % i for i in range(4)]
 
     # ------------------------------------------------------------------ parameter views
     def pview(self, name):
@@ -363,8 +371,8 @@ class Engine:
     def _fused_attention(self, dh):
         return self.code == BF16 and dh in (32, 64) and self.attention != "unfused"
 
-    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None, lse=None):
-        N, dh = self.N, Dm // heads
+    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None, lse=None, N=None):
+        N, dh = (self.N if N is None else N), Dm // heads
         scale = dh ** -0.5
         if self._fused_attention(dh) and probs is None:
             self._op(ops, self.L.countr_attn_fwd, qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None, B, N,
@@ -382,9 +390,9 @@ class Engine:
                    lda=N, ldb=3 * Dm, ldc=Dm, M=N, N=dh, K=N, nbatch=B * heads, nb1=heads, sA0=heads * N * N, sA1=N * N,
                    sB0=N * 3 * Dm, sB1=dh, sC0=N * Dm, sC1=dh, out_bf16=int(self.code == BF16))
 
-    def _attention_bwd(self, ops, qkv, probs, dout, dqkv, B, heads, Dm):
+    def _attention_bwd(self, ops, qkv, probs, dout, dqkv, B, heads, Dm, N=None):
         """dout [rows, Dm] (T) -> dqkv [rows, 3*Dm] (T); probs [B,h,N,N] (T) saved by the forward."""
-        N, dh = self.N, Dm // heads
+        N, dh = (self.N if N is None else N), Dm // heads
         scale = dh ** -0.5
         es = qkv.element_size()
         dP = self._shared("scores", B * heads * N * N)

@@ -16,6 +16,7 @@ import torch.nn as nn
 from .models_crossvit import Block, CrossAttentionBlock, PatchEmbed
 from .util.pos_embed import get_2d_sincos_pos_embed
 from .engine import Engine, is_trainable
+from ._module import HipModule
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -43,7 +44,7 @@ class _DecoderFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
-class SupervisedMAE(nn.Module):
+class SupervisedMAE(HipModule):
     def __init__(self, img_size=384, patch_size=16, in_chans=3,
                  embed_dim=1024, depth=24, num_heads=16,
                  decoder_embed_dim=512, decoder_depth=2, decoder_num_heads=16,
@@ -88,8 +89,6 @@ class SupervisedMAE(nn.Module):
         self.decode_head3 = head(256, final=True)
         self.norm_pix_loss = norm_pix_loss
         self.initialize_weights()
-        self._eng = None
-        self._versions = None
 
     # ------------------------------------------------------------------ init (models_mae_cross.py:108-134)
     def initialize_weights(self):
@@ -111,47 +110,12 @@ class SupervisedMAE(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
-    # ------------------------------------------------------------------ engine plumbing
-    def _apply(self, fn, *a, **k):
-        out = super()._apply(fn, *a, **k)
-        self._eng = None  # parameters moved / re-typed: repack on the next forward
-        return out
+    # ------------------------------------------------------------------ engine plumbing (see _module.HipModule)
+    def _make_engine(self, shapes, device):
+        return Engine(self.cfg, shapes, device, precision=self.precision, img_size=self.img_size)
 
-    def _engine(self):
-        params = list(self.named_parameters())
-        dev = params[0][1].device
-        if dev.type != "cuda":
-            raise RuntimeError("SupervisedMAE (HIP engine) needs its parameters on a GPU: call model.to('cuda'); "
-                               "there is no CPU fallback")
-        if self._eng is None:
-            shapes = [(n, tuple(p.shape)) for n, p in params]
-            eng = Engine(self.cfg, shapes, dev, precision=self.precision, img_size=self.img_size)
-            with torch.no_grad():
-                for n, p in params:
-                    view = eng.pview(n)
-                    view.copy_(p.data.float())
-                    p.data = view  # parameters now alias the flat fp32 master buffer
-            self._train_names = [n for n, _ in params if is_trainable(n)]
-            self._train_params = [p for n, p in params if is_trainable(n)]
-            self._eng = eng
-            self._versions = None
-        eng = self._eng
-        # repack if someone replaced a parameter's storage (e.g. load_state_dict(assign=True))
-        for n, p in params:
-            if p.data_ptr() != eng.pview(n).data_ptr():
-                with torch.no_grad():
-                    eng.pview(n).copy_(p.data.float())
-                    p.data = eng.pview(n)
-                self._versions = None
-        vers = sum(p._version for _, p in params)
-        if vers != self._versions:  # optimizer.step() / load_state_dict changed values: refresh shadows
-            eng.sync_weights()
-            self._versions = vers
-        return eng
-
-    def mark_weights_synced(self):
-        """The engine's fused AdamW keeps the shadows coherent itself."""
-        self._versions = sum(p._version for p in self.parameters())
+    def _is_trainable(self, name):
+        return is_trainable(name)
 
     # ------------------------------------------------------------------ reference surface
     def forward_encoder(self, x):

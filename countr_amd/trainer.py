@@ -14,9 +14,11 @@ from . import _lib
 from .parallel import GradSync
 
 
-class FinetuneStep:
-    def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None):
+class _GraphStep:
+    """Shared machinery of the optimisation steps: dedicated stream, per-phase hipGraph capture/replay, two-bucket gradient
+    all-reduce, device-side AdamW scalars."""
+
+    def __init__(self, model, batch, lr, weight_decay, betas, eps, use_graph, process_group):
         self.model = model
         self.eng = model._engine()
         self.B = batch
@@ -38,33 +40,7 @@ class FinetuneStep:
         self.world = self.sync.world
         self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._ring_ev = [None] * 16
-        self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
-        self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
-        self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
-
-    # ------------------------------------------------------------------ phases
-    def _phase_a(self, S):
-        """forward + loss (+ dL/dout) + backward until the head/decoder_norm gradients (bucket 0) are final."""
-        eng = self.eng
-        p = eng.plan(self.B, S, True)
-        eng.run(p.fwd)
-        if S not in self.sums:
-            self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
-        sums = self.sums[S]
-        HW = eng.img * eng.img
-        _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
-                                           sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
-        eng.run(p.bwd_head)
-
-    def _phase_b(self, S):
-        p = self.eng.plan(self.B, S, True)
-        if S == 0:  # exemplar-CNN gradients are absent for this shot_num: keep the bucket well-defined
-            s, e = self.eng.layout.bucket_range(2)
-            self.eng.G[s:e].zero_()
-        else:
-            s, e = self.eng.layout.bucket_range(3)
-            self.eng.G[s:e].zero_()
-        self.eng.run(p.bwd_rest)
+        self.grad_scale = 1.0
 
     def _phase_c(self, S):
         self.eng.adamw_launch(S, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper)
@@ -100,11 +76,60 @@ class FinetuneStep:
         h[0] = self.lr
         h[1] = 1.0 - self.betas[0] ** eng.step_count
         h[2] = 1.0 - self.betas[1] ** eng.step_count
-        h[3] = 1.0 / self.world
+        h[3] = self.grad_scale / self.world
         eng.hyper.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._ring_ev[slot] = ev
+
+    def _step(self, key):
+        """phase a -> bucket-0 all-reduce overlapped with phase b -> all-reduce of the rest -> fused AdamW."""
+        eng = self.eng
+        with torch.cuda.stream(self.stream):
+            if eng.M is None:
+                eng.M = torch.zeros_like(eng.G)
+                eng.V = torch.zeros_like(eng.G)
+            self._run_phase("a", self._phase_a, key)
+            self.sync.start_bucket0()          # overlaps with the rest of backward
+            self._run_phase("b", self._phase_b, key)
+            self.sync.finish()
+            self._upload_hyper()
+            self._run_phase("c", self._phase_c, key)
+        torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
+        self.model.mark_weights_synced()
+
+
+class FinetuneStep(_GraphStep):
+    def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
+                 process_group=None):
+        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group)
+        self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
+        self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
+        self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
+
+    # ------------------------------------------------------------------ phases
+    def _phase_a(self, S):
+        """forward + loss (+ dL/dout) + backward until the head/decoder_norm gradients (bucket 0) are final."""
+        eng = self.eng
+        p = eng.plan(self.B, S, True)
+        eng.run(p.fwd)
+        if S not in self.sums:
+            self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
+        sums = self.sums[S]
+        HW = eng.img * eng.img
+        _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
+                                           sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
+        eng.run(p.bwd_head)
+
+    def _phase_b(self, S):
+        p = self.eng.plan(self.B, S, True)
+        if S == 0:  # exemplar-CNN gradients are absent for this shot_num: keep the bucket well-defined
+            s, e = self.eng.layout.bucket_range(2)
+            self.eng.G[s:e].zero_()
+        else:
+            s, e = self.eng.layout.bucket_range(3)
+            self.eng.G[s:e].zero_()
+        self.eng.run(p.bwd_rest)
 
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
@@ -125,17 +150,48 @@ class FinetuneStep:
         [loss, pred counts (B), gt counts (B)] without synchronising the host."""
         if lr is not None:
             self.lr = lr
-        eng = self.eng
-        with torch.cuda.stream(self.stream):
-            if eng.M is None:
-                eng.M = torch.zeros_like(eng.G)
-                eng.V = torch.zeros_like(eng.G)
-            self._run_phase("a", self._phase_a, S)
-            self.sync.start_bucket0()          # overlaps with the rest of backward
-            self._run_phase("b", self._phase_b, S)
-            self.sync.finish()
-            self._upload_hyper()
-            self._run_phase("c", self._phase_c, S)
-        torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
-        self.model.mark_weights_synced()
+        self._step(S)
         return self.sums[S]
+
+
+class PretrainStep(_GraphStep):
+    """MAE pretraining step (reference FSC_pretrain.py:254-301 minus the per-step host syncs): random masking, forward,
+    all-patch pixel MSE, full backward (decoder-side bucket all-reduced while the encoder backward runs), fused AdamW.
+    The masking permutation is drawn with torch.rand + argsort exactly as models_mae_noct.py:119-121 (outside the
+    captured region, so every replay sees fresh indices through the plan's index buffers)."""
+
+    def __init__(self, model, batch, mask_ratio=0.5, lr=5e-6, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
+                 process_group=None, accum_scale=1.0):
+        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group)
+        self.K = model.len_keep(mask_ratio)
+        self.grad_scale = accum_scale
+
+    def _phase_a(self, K):
+        eng = self.eng
+        p = eng.plan(self.B, K, True)
+        eng.run(p.fwd)
+        eng.loss_launch(p, self.B, self.model.norm_pix_loss)
+        eng.run(p.bwd_dec)
+
+    def _phase_b(self, K):
+        self.eng.run(self.eng.plan(self.B, K, True).bwd_enc)
+
+    def load(self, imgs, ids_shuffle=None):
+        cur = torch.cuda.current_stream(self.eng.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            p = self.eng.plan(self.B, self.K, True)
+            p.buf["img"].copy_(imgs, non_blocking=True)
+            if ids_shuffle is None:
+                ids_shuffle = self.model.draw_masking(self.B, self.eng.device)
+            self.eng.set_masking(p, ids_shuffle)
+        if imgs.is_cuda:
+            imgs.record_stream(self.stream)
+
+    def step(self, lr=None):
+        """One optimisation step on the batch last given to load(); returns the device loss tensor [1] (no host sync).
+        pred / mask of the step stay in eng.plan(B, K, True).buf["pred" / "mask"]."""
+        if lr is not None:
+            self.lr = lr
+        self._step(self.K)
+        return self.eng.plan(self.B, self.K, True).buf["loss"]

@@ -180,6 +180,21 @@ int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow
                       const int64_t* starts, const int64_t* ends, const float* wds, float lr, float beta1,
                       float beta2, float eps, int step, float grad_scale, const float* hyper_dev, void* stream);
 
+/* ---- MAE pretraining (reference models_mae_noct.py) ----
+ * row gather: dst[r,:] = (idx[r] >= 0 ? src[idx[r],:] : default_row[:]) + add[r % add_mod,:]; idx may be NULL (identity),
+ * default_row/add may be NULL, add_mod <= 0 means add[r,:].  cols % 4 == 0; src/dst dtype codes independent.  Covers
+ * random_masking's gather of kept tokens (:125-126), the unshuffle with mask tokens + decoder_pos_embed (:166-172) and
+ * the backward of both. */
+int countr_gather_rows(const void* src, const int* idx, void* dst, const float* default_row, const float* add, int add_mod,
+                       int rows, int cols, int src_dtype, int dst_dtype, void* stream);
+/* forward_loss (:181-198): target = patchify(imgs) in (py,px,c) order (:84-96), optional norm_pix (unbiased var, eps 1e-6),
+ * loss[0] = mean over ALL patches of the per-patch mean squared error; dpred (optional, dtype dpred_dtype) =
+ * grad_scale * dloss/dpred.  pred fp32 [B*L, 3*patch^2]; imgs fp32 NCHW; workspace fp32[countr_patch_mse_workspace_floats].
+ * Deterministic two-stage reduction (no atomics). */
+int countr_patch_mse_workspace_floats(int B, int H, int W, int patch);
+int countr_patch_mse(const float* pred, const float* imgs, void* dpred, float* loss, float* workspace, int B, int H, int W,
+                     int patch, int norm_pix, float grad_scale, int dpred_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

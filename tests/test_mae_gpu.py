@@ -1,0 +1,184 @@
+"""GPU: MAE pretraining path (drop-in models_mae_noct.MaskedAutoencoderViTNoCT) through the C ABI against the reference
+goldens (tests/golden/mae_b2.npz, produced by the reference's models_mae_noct.py) and the CPU oracle (oracle/mae_ref.py).
+
+Tolerances: fp32 mode -- loss 1e-5 rel, pred 1e-3 of max, gradient norms 1e-3 rel, gradient elements 2e-3 of the tensor's
+max; bf16 mode -- loss 1e-2 rel, pred rms 3e-2, gradient rms error <= 6e-2 of the tensor's rms."""
+import ctypes as C
+import json
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import mae_ref as M
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+NAME = "mae_vit_base_patch16"
+_s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def build(name, precision, seed=0, norm_pix_loss=False):
+    from countr_amd.models_mae_noct import MaskedAutoencoderViTNoCT
+    p, D, depth, H, Dd, ddepth, Hd = W.MAE_CONFIGS[name]
+    sd = W.make_state_dict_mae(name, seed=seed)
+    m = MaskedAutoencoderViTNoCT(patch_size=p, embed_dim=D, depth=depth, num_heads=H, decoder_embed_dim=Dd, decoder_depth=ddepth,
+                                 decoder_num_heads=Hd, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                 norm_pix_loss=norm_pix_loss, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda"), sd
+
+
+# ---------------------------------------------------------------- kernels
+@pytest.mark.parametrize("sdt,ddt", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gather_rows(hip, sdt, ddt):
+    g = torch.Generator().manual_seed(1)
+    rows_src, rows, cols = 300, 700, 512
+    src = torch.randn(rows_src, cols, generator=g)
+    idx = torch.randint(-1, rows_src, (rows,), generator=g, dtype=torch.int32)
+    dflt, add = torch.randn(cols, generator=g), torch.randn(64, cols, generator=g)
+    s = (src.bfloat16() if sdt else src).cuda()
+    out = torch.empty(rows, cols, device="cuda", dtype=torch.bfloat16 if ddt else torch.float32)
+    assert hip.countr_gather_rows(s.data_ptr(), idx.cuda().data_ptr(), out.data_ptr(), dflt.cuda().data_ptr(), add.cuda().data_ptr(), 64,
+                                  rows, cols, sdt, ddt, _s()) == 0
+    sv = s.float().cpu()
+    ref = torch.where((idx >= 0).unsqueeze(1), sv[idx.clamp(min=0).long()], dflt.unsqueeze(0)) + add[torch.arange(rows) % 64]
+    if ddt:
+        ref = ref.bfloat16().float()
+    assert torch.equal(out.float().cpu(), ref)   # a gather is exact (bf16 output: one RNE rounding of the exact sum)
+    # identity / no default / no add
+    out2 = torch.empty(rows_src, cols, device="cuda")
+    assert hip.countr_gather_rows(src.cuda().data_ptr(), None, out2.data_ptr(), None, None, 0, rows_src, cols, 0, 0, _s()) == 0
+    assert torch.equal(out2.cpu(), src)
+    assert hip.countr_gather_rows(src.cuda().data_ptr(), None, out2.data_ptr(), None, None, 0, rows_src, 6, 0, 0, _s()) != 0
+
+
+@pytest.mark.parametrize("norm_pix", [False, True])
+@pytest.mark.parametrize("patch", [16, 14])
+def test_patch_mse(hip, norm_pix, patch):
+    B, H = 2, 384 if patch == 16 else 14 * 8
+    g = torch.Generator().manual_seed(2)
+    imgs = torch.rand(B, 3, H, H, generator=g)
+    L, F = (H // patch) ** 2, 3 * patch * patch
+    pred = torch.randn(B * L, F, generator=g).requires_grad_(True)
+    target = M.patchify(imgs, patch)
+    if norm_pix:
+        target = (target - target.mean(-1, keepdim=True)) / (target.var(-1, keepdim=True) + 1e-6) ** 0.5
+    loss = ((pred.view(B, L, F) - target) ** 2).mean(-1).sum() / (B * L)
+    loss.backward()
+    ws = torch.empty(hip.countr_patch_mse_workspace_floats(B, H, H, patch), device="cuda")
+    out = torch.empty(1, device="cuda")
+    for dt in (0, 1):
+        dp = torch.empty(B * L, F, device="cuda", dtype=torch.bfloat16 if dt else torch.float32)
+        assert hip.countr_patch_mse(pred.detach().cuda().data_ptr(), imgs.cuda().data_ptr(), dp.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                    B, H, H, patch, int(norm_pix), 0.5, dt, _s()) == 0
+        assert abs(out.item() - loss.item()) <= 2e-6 * loss.item()
+        err = (dp.float().cpu() - 0.5 * pred.grad).abs().max().item()
+        assert err <= (5e-3 if dt else 2e-6) * pred.grad.abs().max().item()
+
+
+# ---------------------------------------------------------------- model vs reference goldens + oracle
+@pytest.mark.parametrize("tag,npl", [("plain", False), ("normpix", True)])
+def test_mae_fp32_matches_reference(tag, npl):
+    g = np.load(os.path.join(G, "mae_b2.npz"))
+    meta = json.load(open(os.path.join(G, "mae_meta.json")))
+    m, sd = build(NAME, "fp32", norm_pix_loss=npl)
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(a, b) for a, b in meta["schema"]]
+    imgs, ids_shuffle, ids_restore, len_keep = W.make_mae_inputs(batch=2, seed=0, mask_ratio=0.5)
+    m.train()
+    loss, pred, mask = m(torch.from_numpy(imgs).cuda(), mask_ratio=0.5, ids_shuffle=torch.from_numpy(ids_shuffle).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    gl = float(g["loss_" + tag])
+    assert abs(loss.item() - gl) <= 1e-5 * gl
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    ph = g["pred_head_" + tag]
+    assert np.abs(pred.detach().cpu().numpy()[:, :8] - ph).max() <= 1e-3 * np.abs(ph).max()
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(got) == meta["grad_tensors_" + tag]
+    for k, gr in got.items():
+        gr = gr.cpu().numpy().astype(np.float64)
+        gn = float(g["%s/norm/%s" % (tag, k)])
+        assert abs(np.sqrt((gr ** 2).sum()) - gn) <= 1e-3 * gn + 1e-9, k
+        head = g["%s/head/%s" % (tag, k)]
+        assert np.abs(gr.reshape(-1)[:256] - head).max() <= 2e-3 * max(np.abs(gr).max(), 1e-12) + 2e-8, k
+
+
+def test_mae_bf16_close_to_oracle():
+    m, sd = build(NAME, "bf16")
+    imgs, ids_shuffle, ids_restore, len_keep = W.make_mae_inputs(batch=2, seed=1, mask_ratio=0.5)
+    rl, rp, rm, rg = M.loss_and_grads(sd, imgs, ids_shuffle, ids_restore, len_keep, NAME)
+    loss, pred, mask = m(torch.from_numpy(imgs).cuda(), mask_ratio=0.5, ids_shuffle=torch.from_numpy(ids_shuffle).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - rl.item()) <= 1e-2 * rl.item()
+    assert torch.equal(mask.cpu(), rm)
+    d = pred.detach().cpu() - rp
+    assert d.pow(2).mean().sqrt().item() <= 3e-2 * rp.pow(2).mean().sqrt().item()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if k not in rg:
+            assert p.grad is None
+            continue
+        e = (p.grad.cpu() - rg[k]).pow(2).mean().sqrt().item() / max(rg[k].pow(2).mean().sqrt().item(), 1e-20)
+        worst = max(worst, e)
+        assert e <= 6e-2, (k, e)
+    print("bf16 worst grad rms err", worst)
+
+
+def test_mae_other_mask_ratio_and_eval():
+    """mask_ratio 0.75 (len_keep 144, ragged attention tile) and the no-grad forward; encoder/decoder split."""
+    m, sd = build("tiny_test", "fp32", seed=2)
+    imgs, ids_shuffle, ids_restore, len_keep = W.make_mae_inputs(batch=3, seed=4, mask_ratio=0.75)
+    assert len_keep == 144
+    P = {k: torch.from_numpy(v) for k, v in sd.items()}
+    rl, rp, rm = M.forward(P, imgs, ids_shuffle, ids_restore, len_keep, "tiny_test")
+    x, ids = torch.from_numpy(imgs).cuda(), torch.from_numpy(ids_shuffle).cuda()
+    with torch.no_grad():
+        loss, pred, mask = m(x, mask_ratio=0.75, ids_shuffle=ids)
+        lat, mask2, idr = m.forward_encoder(x, 0.75, ids_shuffle=ids)
+        pred2 = m.forward_decoder(lat, idr)
+        loss2 = m.forward_loss(x, pred2, mask2)
+    assert abs(loss.item() - rl.item()) <= 1e-5 * rl.item()
+    assert (pred.cpu() - rp).abs().max().item() <= 1e-3 * rp.abs().max().item()
+    assert torch.equal(mask.cpu(), rm) and torch.equal(mask2.cpu(), rm) and torch.equal(idr.cpu(), torch.from_numpy(ids_restore))
+    assert (pred2.cpu() - rp).abs().max().item() <= 1e-3 * rp.abs().max().item()
+    assert abs(loss2.item() - rl.item()) <= 1e-5 * rl.item()
+    xm, mk, _ = m.random_masking(torch.from_numpy(imgs[:, 0, :576, :64]).cuda().contiguous(), 0.75, ids_shuffle=ids)
+    ref = torch.gather(torch.from_numpy(imgs[:, 0, :576, :64]), 1, torch.from_numpy(ids_shuffle[:, :144]).unsqueeze(-1).expand(-1, -1, 64))
+    assert torch.equal(xm.cpu(), ref)
+    # the internally drawn permutation is a permutation and keeps exactly len_keep tokens
+    with torch.no_grad():
+        _, _, mk = m(x, mask_ratio=0.75)
+    assert (mk.sum(1) == 576 - 144).all()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pretrain_steps_match_oracle(use_graph):
+    from countr_amd.trainer import PretrainStep
+    from countr_amd.engine import no_weight_decay
+    from oracle import countr_ref as R
+    name = "tiny_test"
+    m, sd = build(name, "fp32", seed=5)
+    step = PretrainStep(m, batch=2, mask_ratio=0.5, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph)
+    ref = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    for it in range(3):
+        imgs, ids_shuffle, ids_restore, len_keep = W.make_mae_inputs(batch=2, seed=20 + it, mask_ratio=0.5)
+        step.load(torch.from_numpy(imgs).cuda(), torch.from_numpy(ids_shuffle).cuda())
+        loss = step.step().clone()
+        torch.cuda.synchronize()
+        cur = {k: v.float().numpy() for k, v in ref.items()}
+        rl, _, _, rg = M.loss_and_grads(cur, imgs, ids_shuffle, ids_restore, len_keep, name)
+        assert abs(loss.item() - rl.item()) <= 1e-4 * rl.item(), it
+        for k, g in rg.items():
+            wd = 0.0 if no_weight_decay(k, ref[k].shape) else 0.05
+            ref[k], m1, m2 = R.adamw_step(ref[k], g.double(), mom[k][0], mom[k][1], it + 1, 1e-3, eps=1e-4, wd=wd)
+            mom[k] = (m1, m2)
+        for k, p in m.named_parameters():
+            d = (p.detach().cpu().double() - ref[k]).abs()
+            assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (it + 1), (it, k)
