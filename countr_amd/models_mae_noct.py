@@ -23,8 +23,9 @@ class _MaeFn(torch.autograd.Function):
         eng = model._engine()
         loss, pred, mask = eng.forward(imgs, ids_shuffle, len_keep, train=True, norm_pix=model.norm_pix_loss)
         ctx.model, ctx.B, ctx.K = model, imgs.shape[0], len_keep
+        mask = mask.clone()
         ctx.mark_non_differentiable(mask)
-        return loss[0].clone(), pred.clone(), mask.clone()
+        return loss[0].clone(), pred.clone(), mask
 
     @staticmethod
     def backward(ctx, dloss, dpred, dmask):
