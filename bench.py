@@ -74,6 +74,60 @@ def attention_roofline(model, batch, iters=20):
             "us_per_launch": sec * 1e6}
 
 
+PRETRAIN_GF_PER_IMG = 3 * (288 * 12 * 2 * (12 * 768 * 768) + 12 * 4 * 288 * 288 * 768      # encoder on 288 kept tokens
+                           + 576 * 8 * 2 * (12 * 512 * 512) + 8 * 4 * 576 * 576 * 512      # decoder on 576 tokens
+                           + 2 * (288 * 768 * 768 + 288 * 768 * 512 + 576 * 512 * 768))    # embeds + pixel head; x3 = fwd+bwd
+
+
+def bench_pretrain(args, world, rank, dev):
+    """MAE pretraining step (FSC_pretrain.py:254-301; mask_ratio 0.5, batch 8 per GPU by default): not the BASELINE.json
+    metric -- selected explicitly with --workload pretrain."""
+    import models_mae_noct
+    from countr_amd.trainer import PretrainStep
+    torch.manual_seed(rank)
+    model = models_mae_noct.__dict__["mae_vit_base_patch16"](norm_pix_loss=False, precision=args.precision)
+    model.to(dev).train()
+    B = args.batch
+    step = PretrainStep(model, batch=B, mask_ratio=0.5, lr=5e-6, weight_decay=0.05, use_graph=not args.no_graph)
+    imgs = torch.rand(B, 3, 384, 384, device=dev)
+
+    def one():
+        step.load(imgs)          # draws a fresh masking permutation (torch.rand + argsort) every step, as the reference
+        return step.step()
+    for _ in range(max(args.warmup, 2)):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    lv = loss.item()
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        print(json.dumps({
+            "metric": "images/sec (384x384, mask_ratio 0.5) MAE pretrain step", "value": ips, "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "MAE pretrain ViT-B/16 + 8x512-d decoder (models_mae_noct.mae_vit_base_patch16), batch=%d per GPU, "
+                                   "random masking + fwd + all-patch MSE + full bwd + AdamW" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
+            "final_loss": lv, "step_tflops": PRETRAIN_GF_PER_IMG * ips / 1e12}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +137,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="finetune", choices=["finetune", "pretrain"],
+                    help="finetune = BASELINE.json metric (default); pretrain = MAE pretraining step (SURVEY 8f rank 3, config 4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
     args = ap.parse_args()
 
@@ -98,6 +154,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.workload == "pretrain":
+        return bench_pretrain(args, world, rank, dev)
     import models_mae_cross
     from countr_amd.trainer import FinetuneStep
     from countr_amd.synthetic import make_batch

@@ -325,25 +325,44 @@ constexpr bool is_rowlike(int mode) { return mode == COUNTR_OP_ROW || mode == CO
 // N-side permutation), `row4` the first of the 4 consecutive rows this lane addresses for a
 // transpose read.
 // ---------------------------------------------------------------------------------------------
+// The reads are INLINE ASM on purpose: for compiler-visible ds_reads the backend inserts s_waitcnt vmcnt(0) in front of
+// them whenever an LDS-DMA load is in flight (it cannot prove that the DMA destination and the read do not alias), which
+// serialises "stream tile t+1 / multiply tile t" completely.  With opaque reads the kernel owns both counters: vmcnt for
+// the DMA stages (explicit s_waitcnt + barrier before a stage is read) and lgkmcnt for the fragments (lds_wait below).
+typedef __attribute__((address_space(3))) const char* lds_cptr_t;
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(lds_cptr_t)p; }
+
+template <int MODE> struct FragReads { static constexpr int N = is_rowlike(MODE) ? 1 : 2; };  // LDS instructions per fragment
+
 template <int MODE>
-__device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int row, int row4, int kk, int lane) {
+__device__ __forceinline__ bf16x8_t frag_bf16(uint32_t lds, int row, int row4, int kk, int lane) {
   const int g = lane >> 4, i = lane & 15;
   if constexpr (is_rowlike(MODE)) {
-    return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + (((kk * 4 + g) ^ swz_row(row)) << 4));
+    bf16x8_t v;
+    const uint32_t a = lds + row * 128 + (((kk * 4 + g) ^ swz_row(row)) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+    return v;
   } else {
     // K-major image [k][row]: two hardware-transposing reads of a [4 k][16 rows] block each.
-    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
     const int k0 = kk * 32 + g * 8 + (i >> 2), k1 = k0 + 4;
-    const char* p0 = lds + k0 * 256 + (((row4 >> 3) ^ swz_col(k0)) << 4) + (row4 & 7) * 2;
-    const char* p1 = lds + k1 * 256 + (((row4 >> 3) ^ swz_col(k1)) << 4) + (row4 & 7) * 2;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p0));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p1));
+    const uint32_t a0 = lds + k0 * 256 + (((row4 >> 3) ^ swz_col(k0)) << 4) + (row4 & 7) * 2;
+    const uint32_t a1 = lds + k1 * 256 + (((row4 >> 3) ^ swz_col(k1)) << 4) + (row4 & 7) * 2;
+    s16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-    s16x8_t r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    const s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, r);
   }
+}
+
+// Wait until at most PENDING LDS reads are outstanding; the fragments are threaded through the asm so that the MFMAs
+// consuming them cannot be scheduled above the wait.
+template <int PENDING>
+__device__ __forceinline__ void lds_wait(bf16x8_t (&x)[4], bf16x8_t (&w)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
+               : "n"(PENDING));
 }
 
 // fp32: 4 consecutive MFMA k-steps' operands; lane (i, g) holds k = c16*16 + 4*g + s, s = 0..3.
@@ -364,7 +383,7 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
 }
 
 template <typename T, int MA, int MB, int STAGES, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN, NW = WM * WN;
   constexpr int SA = BMt * 128, SB = BNt * 128;  // bf16 stage bytes per operand
   constexpr int BK = Cfg<T>::BK;
@@ -426,6 +445,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
   if constexpr (sizeof(T) == 2) {
     // ---------------- bf16: LDS-DMA staging, two stages, tile t+1 in flight while tile t is multiplied
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // k-skew: workgroups walk the k-tiles in rotated order so that, at any moment, the workgroups of an XCD read different
+    // 128-byte k-columns.  In lock step they would all hit the few L2 channels that one k-column of a matrix with a
+    // power-of-two-ish leading dimension maps to (partition camping).  Only the fp32 summation order changes.
+    const int kskew = (MB == COUNTR_OP_IM2COL || ntiles == 0) ? 0 : (int)(((unsigned)lt * (unsigned)skew_mul) % (unsigned)ntiles);
+    auto ktile = [&](int t) { int tt = t + kskew; if (tt >= ntiles) tt -= ntiles; return kstart + tt * BK; };
     DmaLoader<MA, BMt, NW> la;
     DmaLoader<MB, BNt, NW> lb;
     la.init(dA, m0, kstart, wv, lane);
@@ -438,28 +462,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
     f32x4_t accb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) accb[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    auto mma_tile = [&](const char* sa, const char* sb) {
+    constexpr int KREADS = 4 * FragReads<MA>::N + 4 * FragReads<MB>::N;   // LDS reads per 32-wide k-step
+    constexpr int KPEND = KREADS > 15 ? 15 : KREADS;                      // lgkmcnt is a 4-bit counter
+    auto mma_tile = [&](const char* sa_, const char* sb_) {
+      const uint32_t sa = lds_addr(sa_), sb = lds_addr(sb_);
+      bf16x8_t xf[2][4], wf[2][4];
+#if COUNTR_ABL == 2
+      for (int kk = 0; kk < 2; ++kk)
+        for (int q = 0; q < 4; ++q) { xf[kk][q] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, q, kk, 1)); wf[kk][q] = xf[kk][q]; }
+#else
+      // both k-steps' fragments are requested up front; the MFMAs of step 0 run while step 1's reads are still in flight
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8_t xf[4], wf[4];
-#if COUNTR_ABL == 2
-        if (kk == 0 && acc[0][0][0] == 12345.f) {
-#endif
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
-          xf[tm] = frag_bf16<MA>(sa, mrow(tm), wm0 + tm * 16 + (li & 3) * 4, kk, lane);
+          xf[kk][tm] = frag_bf16<MA>(sa, mrow(tm), wm0 + tm * 16 + (li & 3) * 4, kk, lane);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-          wf[tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
-#if COUNTR_ABL == 2
-        } else {
-          for (int q = 0; q < 4; ++q) { xf[q] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, q, kk, 1)); wf[q] = xf[q]; }
-        }
+          wf[kk][tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
+      }
+#endif
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#if COUNTR_ABL != 2
+        if (kk == 0) lds_wait<KPEND>(xf[0], wf[0]);
+        else lds_wait<0>(xf[1], wf[1]);
 #endif
 #if COUNTR_ABL == 1
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint4 a = __builtin_bit_cast(uint4, xf[q]), b = __builtin_bit_cast(uint4, wf[q]);
+          const uint4 a = __builtin_bit_cast(uint4, xf[kk][q]), b = __builtin_bit_cast(uint4, wf[kk][q]);
           acc[q][0][0] += __uint_as_float(a.x ^ b.x); acc[q][1][1] += __uint_as_float(a.y ^ b.y);
           acc[q][2][2] += __uint_as_float(a.z ^ b.z); acc[q][3][3] += __uint_as_float(a.w ^ b.w);
         }
@@ -468,12 +500,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][tn], xf[kk][tm], acc[tm][tn], 0, 0, 0);
 #endif
         if (do_rowsum) {  // wave-uniform: row sums of the M-side operand = bias gradient of a wgrad GEMM
           const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[tm], accb[tm], 0, 0, 0);
+          for (int tm = 0; tm < 4; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[kk][tm], accb[tm], 0, 0, 0);
         }
       }
     };
@@ -481,18 +513,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
       // Single LDS stage (32 KB): up to 5 workgroups stay resident per CU and hide each other's DMA latency.
       // Chosen by the host for big grids (>= ~3 workgroups per CU), where it beats per-workgroup double buffering.
       for (int t = 0; t < ntiles; ++t) {
-        la.issue(kstart + t * BK, kend, smem, wv);
-        lb.issue(kstart + t * BK, kend, smem + SA, wv);
+        la.issue(ktile(t), kend, smem, wv);
+        lb.issue(ktile(t), kend, smem + SA, wv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mma_tile(smem, smem + SA);
         __builtin_amdgcn_s_barrier();  // all fragment reads of this tile are consumed before it is overwritten
       }
+    } else if constexpr (STAGES >= 3) {
+      // Deep pipeline for SMALL grids (<= 1 workgroup per CU, nothing else to hide the DMA round trip): STAGES-1 tiles are in
+      // flight while one is multiplied.  Counted vmcnt: DMA loads retire in order, so "at most (STAGES-2) tiles' worth of
+      // loads outstanding" means tile t has landed.
+      constexpr int PER = DmaLoader<MA, BMt, NW>::PASSES + DmaLoader<MB, BNt, NW>::PASSES;   // DMA instructions per wave per tile
+      static_assert((STAGES - 2) * PER <= 63, "vmcnt immediate");
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (s < ntiles) {
+          la.issue(ktile(s), kend, smem + s * (SA + SB), wv);
+          lb.issue(ktile(s), kend, smem + s * (SA + SB) + SA, wv);
+        }
+      int slot = 0, islot = STAGES - 1;
+      for (int t = 0; t < ntiles; ++t) {
+        if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile t visible to all waves; every wave is done with the slot refilled below
+        if (t + STAGES - 1 < ntiles) {
+          char* nxt = smem + islot * (SA + SB);
+          la.issue(ktile(t + STAGES - 1), kend, nxt, wv);
+          lb.issue(ktile(t + STAGES - 1), kend, nxt + SA, wv);
+        }
+        mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
+        slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+        islot = (islot + 1 == STAGES) ? 0 : islot + 1;
+      }
     } else {
       // Two stages (64 KB, 2 workgroups per CU): tile t+1 streams in while tile t is multiplied.
       if (ntiles > 0) {
-        la.issue(kstart, kend, smem, wv);
-        lb.issue(kstart, kend, smem + SA, wv);
+        la.issue(ktile(0), kend, smem, wv);
+        lb.issue(ktile(0), kend, smem + SA, wv);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -500,8 +558,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
         const int cur = t & 1;
         if (t + 1 < ntiles && (COUNTR_ABL != 3)) {
           char* nxt = smem + (cur ^ 1) * (SA + SB);
-          la.issue(kstart + (t + 1) * BK, kend, nxt, wv);
-          lb.issue(kstart + (t + 1) * BK, kend, nxt + SA, wv);
+          la.issue(ktile(t + 1), kend, nxt, wv);
+          lb.issue(ktile(t + 1), kend, nxt + SA, wv);
         }
         mma_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -631,7 +689,8 @@ int launch_variant(const countr_gemm_args& a, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN>), grid, dim3(64 * WM * WN), lds_bytes, s, a);
+  static const int skew = [] { const char* e = getenv("COUNTR_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN>), grid, dim3(64 * WM * WN), lds_bytes, s, a, skew);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
@@ -658,11 +717,17 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       if (tile == 24) return launch_variant<T, MA, MB, 1, 2, 4>(a, s);
       if (tile == 42) return launch_variant<T, MA, MB, 1, 4, 2>(a, s);
     }
+    if constexpr (is_rowlike(MA)) {
+      if (ftile == 12) return force >= 3 ? launch_variant<T, MA, MB, 4, 1, 2>(a, s) : launch_variant<T, MA, MB, 2, 1, 2>(a, s);
+    }
     if (force == 1) return launch_variant<T, MA, MB, 1, 2, 2>(a, s);
     if (force == 2) return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
-    // deep-K launches on big grids: single stage + high occupancy; otherwise double-buffered
-    // (measured crossover on MI355X / 256 CUs with tools/bench_gemm.py)
-    if (t128 >= 512 && ktiles >= 24) return launch_variant<T, MA, MB, 1, 2, 2>(a, s);
+    if (force == 3) return launch_variant<T, MA, MB, 3, 2, 2>(a, s);
+    if (force == 4) return launch_variant<T, MA, MB, 4, 2, 2>(a, s);
+    // Double-buffered everywhere: since the fragment reads are opaque to the compiler (no implicit vmcnt(0) in front of
+    // them) tile t+1 really streams in under tile t's MFMAs, and the single-stage variant loses on every measured shape
+    // (tools/bench_gemm.py: conv wgrad 192x192 502 vs 681 us, conv fwd 429 vs 467 us).
+    (void)t128; (void)ktiles;
   }
   return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
 }

@@ -70,3 +70,20 @@ def load_model_FSC(args, model_without_ddp):
     model_without_ddp.load_state_dict(sd, strict=False)
     print("Resume checkpoint %s" % args.resume)
     return ckpt
+
+
+def load_model(args, model_without_ddp):
+    """util/misc.py:338-361 (pretraining resume, starts from MAE ImageNet weights FSC_pretrain.py:80): strict=False, both
+    pos-embeds dropped on shape mismatch; returns the checkpoint (the caller restores the flat AdamW state / epoch)."""
+    if not args.resume or not os.path.exists(args.resume):
+        return None
+    ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
+    sd = ckpt["model"]
+    have = model_without_ddp.state_dict()
+    for k in ("pos_embed", "decoder_pos_embed"):
+        if k in sd and sd[k].shape != have[k].shape:
+            print("Removing key %s from pretrained checkpoint" % k)
+            del sd[k]
+    model_without_ddp.load_state_dict(sd, strict=False)
+    print("Resume checkpoint %s" % args.resume)
+    return ckpt

@@ -27,6 +27,18 @@ for name, N, K in (("qkv 4608x2304x768", 2304, 768), ("proj 4608x768x768", 768, 
     a = base(); a.A, a.B, a.C = A_.data_ptr(), B_.data_ptr(), Cc.data_ptr(); a.lda = a.ldb = K; a.ldc = N
     a.M, a.N, a.K = M, N, K; a.out_bf16 = 1
     run(name, a, 1, 0, 0, 2.0 * M * N * K)
+# MAE pretrain encoder shapes (288 kept tokens per image): small grids
+Mp = B * 288
+for name, N, K in (("pre qkv 2304x2304x768", 2304, 768), ("pre proj 2304x768x768", 768, 768), ("pre fc1 2304x3072x768", 3072, 768),
+                   ("pre fc2 2304x768x3072", 768, 3072)):
+    A_, B_ = mk(Mp, K), mk(N, K); Cc = torch.empty((Mp, N), device="cuda", dtype=torch.bfloat16)
+    a = base(); a.A, a.B, a.C = A_.data_ptr(), B_.data_ptr(), Cc.data_ptr(); a.lda = a.ldb = K; a.ldc = N
+    a.M, a.N, a.K = Mp, N, K; a.out_bf16 = 1
+    run(name, a, 1, 0, 0, 2.0 * Mp * N * K)
+for name, N, K in (("pre dgrad fc1 2304x768x3072", 3072, 768), ("pre dgrad fc2 2304x3072x768", 768, 3072), ("pre dgrad qkv 2304x768x2304", 2304, 768)):
+    dy, w = mk(Mp, N), mk(N, K); dx = torch.empty((Mp, K), device="cuda", dtype=torch.bfloat16)
+    a = base(); a.A, a.B, a.C = dy.data_ptr(), w.data_ptr(), dx.data_ptr(); a.lda, a.ldb, a.ldc = N, K, K; a.M, a.N, a.K = Mp, K, N; a.out_bf16 = 1
+    run(name + " (row,col)", a, 1, 0, 1, 2.0 * Mp * N * K)
 # dgrad-style ROW x COL and wgrad-style COL x COL
 N, K = 2048, 512
 dy, w = mk(M, N), mk(N, K); dx = torch.empty((M, K), device="cuda", dtype=torch.bfloat16)
