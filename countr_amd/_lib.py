@@ -66,7 +66,7 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "countr_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "countr_layernorm_bwd_nblocks": [],
-    "countr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "countr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "countr_colsum_partials": [_vp, _vp, _i, _i, _i, _vp],
     "countr_groupnorm_nsplit": [_i],
     "countr_groupnorm_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],

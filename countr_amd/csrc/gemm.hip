@@ -714,8 +714,8 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       (void)t256; (void)t128x256;
       if (!tile) tile = 22;
       if (tile == 44) return launch_variant<T, MA, MB, 2, 4, 4>(a, s);
-      if (tile == 24) return launch_variant<T, MA, MB, 1, 2, 4>(a, s);
-      if (tile == 42) return launch_variant<T, MA, MB, 1, 4, 2>(a, s);
+      if (tile == 24) return launch_variant<T, MA, MB, 2, 2, 4>(a, s);
+      if (tile == 42) return launch_variant<T, MA, MB, 2, 4, 2>(a, s);
     }
     if constexpr (is_rowlike(MA)) {
       if (ftile == 12) return force >= 3 ? launch_variant<T, MA, MB, 4, 1, 2>(a, s) : launch_variant<T, MA, MB, 2, 1, 2>(a, s);

@@ -63,7 +63,8 @@ template <typename TI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            float* __restrict__ partial, int rows, int D, int accumulate) {
+                                                            bf16_t* __restrict__ dx_bf16, float* __restrict__ partial, int rows,
+                                                            int D, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem_ln[];
   float* sm = reinterpret_cast<float*>(smem_ln);  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += rs * (gy[i][e] - s1 - xh[i][e] * s2);
         st4<float>(dxr + c, o);
+        if (dx_bf16) st4<bf16_t>(dx_bf16 + (int64_t)row * D + c, o);   // GEMM-operand copy of the updated residual gradient
       }
     }
   }
@@ -644,13 +646,17 @@ extern "C" int countr_layernorm_bwd_nblocks(void) { return 256; }
 
 extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                     float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int D,
-                                    int dy_bf16, int accumulate_dx, int accumulate_dgb, void* stream) {
+                                    int dy_bf16, int accumulate_dx, int accumulate_dgb, void* dx_bf16, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace || D % 4 || D > 2048) { countr_set_error("countr_layernorm_bwd: bad args"); return -1; }
   const int nb = 256;
   const size_t lds = (size_t)4 * 2 * D * sizeof(float);
-  if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, workspace, rows, D, accumulate_dx);
-  // workspace rows are {dgamma[D], dbeta[D]} per block
+  if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
+  // workspace rows are {dgamma[D], dbeta[D]} per block; adjacent outputs (the flat gradient buffer) finish in one launch
+  if (dgamma && dbeta == dgamma + D) {
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, 2 * D, (int64_t)2 * D, accumulate_dgb);
+    COUNTR_LAUNCH_CHECK("countr_layernorm_bwd");
+  }
   if (dgamma) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, D, (int64_t)2 * D, accumulate_dgb);
   if (dbeta) hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, STREAM(stream), workspace + D, dbeta, nb, D, (int64_t)2 * D, accumulate_dgb);
   COUNTR_LAUNCH_CHECK("countr_layernorm_bwd");

@@ -361,11 +361,13 @@ class Engine:
                  mean.data_ptr() if mean is not None else None, rstd.data_ptr() if rstd is not None else None, rows, D, 1e-6,
                  int(y.dtype == torch.bfloat16))
 
-    def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate):
+    def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate, dx_t=None):
+        """dx_t (bf16 mode): also emit the updated residual gradient as the bf16 operand of the next backward GEMM."""
         ws = self._shared("lnbwd", 256 * 2 * 2048)
         self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
                  rstd.data_ptr(), dx.data_ptr(), self._gp(name + ".weight"), self._gp(name + ".bias"), ws.data_ptr(), rows, D,
-                 int(dy.dtype == torch.bfloat16), int(accumulate), 0)
+                 int(dy.dtype == torch.bfloat16), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
+        return dx if self.code == F32 else dx_t
 
     # unfused self-attention forward on a packed qkv [rows, 3*Dm]
     def _fused_attention(self, dh):
@@ -643,7 +645,7 @@ class Engine:
                 self._join(ops)
         gx = A("gx", (rows, Dd), f32)
         gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
-        self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False)
+        g_t = self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False, dx_t=gxT)
 
         ops = p.bwd_rest
         dh = A("dh", (rows, 4 * Dd), T)
@@ -661,19 +663,17 @@ class Engine:
         for i in reversed(range(self.ddepth)):
             b = "decoder_blocks.%d" % i
             d = blk[i]
-            # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))
-            g_t = self._cast(ops, gx, gxT, rows * Dd)
+            # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))  (g_t = bf16/fp32 operand view of gx, emitted by the LN backward)
             self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh)
             self._op(ops, L.countr_gelu_bwd, dh.data_ptr(), d["hpre"].data_ptr(), dh.data_ptr(), rows * 4 * Dd, code)
             self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t)
-            self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True)
+            g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=gxT)
             # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
-            g_t = self._cast(ops, gx, gxT, rows * Dd)
             self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
             self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
                      dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code)
             self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
-            self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True)
+            g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=gxT)
             dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
             dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
             for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
@@ -682,7 +682,6 @@ class Engine:
                                    resid=(None if first_tok else dy_tok), out_bf16=False)
                 first_tok = False
             # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
-            g_t = self._cast(ops, gx, gxT, rows * Dd)
             self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
             if d["lse"] is not None:
                 dlt = self._shared("attn_delta", B * Hd * N)
@@ -691,9 +690,8 @@ class Engine:
             else:
                 self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
             self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t)
-            self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True)
+            g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=gxT)
         # ---- decoder_embed (no dgrad: the encoder is frozen)
-        g_t = self._cast(ops, gx, gxT, rows * Dd)
         self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
         # ---- exemplar tokens
         if S == 0:

@@ -70,17 +70,16 @@ class MaeEngine(Engine):
         self._linear(ops, d["hact"], b + ".mlp.fc2.weight", d["x2"], rows, Dm, 4 * Dm, resid=d["x1"])
         return d
 
-    def _block_bwd(self, ops, b, d, s, B, N, Dm, heads):
-        """s: scratch dict {gx (fp32 grad of the residual stream, in/out), gxT, dh, dn_t, dproj_in, dqkv}."""
+    def _block_bwd(self, ops, b, d, s, B, N, Dm, heads, g_t):
+        """s: scratch dict {gx (fp32 grad of the residual stream, in/out), gxT, dh, dn_t, dproj_in, dqkv}; g_t = the GEMM-operand
+        view of gx on entry (emitted by the previous LayerNorm backward).  Returns the operand view of the updated gx."""
         L, code = self.L, self.code
         rows = B * N
         gx = s["gx"]
-        g_t = self._cast(ops, gx, s["gxT"], rows * Dm)
         self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dm, 4 * Dm, dx=s["dh"])
         self._op(ops, L.countr_gelu_bwd, s["dh"].data_ptr(), d["hpre"].data_ptr(), s["dh"].data_ptr(), rows * 4 * Dm, code)
         self._linear_bwd(ops, s["dh"], d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dm, Dm, dx=s["dn_t"])
-        self._layernorm_bwd(ops, s["dn_t"], d["x1"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dm, accumulate=True)
-        g_t = self._cast(ops, gx, s["gxT"], rows * Dm)
+        g_t = self._layernorm_bwd(ops, s["dn_t"], d["x1"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dm, accumulate=True, dx_t=s["gxT"])
         self._linear_bwd(ops, g_t, d["att"], b + ".attn.proj.weight", rows, Dm, Dm, dx=s["dproj_in"])
         if d["lse"] is not None:
             dlt = self._shared("attn_delta", B * heads * N)
@@ -89,7 +88,7 @@ class MaeEngine(Engine):
         else:
             self._attention_bwd(ops, d["qkv"], d["probs"], s["dproj_in"], s["dqkv"], B, heads, Dm, N=N)
         self._linear_bwd(ops, s["dqkv"], d["n1"], b + ".attn.qkv.weight", rows, 3 * Dm, Dm, dx=s["dn_t"])
-        self._layernorm_bwd(ops, s["dn_t"], d["xin"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dm, accumulate=True)
+        return self._layernorm_bwd(ops, s["dn_t"], d["xin"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dm, accumulate=True, dx_t=s["gxT"])
 
     def _bwd_scratch(self, p, tag, rows, Dm):
         T, f32 = self.tdt, torch.float32
@@ -180,9 +179,9 @@ class MaeEngine(Engine):
         ddn = A("ddn", (rn, Dd), T)
         sd = self._bwd_scratch(p, "dec", rn, Dd)
         self._linear_bwd(ops, dpred, dn, "decoder_pred.weight", rn, F, Dd, dx=ddn)
-        self._layernorm_bwd(ops, ddn, x, "decoder_norm", mN, rN, sd["gx"], rn, Dd, accumulate=False)
+        g_t = self._layernorm_bwd(ops, ddn, x, "decoder_norm", mN, rN, sd["gx"], rn, Dd, accumulate=False, dx_t=sd["gxT"])
         for i in reversed(range(self.ddepth)):
-            self._block_bwd(ops, "decoder_blocks.%d" % i, dec[i], sd, B, N, Dd, Hd)
+            g_t = self._block_bwd(ops, "decoder_blocks.%d" % i, dec[i], sd, B, N, Dd, Hd, g_t)
         # mask_token: sum of the gradient rows at masked positions (models_mae_noct.py:166-167)
         if rn > rk:
             gm = A("gmask", (rn - rk, Dd), f32)
@@ -197,10 +196,9 @@ class MaeEngine(Engine):
 
         ops = p.bwd_enc
         se = self._bwd_scratch(p, "enc", rk, D)
-        self._layernorm_bwd(ops, dlat, x_enc_out, "norm", mE, rE, se["gx"], rk, D, accumulate=False)
+        g_t = self._layernorm_bwd(ops, dlat, x_enc_out, "norm", mE, rE, se["gx"], rk, D, accumulate=False, dx_t=se["gxT"])
         for i in reversed(range(self.depth)):
-            self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H)
-        g_t = self._cast(ops, se["gx"], se["gxT"], rk * D)
+            g_t = self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H, g_t)
         self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
         return p
 

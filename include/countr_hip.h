@@ -92,12 +92,14 @@ int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, in
  * mean/rstd (fp32 [rows]) are optional outputs kept for the backward. */
 int countr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
                          float* rstd, int rows, int D, float eps, int out_bf16, void* stream);
-/* dx (+)= LN backward of dy; dgamma[D], dbeta[D] fp32 (may be NULL).
+/* dx (+)= LN backward of dy; dgamma[D], dbeta[D] fp32 (may be NULL).  dx_bf16 (optional) receives a bf16 copy of the
+ * updated dx (the operand of the next backward GEMM), saving a separate cast pass.
  * workspace: fp32 [countr_layernorm_bwd_nblocks()][2][D]. */
 int countr_layernorm_bwd_nblocks(void);
 int countr_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
                          const float* rstd, float* dx, float* dgamma, float* dbeta, float* workspace,
-                         int rows, int D, int dy_bf16, int accumulate_dx, int accumulate_dgb, void* stream);
+                         int rows, int D, int dy_bf16, int accumulate_dx, int accumulate_dgb, void* dx_bf16,
+                         void* stream);
 int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream);
 
 /* -------- GroupNorm(8, 256) + ReLU on NHWC maps (decode_head*: models_mae_cross.py:80-100).

@@ -57,12 +57,20 @@ def test_layernorm_fwd_bwd(hip, D, tdt, code, tol):
     dx = torch.full((rows, D), 0.5, device="cuda")
     dgb = torch.zeros((2, D), device="cuda")
     dyd = dy.cuda()
+    dxb = torch.empty((rows, D), device="cuda", dtype=torch.bfloat16)
     _lib.check(hip.countr_layernorm_bwd(P(dyd), P(xd), P(gd), P(mean), P(rstd), P(dx), P(dgb[0]), P(dgb[1]), P(ws), rows, D,
-                                        code, 1, 0, st()))
+                                        code, 1, 0, P(dxb), st()))   # adjacent dgamma/dbeta: single finisher launch
     yr.backward(dy.double())
     assert relerr(dx - 0.5, xr.grad) < 1e-4
     assert relerr(dgb[0], gr.grad) < 1e-4
     assert relerr(dgb[1], br.grad) < 1e-4
+    assert torch.equal(dxb, dx.bfloat16())          # the optional bf16 copy is the RNE rounding of the updated dx
+    # separate (non-adjacent) outputs, accumulate into existing values, no bf16 copy
+    dg2, db2 = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+    _lib.check(hip.countr_layernorm_bwd(P(dyd), P(xd), P(gd), P(mean), P(rstd), P(dx), P(dg2), P(db2), P(ws), rows, D,
+                                        code, 0, 1, None, st()))
+    assert relerr(dg2 - 1, gr.grad) < 1e-4 and relerr(db2 - 1, br.grad) < 1e-4
+    assert relerr(dx, xr.grad) < 1e-4
 
 
 @pytest.mark.parametrize("HW", [24 * 24, 96 * 96])
