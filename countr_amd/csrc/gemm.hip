@@ -383,7 +383,7 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
 }
 
 template <typename T, int MA, int MB, int STAGES, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
   constexpr int BMt = 64 * WM, BNt = 64 * WN, NW = WM * WN;
   constexpr int SA = BMt * 128, SB = BNt * 128;  // bf16 stage bytes per operand
   constexpr int BK = Cfg<T>::BK;
@@ -449,7 +449,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
     // 128-byte k-columns.  In lock step they would all hit the few L2 channels that one k-column of a matrix with a
     // power-of-two-ish leading dimension maps to (partition camping).  Only the fp32 summation order changes.
     const int kskew = (MB == COUNTR_OP_IM2COL || ntiles == 0) ? 0 : (int)(((unsigned)lt * (unsigned)skew_mul) % (unsigned)ntiles);
-    auto ktile = [&](int t) { int tt = t + kskew; if (tt >= ntiles) tt -= ntiles; return kstart + tt * BK; };
+    // implicit-GEMM convolutions walk K as (channel chunk outer, tap inner) although K is stored [tap][Cin]: the 9 taps of one
+    // 64-channel chunk re-read the same 128-byte line segments of neighbouring pixels back to back, so the live set of an XCD's
+    // resident workgroups stays well inside its 4 MB L2 (tap-major order cycles through ALL channels of ~4k pixels = the whole
+    // L2 between two uses of a line: PMC showed 6-12x the algorithmic bytes coming over the fabric).  Summation order only.
+    const bool conv_order = (MA == COUNTR_OP_IM2ROW) && !split && (g.Cin % BK == 0) && (kend - kstart == 9 * g.Cin) && conv_korder;
+    const int nchunk = conv_order ? g.Cin / BK : 1;
+    auto ktile = [&](int t) {
+      if (conv_order) { const int c = t / 9, tap = t - c * 9; return kstart + (tap * nchunk + c) * BK; }
+      int tt = t + kskew; if (tt >= ntiles) tt -= ntiles; return kstart + tt * BK;
+    };
     DmaLoader<MA, BMt, NW> la;
     DmaLoader<MB, BNt, NW> lb;
     la.init(dA, m0, kstart, wv, lane);
@@ -690,7 +699,8 @@ int launch_variant(const countr_gemm_args& a, hipStream_t s) {
     attr_set = true;
   }
   static const int skew = [] { const char* e = getenv("COUNTR_GEMM_SKEW"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN>), grid, dim3(64 * WM * WN), lds_bytes, s, a, skew);
+  static const int korder = [] { const char* e = getenv("COUNTR_CONV_KORDER"); return e ? atoi(e) : 1; }();
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN>), grid, dim3(64 * WM * WN), lds_bytes, s, a, skew, korder);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
