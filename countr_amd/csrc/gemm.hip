@@ -665,7 +665,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += b[e];
       }
-      if (g.C2) {
+      if (g.act == COUNTR_ACT_GELU_BWD) {   // dgrad of fc2 fused with GELU': C2 is the saved pre-activation (INPUT, layout of C)
+        float h[4];
+        if (g.out_bf16) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(g.C2) + crow + n, h);
+        else ld4<float>(reinterpret_cast<const float*>(g.C2) + crow + n, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(h[e]);
+      } else if (g.C2) {
         if (g.out_bf16) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C2) + crow + n, v);
         else st4<float>(reinterpret_cast<float*>(g.C2) + crow + n, v);
       }
@@ -783,6 +789,9 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
   if ((a->splitk > 1 && !a->partial) || (a->partial && a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
   if (a->rowsum_partial && (dtype != COUNTR_BF16 || !a->partial)) { countr_set_error("countr_gemm: rowsum_partial needs the bf16 split-K path"); return -1; }
+  if (a->act < COUNTR_ACT_NONE || a->act > COUNTR_ACT_GELU_BWD || (a->act == COUNTR_ACT_GELU_BWD && (!a->C2 || a->partial))) {
+    countr_set_error("countr_gemm: bad activation code (GELU_BWD needs the saved pre-activation in C2 and no split-K)"); return -1;
+  }
   const int epc = dtype == COUNTR_BF16 ? 8 : 4;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->N & 3)) { countr_set_error("countr_gemm: bad shape (need N % 4 == 0)"); return -1; }
   if ((modeA == COUNTR_OP_ROW || modeB == COUNTR_OP_ROW) && (a->K % epc)) { countr_set_error("countr_gemm: K must be a multiple of the 16-byte chunk"); return -1; }

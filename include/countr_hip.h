@@ -37,6 +37,8 @@ extern "C" {
 
 #define COUNTR_ACT_NONE 0
 #define COUNTR_ACT_GELU 1 /* exact erf GELU, nn.GELU default (models_crossvit.py:49,63) */
+#define COUNTR_ACT_GELU_BWD 2 /* out = acc * GELU'(C2): autograd of the line above fused into the fc2 dgrad GEMM; C2 is an
+                                 INPUT here (the saved pre-activation, same layout and dtype as C) */
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */

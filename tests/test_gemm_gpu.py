@@ -81,6 +81,36 @@ def test_gemm_epilogue(hip, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_gelu_backward_epilogue(hip, dt):
+    """fc2 dgrad fused with GELU': out = (dy @ W) * gelu'(pre), pre = the saved pre-activation read through C2 (ROW x COL)."""
+    M, N, K = 1000, 512, 128          # dy [M, K] (K = fc2 out features), W [K, N] (N = hidden), out/pre [M, N]
+    dy = _mk((M, K), dt, 13)
+    W = _mk((K, N), dt, 14)
+    pre = (_mk((M, N), torch.float32, 15) * 3).to(dt)
+    out = torch.empty((M, N), device="cuda", dtype=dt)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C, a.C2 = dy.data_ptr(), W.data_ptr(), out.data_ptr(), pre.data_ptr()
+    a.lda, a.ldb, a.ldc = K, N, N
+    a.M, a.N, a.K = M, N, K
+    a.act = _lib.ACT_GELU_BWD
+    a.out_bf16 = int(dt == torch.bfloat16)
+    a.alpha = 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    keep = pre.clone()
+    _lib.check(hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 0, 1, _stream()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(pre, keep)                      # C2 is an input in this mode
+    x = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(dy.double() @ W.double())
+    tol = 2e-2 if dt == torch.bfloat16 else 1e-4
+    assert (out.double() - x.grad).abs().max().item() <= tol * x.grad.abs().max().item()
+    a.C2 = None                                         # the mode requires the saved pre-activation
+    assert hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 0, 1, _stream()) != 0
+    a.act = 7
+    assert hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 0, 1, _stream()) != 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_batched_and_splitk(hip, dt):
     # batched: q k^T per (b, h) read straight out of a packed qkv [B, N, 3, H, dh]
     Bsz, Ntok, H, dh = 2, 576, 3, 64
