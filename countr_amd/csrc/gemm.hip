@@ -728,7 +728,10 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       // measured (tools/bench_gemm.py, COUNTR_GEMM_TILE=22|24|42|44): 256-wide tiles lose to 128x128 with this loop
       // structure (8-wave variants drop to one workgroup per CU, the 16-wave 256x256 one spills), so 22 stays the default
       (void)t256; (void)t128x256;
-      if (!tile) tile = 22;
+      // ... except on very large grids (the 192x192 density-head convolutions, 4608 tiles): there the 8-wave 128x256 tile's
+      // halved operand traffic per MFMA is worth +7 % (420 vs 450 us); at <= ~1000 tiles it loses to the tail.
+      static const int big = [] { const char* e = getenv("COUNTR_GEMM_BIGTILE"); return e ? atoi(e) : 4096; }();
+      if (!tile) tile = (t128 >= big && a.N >= 256) ? 24 : 22;
       if (tile == 44) return launch_variant<T, MA, MB, 2, 4, 4>(a, s);
       if (tile == 24) return launch_variant<T, MA, MB, 2, 2, 4>(a, s);
       if (tile == 42) return launch_variant<T, MA, MB, 2, 4, 2>(a, s);
