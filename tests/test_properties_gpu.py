@@ -1,0 +1,121 @@
+"""GPU: size-independent properties of the hot path at BASELINE.json's full size (ViT-B/16, batch 8, 384x384, 3 exemplars, bf16)
+where the CPU oracle would take minutes: per-sample independence, determinism, exact linearity of the backward pass in dL/dout,
+exemplar-order invariance, masking equivalence of the MAE encoder, and loss-mask semantics of the fused step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+MODEL = "mae_vit_base_patch16"
+
+
+@pytest.fixture(scope="module")
+def model():
+    import models_mae_cross as mm
+    m = mm.__dict__[MODEL](precision="bf16")
+    sd = W.make_state_dict(MODEL, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda")
+
+
+@pytest.fixture(scope="module")
+def batch8():
+    imgs, boxes, gt, mask = W.make_inputs(batch=8, shots=3, seed=5)
+    return tuple(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask))
+
+
+def test_samples_are_independent_and_runs_are_deterministic(model, batch8):
+    """IN / GN / LN statistics are per sample and every reduction is order-fixed: sample i of a batch of 8 equals the same
+    sample run alone, bit for bit, and repeating the batch reproduces it bit for bit (no atomics anywhere)."""
+    imgs, boxes, _, _ = batch8
+    model.eval()
+    with torch.no_grad():
+        full = model(imgs, boxes, 3).clone()
+        again = model(imgs, boxes, 3).clone()
+        assert torch.equal(full, again)
+        for i in (0, 5):
+            alone = model(imgs[i:i + 1], boxes[i:i + 1], 3)
+            assert torch.equal(alone[0] if alone.dim() == 3 else alone, full[i]), i
+        pair = model(imgs[2:4], boxes[2:4], 3)
+        assert torch.equal(pair, full[2:4])
+        assert full.shape == (8, 384, 384) and torch.isfinite(full).all()
+
+
+def test_backward_is_exactly_linear_in_dout_and_deterministic(model, batch8):
+    """Every backward kernel is linear in its incoming gradient and scaling by a power of two is exact in fp32 and bf16, so
+    grads(4 * dout) == 4 * grads(dout) bit for bit; two identical backward passes agree bit for bit."""
+    imgs, boxes, gt, mask = batch8
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    w = torch.rand(8, 384, 384, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) - 0.5
+
+    def grads(scale):
+        for p in model.parameters():
+            p.grad = None
+        out = model(imgs, boxes, 3)
+        (out * w).sum().mul(scale).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    g1, g1b, g4 = grads(1.0), grads(1.0), grads(4.0)
+    assert len(g1) == 74
+    for k in g1:
+        assert torch.equal(g1[k], g1b[k]), k
+        assert torch.equal(g4[k], 4 * g1[k]), k
+        assert torch.isfinite(g1[k]).all(), k
+
+
+def test_exemplar_order_does_not_matter(model, batch8):
+    """Cross-attention sums over the exemplar tokens (models_crossvit.py:121-125): permuting the 3 exemplars only changes
+    the summation order (bf16 mode tolerance 2e-2 of the map maximum, counts within 0.5 %)."""
+    imgs, boxes, _, _ = batch8
+    model.eval()
+    with torch.no_grad():
+        a = model(imgs, boxes, 3).clone()
+        b = model(imgs, boxes[:, [2, 0, 1]].contiguous(), 3)
+    assert (a - b).abs().max().item() <= 2e-2 * a.abs().max().item()
+    ca, cb = a.sum((1, 2)) / 60, b.sum((1, 2)) / 60
+    assert ((ca - cb).abs() <= 5e-3 * ca.abs() + 0.05).all()
+
+
+def test_fused_step_loss_mask_semantics(model, batch8):
+    """FSC_finetune_cross.py:290-296: masked-out pixels contribute nothing -- changing the ground truth only where the mask is 0
+    leaves the loss and every gradient bit-identical; the reported counts are sum/60 of prediction and ground truth."""
+    from countr_amd.trainer import FinetuneStep
+    imgs, boxes, gt, mask = batch8
+    model.train()
+    step = FinetuneStep(model, batch=8, lr=0.0, weight_decay=0.0, use_graph=False)   # lr 0: parameters stay put
+    step.load(imgs, boxes, gt, mask, 3)
+    s1 = step.step(3).clone()
+    g1 = step.eng.G.clone()
+    gt2 = gt + (1 - mask) * 7.5
+    step.load(imgs, boxes, gt2, mask, 3)
+    s2 = step.step(3).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(s1[0], s2[0]) and torch.equal(g1, step.eng.G)
+    assert torch.allclose(s1[9:17], gt.sum((1, 2)) / 60, rtol=1e-5)
+    assert torch.allclose(s2[9:17], gt2.sum((1, 2)) / 60, rtol=1e-5)
+    assert torch.equal(s1[1:9], s2[1:9])
+
+
+def test_mae_encoder_sees_only_kept_patches_and_masked_pixels_do_not_leak():
+    """models_mae_noct.py:110-157: the encoder input is the gather of the kept patches, so changing pixels inside MASKED patches
+    must leave the latent bit-identical (full-size ViT-B, batch 8, bf16); the all-patch loss does change."""
+    import models_mae_noct as mn
+    m = mn.mae_vit_base_patch16(precision="bf16")
+    sd = W.make_state_dict_mae(seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to("cuda").eval()
+    imgs, ids_shuffle, ids_restore, K = W.make_mae_inputs(batch=8, seed=7)
+    x, ids = torch.from_numpy(imgs).cuda(), torch.from_numpy(ids_shuffle).cuda()
+    with torch.no_grad():
+        lat1, mask, _ = m.forward_encoder(x, 0.5, ids_shuffle=ids)
+        l1, _, _ = m(x, mask_ratio=0.5, ids_shuffle=ids)
+        pm = mask.view(8, 24, 24).repeat_interleave(16, 1).repeat_interleave(16, 2).unsqueeze(1)   # 1 on masked pixels
+        x2 = x + pm * 0.25
+        lat2, mask2, _ = m.forward_encoder(x2, 0.5, ids_shuffle=ids)
+        l2, _, _ = m(x2, mask_ratio=0.5, ids_shuffle=ids)
+    assert torch.equal(mask, mask2) and mask.sum().item() == 8 * 288
+    assert torch.equal(lat1, lat2)
+    assert l1.item() != l2.item()
