@@ -166,3 +166,18 @@ def test_bf16_gradients_close_to_oracle(bf16_model):
         # exemplar-CNN gradients arrive through the (tiny) cross-attention k/v signal: measured 0.96-0.98
         assert cos > (0.94 if k.startswith("decoder_proj") else 0.98), (k, cos.item())
         assert abs(got.norm() - ref.norm()) / ref.norm() < 0.1, k
+
+
+@pytest.mark.parametrize("name,tol", [("mae_vit_large_patch16", 1e-3), ("mae_vit_base6_patch16", 1e-3)])
+def test_other_factories_fp32_match_oracle(name, tol):
+    """The other reference factories (models_mae_cross.py:215-253): ViT-L/16 encoder (D = 1024, 24 blocks, 16 heads) and the
+    6-block decoder variant, fp32 parity mode vs the CPU oracle on one image; same bar as the headline model."""
+    m, sd = build("fp32", seed=4, model=name)
+    imgs, boxes, gt, mask = W.make_inputs(batch=1, shots=3, seed=11)
+    with torch.no_grad():
+        out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3)
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    ref = R.forward(sd, imgs, boxes, 3, name).numpy()
+    got = out.cpu().numpy().reshape(ref.shape)
+    assert rel(got, ref) <= tol
+    assert abs(got.sum() / 60 - ref.sum() / 60) < 0.5
