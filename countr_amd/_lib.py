@@ -93,6 +93,7 @@ _SIGS = {
     "countr_gather_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "countr_patch_mse_workspace_floats": [_i, _i, _i, _i],
     "countr_patch_mse": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_conv_shadows": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "countr_masked_mse_workspace_floats": [_i],
     "countr_masked_mse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "countr_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp, _vp],

@@ -285,6 +285,34 @@ __global__ void cast_permute_kernel(const float* __restrict__ src, T* __restrict
   }
 }
 
+// all conv-weight shadows of the model in ONE launch: blockIdx.y = convolution, both permuted forms per element
+struct ConvShadowTable {
+  int n;
+  const float* src[8];
+  void* wf[8];
+  void* wd[8];
+  int co[8], ci[8], taps[8];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void conv_shadows_kernel(const ConvShadowTable t) {
+  const int e = blockIdx.y;
+  const int Co = t.co[e], Ci = t.ci[e], taps = t.taps[e];
+  const float* __restrict__ src = t.src[e];
+  T* __restrict__ wf = reinterpret_cast<T*>(t.wf[e]);
+  T* __restrict__ wd = reinterpret_cast<T*>(t.wd[e]);
+  const int64_t n = (int64_t)Co * Ci * taps;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    {  // OHWI [Co][tap][Ci]
+      const int ci = (int)(i % Ci); const int tap = (int)((i / Ci) % taps); const int co = (int)(i / ((int64_t)Ci * taps));
+      stf<T>(wf + i, src[((int64_t)co * Ci + ci) * taps + tap]);
+    }
+    {  // dgrad form [Ci][tap'][Co]
+      const int co = (int)(i % Co); const int tap = (int)((i / Co) % taps); const int ci = (int)(i / ((int64_t)Co * taps));
+      stf<T>(wd + i, src[((int64_t)co * Ci + ci) * taps + (taps - 1 - tap)]);
+    }
+  }
+}
+
 // ---------------- masked MSE loss + its gradient + counts (FSC_finetune_cross.py:290-303)
 // loss = sum((pred-gt)^2 * mask / HW) / B ; dpred = 2 (pred-gt) mask / (HW * B) * grad_scale
 // sums[0] = loss, sums[1 + b] = sum(pred[b]) / 60, sums[1 + B + b] = sum(gt[b]) / 60
@@ -440,6 +468,24 @@ extern "C" int countr_cast_permute(const float* src, void* dst, int64_t n, int m
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(cast_permute_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), src, (bf16_t*)dst, n, mode, Co, Ci, taps);
   else hipLaunchKernelGGL(cast_permute_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), src, (float*)dst, n, mode, Co, Ci, taps);
   COUNTR_LAUNCH_CHECK("countr_cast_permute");
+}
+
+extern "C" int countr_conv_shadows(int n, const float* const* src, void* const* wf, void* const* wd, const int* co, const int* ci,
+                                   const int* taps, int dtype, void* stream) {
+  if (n < 1 || n > 8 || !src || !wf || !wd || !co || !ci || !taps) { countr_set_error("countr_conv_shadows: 1..8 convolutions"); return -1; }
+  ConvShadowTable t;
+  t.n = n;
+  int64_t big = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || !wf[i] || !wd[i]) { countr_set_error("countr_conv_shadows: null"); return -1; }
+    t.src[i] = src[i]; t.wf[i] = wf[i]; t.wd[i] = wd[i]; t.co[i] = co[i]; t.ci[i] = ci[i]; t.taps[i] = taps[i];
+    const int64_t m = (int64_t)co[i] * ci[i] * taps[i];
+    if (m > big) big = m;
+  }
+  dim3 grid(nblocks(big, 256, 512), n);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv_shadows_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), t);
+  else hipLaunchKernelGGL(conv_shadows_kernel<float>, grid, dim3(256), 0, STREAM(stream), t);
+  COUNTR_LAUNCH_CHECK("countr_conv_shadows");
 }
 
 extern "C" int countr_masked_mse_workspace_floats(int B) { return B * MSE_BLOCKS * 3; }

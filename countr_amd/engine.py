@@ -191,11 +191,7 @@ class Engine:
             lo = lay.train_start if trainable_only else 0
             _lib.check(L.countr_cast_permute(self.P.data_ptr() + 4 * lo, self.Wt.data_ptr() + 2 * lo, lay.total - lo, 0, 0, 0, 0,
                                              BF16, st), "cast")
-        for n in self.conv_names:
-            co, ci, kh, kw = lay.shapes[n]
-            numel = co * ci * kh * kw
-            _lib.check(L.countr_cast_permute(self._pp(n), self.Wf[n].data_ptr(), numel, 1, co, ci, kh * kw, self.code, st), "perm")
-            _lib.check(L.countr_cast_permute(self._pp(n), self.Wd[n].data_ptr(), numel, 2, co, ci, kh * kw, self.code, st), "perm")
+        self._refresh_conv_shadows()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -768,10 +764,16 @@ class Engine:
         self.adamw_launch(S, weight_decay, betas, eps, lr=lr, step=self.step_count, grad_scale=grad_scale)
 
     def _refresh_conv_shadows(self):
-        st = self._stream()
-        lay = self.layout
-        for n in self.conv_names:
-            co, ci, kh, kw = lay.shapes[n]
-            numel = co * ci * kh * kw
-            _lib.check(self.L.countr_cast_permute(self._pp(n), self.Wf[n].data_ptr(), numel, 1, co, ci, kh * kw, self.code, st), "perm")
-            _lib.check(self.L.countr_cast_permute(self._pp(n), self.Wd[n].data_ptr(), numel, 2, co, ci, kh * kw, self.code, st), "perm")
+        """OHWI + dgrad-form shadows of every conv weight, one launch (the table of pointers is built once)."""
+        if not self.conv_names:
+            return
+        if getattr(self, "_shadow_tab", None) is None:
+            n = len(self.conv_names)
+            shp = [self.layout.shapes[c] for c in self.conv_names]
+            self._shadow_tab = (n, (C.c_void_p * n)(*[self._pp(c) for c in self.conv_names]),
+                                (C.c_void_p * n)(*[self.Wf[c].data_ptr() for c in self.conv_names]),
+                                (C.c_void_p * n)(*[self.Wd[c].data_ptr() for c in self.conv_names]),
+                                (C.c_int * n)(*[s_[0] for s_ in shp]), (C.c_int * n)(*[s_[1] for s_ in shp]),
+                                (C.c_int * n)(*[s_[2] * s_[3] for s_ in shp]))
+        n, src, wf, wd, co, ci, taps = self._shadow_tab
+        _lib.check(self.L.countr_conv_shadows(n, src, wf, wd, co, ci, taps, self.code, self._stream()), "conv_shadows")
