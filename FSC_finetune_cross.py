@@ -4,8 +4,10 @@
 The hot loop (:265-319) is the fused FinetuneStep: forward + masked-MSE + decoder backward + RCCL gradient all-reduce +
 AdamW, graph-captured, bf16 (no GradScaler), LR schedule per iteration as util/lr_sched.py.  Launch one process per GPU
 with `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 FSC_finetune_cross.py ...`.
-The FSC147 augmentation pipeline (util/FSC147.py: imgaug/cv2/torchvision, none available offline) is out of scope
-(SURVEY.md section 2.1); `--synthetic_steps K` trains on synthetic FSC147-shaped batches (K iterations per epoch)."""
+Data: with the FSC147 files present (--data_path/--anno_file/--data_split_file/--im_dir) batches come from
+countr_amd/data/fsc147.py (PIL/scipy restatement of the reference's non-augmented train transform; the imgaug/cv2 augmentation
+pipeline of util/FSC147.py is out of scope); `--synthetic_steps K` trains on synthetic FSC147-shaped batches instead (K
+iterations per epoch) and is the automatic fallback when the dataset is absent."""
 import argparse
 import json
 import time
@@ -61,7 +63,8 @@ def get_args_parser():
     p.add_argument("--wandb_id", default=None, type=str)
     # additions
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    p.add_argument("--synthetic_steps", default=50, type=int, help="iterations per epoch on synthetic batches")
+    p.add_argument("--synthetic_steps", default=0, type=int,
+                   help="K > 0: K iterations per epoch on synthetic batches; 0: FSC147 from --data_path (synthetic, 50 it/epoch, if absent)")
     p.add_argument("--log_every", default=50, type=int, help="iterations between loss reports (each report is a host sync)")
     return p
 
@@ -84,14 +87,35 @@ def main(args):
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95))
     if ckpt is not None and args.do_resume and "epoch" in ckpt:
         args.start_epoch = ckpt["epoch"] + 1
-    n_iter = args.synthetic_steps
+    from countr_amd.data import fsc147
+    loader = None
+    if args.synthetic_steps <= 0 and fsc147.available(args):
+        ds = fsc147.TrainData(args, split="train", do_aug=args.do_aug)
+        sampler = torch.utils.data.DistributedSampler(ds, num_replicas=misc.get_world_size(), rank=misc.get_rank(), shuffle=True)
+        loader = torch.utils.data.DataLoader(ds, sampler=sampler, batch_size=args.batch_size, num_workers=args.num_workers,
+                                             pin_memory=args.pin_mem, drop_last=True)   # drop_last: the fused step has a static batch
+        n_iter = len(loader)
+    else:
+        if args.synthetic_steps <= 0:
+            print("FSC147 not found under %s: training on synthetic batches" % args.data_path)
+        n_iter = args.synthetic_steps if args.synthetic_steps > 0 else 50
+    loss_mask_gen = torch.Generator(device=device).manual_seed(seed)
     t_start = time.time()
     for epoch in range(args.start_epoch, args.epochs):
         mae = rmse = 0.0
+        if loader is not None:
+            loader.sampler.set_epoch(epoch)                                             # :260-261
+        it_data = iter(loader) if loader is not None else None
         for it in range(n_iter):
             lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)        # :271
             S = shared_shot_num(epoch * n_iter + it, seed=args.seed)                   # :278-284 (shared across ranks)
-            imgs, boxes, gt, mask = make_batch(args.batch_size, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
+            if it_data is not None:
+                imgs, gt, _n, boxes, _pos, _m, _ids = next(it_data)
+                # loss mask: Bernoulli(0.8) per pixel, one mask per batch (FSC_finetune_cross.py:290-292)
+                mask = (torch.rand(384, 384, device=device, generator=loss_mask_gen) < 0.8).float()
+                imgs, gt, boxes = (t.to(device, non_blocking=True) for t in (imgs, gt, boxes))
+            else:
+                imgs, boxes, gt, mask = make_batch(args.batch_size, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
             step.load(imgs, boxes, gt, mask, S)
             sums = step.step(S, lr=lr)
             if (it + 1) % args.log_every == 0 or it + 1 == n_iter:

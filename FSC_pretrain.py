@@ -4,8 +4,9 @@
 The hot loop (:254-310) is the fused PretrainStep: random masking + forward + all-patch pixel MSE + full backward + RCCL
 gradient all-reduce + AdamW, graph-captured, bf16 (no GradScaler), LR schedule per iteration as util/lr_sched.py.
 Launch one process per GPU: `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 FSC_pretrain.py ...`.
-The FSC147 image pipeline (util/FSC147.py + TransformPreTrain, imgaug/cv2/torchvision: none available offline) is out of
-scope; `--synthetic_steps K` trains on synthetic 384x384 images (K iterations per epoch).  TensorBoard / W&B logging is
+Data: with the FSC147 files present images come from countr_amd/data/fsc147.py (PIL restatement of ResizePreTrainImage +
+RandomResizedCrop/flip, util/FSC147.py:58-83,369-374); `--synthetic_steps K` trains on synthetic 384x384 images instead (K
+iterations per epoch) and is the automatic fallback when the dataset is absent.  TensorBoard / W&B logging is
 replaced by JSON lines on stdout and log.txt."""
 import argparse
 import json
@@ -58,7 +59,8 @@ def get_args_parser():
     p.add_argument("--wandb_id", default=None, type=str)
     # additions
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    p.add_argument("--synthetic_steps", default=50, type=int, help="iterations per epoch on synthetic images")
+    p.add_argument("--synthetic_steps", default=0, type=int,
+                   help="K > 0: K iterations per epoch on synthetic images; 0: FSC147 from --data_path (synthetic, 50 it/epoch, if absent)")
     p.add_argument("--log_every", default=20, type=int, help="iterations between loss reports (each report is a host sync)")
     return p
 
@@ -87,15 +89,32 @@ def main(args):
         step.eng.step_count = int(opt["step"])
         args.start_epoch = ckpt["epoch"] + 1
         print("With optim & sched!")
-    n_iter = args.synthetic_steps
+    from countr_amd.data import fsc147
+    loader = None
+    if args.synthetic_steps <= 0 and fsc147.available(args):
+        ds = fsc147.PretrainData(args)
+        sampler = torch.utils.data.DistributedSampler(ds, num_replicas=misc.get_world_size(), rank=misc.get_rank(), shuffle=True)
+        loader = torch.utils.data.DataLoader(ds, sampler=sampler, batch_size=args.batch_size, num_workers=args.num_workers,
+                                             pin_memory=args.pin_mem, drop_last=True)   # drop_last: the fused step has a static batch
+        n_iter = len(loader)
+    else:
+        if args.synthetic_steps <= 0:
+            print("FSC147 not found under %s: training on synthetic images" % args.data_path)
+        n_iter = args.synthetic_steps if args.synthetic_steps > 0 else 50
     g = torch.Generator(device=device).manual_seed(seed)
     t_start = time.time()
     for epoch in range(args.start_epoch, args.epochs):
         losses = []
         lr = args.lr
+        if loader is not None:
+            loader.sampler.set_epoch(epoch)                                             # :236-237
+        it_data = iter(loader) if loader is not None else None
         for it in range(n_iter):
             lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)        # :258-259
-            imgs = torch.rand(args.batch_size, 3, 384, 384, device=device, generator=g)
+            if it_data is not None:
+                imgs = next(it_data).to(device, non_blocking=True)
+            else:
+                imgs = torch.rand(args.batch_size, 3, 384, 384, device=device, generator=g)
             step.load(imgs)
             loss = step.step(lr=lr)
             if (it + 1) % args.log_every == 0 or it + 1 == n_iter:

@@ -1,0 +1,73 @@
+"""GPU: the three drop-in CLIs end to end (FSC_finetune_cross.py, FSC_pretrain.py, FSC_test_cross.py) on a tiny on-disk
+FSC147-shaped dataset (PIL/scipy loaders -> fused steps -> checkpoint -> test CLI reading that checkpoint) and on the synthetic
+fallback.  Subprocesses, as a user would run them."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, cwd=ROOT):
+    r = subprocess.run([sys.executable] + cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.fixture(scope="module")
+def fake_fsc(tmp_path_factory):
+    from PIL import Image
+    root = tmp_path_factory.mktemp("fsc")
+    (root / "images_384_VarV2").mkdir()
+    rs = np.random.RandomState(0)
+    anno, names = {}, []
+    for k, (w, h) in enumerate([(640, 384), (512, 384), (700, 400), (900, 384)]):
+        name = "%d.jpg" % k
+        Image.fromarray(rs.randint(0, 255, size=(h, w, 3)).astype(np.uint8)).save(root / "images_384_VarV2" / name)
+        pts = np.stack([rs.uniform(5, w - 5, 12), rs.uniform(5, h - 5, 12)], 1).tolist()
+        boxes = []
+        for b in range(3):
+            x1, y1 = int(rs.uniform(0, w - 80)), int(rs.uniform(0, h - 80))
+            boxes.append([[x1, y1], [x1, y1 + 40], [x1 + 50, y1 + 40], [x1 + 50, y1]])
+        anno[name] = {"points": pts, "box_examples_coordinates": boxes}
+        names.append(name)
+    json.dump(anno, open(root / "annotation_FSC147_384.json", "w"))
+    json.dump({"train": names, "val": names[:2], "test": names[2:]}, open(root / "Train_Test_Val_FSC_147.json", "w"))
+    return str(root)
+
+
+def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
+    out = str(tmp_path / "ft")
+    log = run(["FSC_finetune_cross.py", "--data_path", fake_fsc, "--batch_size", "2", "--epochs", "1", "--warmup_epochs", "0",
+               "--num_workers", "0", "--no_do_aug", "--output_dir", out, "--resume", "", "--log_every", "1", "--blr", "1e-3"])
+    lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(np.isfinite(l["loss"]) for l in lines)          # 4 images / batch 2, drop_last
+    ckpt = os.path.join(out, "checkpoint__finetuning_last.pth")
+    assert os.path.exists(ckpt)
+    log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "test", "--box_bound", "3"])
+    res = json.loads([l for l in log.splitlines() if l.startswith("{")][-1])
+    assert res["images"] == 2 and np.isfinite(res["MAE"]) and np.isfinite(res["RMSE"])
+    # zero-shot path of the same CLI
+    log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "val", "--box_bound", "0"])
+    assert json.loads([l for l in log.splitlines() if l.startswith("{")][-1])["images"] == 2
+
+
+def test_pretrain_cli_on_files_and_synthetic_fallback(fake_fsc, tmp_path):
+    out = str(tmp_path / "pre")
+    log = run(["FSC_pretrain.py", "--data_path", fake_fsc, "--batch_size", "2", "--epochs", "1", "--warmup_epochs", "0",
+               "--num_workers", "0", "--output_dir", out, "--resume", "", "--log_every", "1"])
+    lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(np.isfinite(l["loss"]) and l["loss"] > 0 for l in lines)
+    assert os.path.exists(os.path.join(out, "checkpoint__pretraining_0.pth")) and os.path.exists(os.path.join(out, "log.txt"))
+    # resume from our own checkpoint (flat AdamW state restored), synthetic images
+    log = run(["FSC_pretrain.py", "--data_path", "/nonexistent", "--batch_size", "2", "--epochs", "2", "--warmup_epochs", "0",
+               "--synthetic_steps", "2", "--output_dir", out, "--resume", os.path.join(out, "checkpoint__pretraining_0.pth"),
+               "--log_every", "1"])
+    assert "With optim & sched!" in log
+    lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
+    assert [l["epoch"] for l in lines] == [1, 1]
