@@ -6,6 +6,7 @@
 //   fp32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain) for the parity mode
 // Reference call sites: models_crossvit.py:62,65,84-92,115-127; models_mae_cross.py:47-100,138,152.
 #include "common.cuh"
+#include <type_traits>
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 
@@ -382,9 +383,12 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
   }
 }
 
-template <typename T, int MA, int MB, int STAGES, int WM, int WN>
+// TMW = 16-row MFMA tiles per wave along M (4: 64x64 wave tile, 8: 128x64 wave tile -> half the staged bytes and 25 % fewer
+// fragment reads per MFMA; used for the 256x256 workgroup tile).
+template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
-  constexpr int BMt = 64 * WM, BNt = 64 * WN, NW = WM * WN;
+  static_assert(TMW == 4 || TMW == 8, "wave tile is 64x64 or 128x64");
+  constexpr int BMt = 16 * TMW * WM, BNt = 64 * WN, NW = WM * WN;
   constexpr int SA = BMt * 128, SB = BNt * 128;  // bf16 stage bytes per operand
   constexpr int BK = Cfg<T>::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -424,13 +428,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
   OpDesc dA{reinterpret_cast<const char*>(g.A) + offA * (int64_t)sizeof(T), g.lda, g.M, g.H, g.W, g.Cin};
   OpDesc dB{reinterpret_cast<const char*>(g.B) + offB * (int64_t)sizeof(T), g.ldb, g.N, g.H, g.W, g.Cin};
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[TMW][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TMW; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+  const int wm0 = (wave / WN) * (16 * TMW), wn0 = (wave % WN) * 64;
   const int li = lane & 15;
   // N-side row permutation: MFMA output row i of tile tn is column wn0 + (i>>2)*16 + tn*4 + (i&3),
   // so that a lane ends up holding 16 consecutive output columns (vector stores in the epilogue).
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
   // M-side: row-like bf16 operands use the same permuted row order as the N side (conflict-free swizzle, see swz_row);
   // the lane's output row for tile tm follows.  K-strided / fp32 operands keep consecutive rows.
   constexpr bool MPERM = (sizeof(T) == 2) && is_rowlike(MA);
-  auto mrow = [&](int tm) { return MPERM ? (wm0 + (li >> 2) * 16 + tm * 4 + (li & 3)) : (wm0 + tm * 16 + li); };
+  auto mrow = [&](int tm) { return MPERM ? (wm0 + (tm >> 2) * 64 + (li >> 2) * 16 + (tm & 3) * 4 + (li & 3)) : (wm0 + tm * 16 + li); };
   const int ntiles = (kend > kstart) ? (kend - kstart + BK - 1) / BK : 0;
 
   if constexpr (sizeof(T) == 2) {
@@ -468,54 +472,66 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
 #endif
     // optional fused bias gradient: sum_k A(m, k), accumulated by the waves of the first N-tile column only
     const bool do_rowsum = g.rowsum_partial != nullptr && tile_n == 0 && (wave % WN) == 0;
-    f32x4_t accb[4];
+    f32x4_t accb[TMW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) accb[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int KREADS = 4 * FragReads<MA>::N + 4 * FragReads<MB>::N;   // LDS reads per 32-wide k-step
-    constexpr int KPEND = KREADS > 15 ? 15 : KREADS;                      // lgkmcnt is a 4-bit counter
+    for (int q = 0; q < TMW; ++q) accb[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // One k-tile = NS steps of 16 MFMAs: step s covers k-step kk = s / NH (32 of the 64 staged k) and the 64-row half
+    // h = s % NH of the wave tile.  Step s+1's fragments are requested before step s's MFMAs are issued (the W fragments
+    // of a k-step are shared by its halves), so LDS round trips hide under the matrix pipe.
+    constexpr int NH = TMW / 4, NS = 2 * NH;
+    constexpr int XR = 4 * FragReads<MA>::N, WR = 4 * FragReads<MB>::N;   // LDS instructions per step for x / w fragments
     auto mma_tile = [&](const char* sa_, const char* sb_) {
       const uint32_t sa = lds_addr(sa_), sb = lds_addr(sb_);
       bf16x8_t xf[2][4], wf[2][4];
+      auto request = [&](auto S) {
+        constexpr int s = decltype(S)::value, kk = s / NH, h = s % NH;
 #if COUNTR_ABL == 2
-      for (int kk = 0; kk < 2; ++kk)
-        for (int q = 0; q < 4; ++q) { xf[kk][q] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, q, kk, 1)); wf[kk][q] = xf[kk][q]; }
+        for (int q = 0; q < 4; ++q) { xf[s & 1][q] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, q, kk, 1)); if (h == 0) wf[kk][q] = xf[s & 1][q]; }
 #else
-      // both k-steps' fragments are requested up front; the MFMAs of step 0 run while step 1's reads are still in flight
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
-          xf[kk][tm] = frag_bf16<MA>(sa, mrow(tm), wm0 + tm * 16 + (li & 3) * 4, kk, lane);
+          xf[s & 1][tm] = frag_bf16<MA>(sa, mrow(h * 4 + tm), wm0 + (h * 4 + tm) * 16 + (li & 3) * 4, kk, lane);
+        if constexpr (h == 0) {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-          wf[kk][tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
-      }
+          for (int tn = 0; tn < 4; ++tn)
+            wf[kk][tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
+        }
 #endif
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      };
+      auto step = [&](auto S) {
+        constexpr int s = decltype(S)::value, kk = s / NH, h = s % NH;
+        if constexpr (s + 1 < NS) request(std::integral_constant<int, s + 1>{});
 #if COUNTR_ABL != 2
-        if (kk == 0) lds_wait<KPEND>(xf[0], wf[0]);
-        else lds_wait<0>(xf[1], wf[1]);
+        constexpr int nxt = (s + 1 < NS) ? XR + (((s + 1) % NH) == 0 ? WR : 0) : 0;   // reads allowed to stay in flight
+        lds_wait<(nxt > 15 ? 15 : nxt)>(xf[s & 1], wf[kk]);                            // lgkmcnt is a 4-bit counter
 #endif
 #if COUNTR_ABL == 1
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint4 a = __builtin_bit_cast(uint4, xf[kk][q]), b = __builtin_bit_cast(uint4, wf[kk][q]);
-          acc[q][0][0] += __uint_as_float(a.x ^ b.x); acc[q][1][1] += __uint_as_float(a.y ^ b.y);
-          acc[q][2][2] += __uint_as_float(a.z ^ b.z); acc[q][3][3] += __uint_as_float(a.w ^ b.w);
+          const uint4 a = __builtin_bit_cast(uint4, xf[s & 1][q]), b = __builtin_bit_cast(uint4, wf[kk][q]);
+          acc[h * 4 + q][0][0] += __uint_as_float(a.x ^ b.x); acc[h * 4 + q][1][1] += __uint_as_float(a.y ^ b.y);
+          acc[h * 4 + q][2][2] += __uint_as_float(a.z ^ b.z); acc[h * 4 + q][3][3] += __uint_as_float(a.w ^ b.w);
         }
 #else
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][tn], xf[kk][tm], acc[tm][tn], 0, 0, 0);
+            acc[h * 4 + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][tn], xf[s & 1][tm], acc[h * 4 + tm][tn], 0, 0, 0);
 #endif
         if (do_rowsum) {  // wave-uniform: row sums of the M-side operand = bias gradient of a wgrad GEMM
           const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[kk][tm], accb[tm], 0, 0, 0);
+          for (int tm = 0; tm < 4; ++tm)
+            accb[h * 4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[s & 1][tm], accb[h * 4 + tm], 0, 0, 0);
         }
+      };
+      request(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      if constexpr (NS > 2) {
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
       }
     };
     if constexpr (STAGES == 1) {
@@ -577,14 +593,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
     }
     if (do_rowsum && (lane >> 4) == 0) {
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
+      for (int tm = 0; tm < TMW; ++tm) {
         const int m = m0 + mrow(tm);
         if (m < g.M) g.rowsum_partial[(int64_t)blockIdx.z * g.M + m] = accb[tm][0];
       }
     }
   } else {
     // ---------------- fp32 parity path: register-staged, padded tiles (2x2 waves only)
-    static_assert(sizeof(T) == 2 || (WM == 2 && WN == 2), "fp32 path is 128x128 only");
+    static_assert(sizeof(T) == 2 || (WM == 2 && WN == 2 && TMW == 4), "fp32 path is 128x128 only");
     Loader<T, MA> la;
     Loader<T, MB> lb;
     la.init(dA, m0, kstart, tid);
@@ -636,7 +652,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
   const int gq = lane >> 4;
   const int nb = n0 + wn0 + gq * 16;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
+  for (int tm = 0; tm < TMW; ++tm) {
     const int m = m0 + mrow(tm);
     if (m >= g.M) continue;
     if (split) {
@@ -691,22 +707,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
   }
 }
 
-template <typename T, int MA, int MB, int STAGES, int WM, int WN>
+template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4>
 int launch_variant(const countr_gemm_args& a, hipStream_t s) {
-  constexpr int BMt = 64 * WM, BNt = 64 * WN;
+  constexpr int BMt = 16 * TMW * WM, BNt = 64 * WN;
   constexpr int lds_bytes = sizeof(T) == 2 ? STAGES * (BMt + BNt) * 128 : 4 * OP_BYTES;
   const int tilesM = (a.M + BMt - 1) / BMt, tilesN = (a.N + BNt - 1) / BNt;
   const int zdim = a.partial ? (a.splitk > 1 ? a.splitk : 1) : (a.nbatch > 1 ? a.nbatch : 1);
   dim3 grid(tilesM * tilesN, 1, zdim);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
   static const int skew = [] { const char* e = getenv("COUNTR_GEMM_SKEW"); return e ? atoi(e) : 0; }();
   static const int korder = [] { const char* e = getenv("COUNTR_CONV_KORDER"); return e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN>), grid, dim3(64 * WM * WN), lds_bytes, s, a, skew, korder);
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW>), grid, dim3(64 * WM * WN), lds_bytes, s, a, skew, korder);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
@@ -732,6 +748,7 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       // halved operand traffic per MFMA is worth +7 % (420 vs 450 us); at <= ~1000 tiles it loses to the tail.
       static const int big = [] { const char* e = getenv("COUNTR_GEMM_BIGTILE"); return e ? atoi(e) : 4096; }();
       if (!tile) tile = (t128 >= big && a.N >= 256) ? 24 : 22;
+      if (tile == 88) return launch_variant<T, MA, MB, 2, 2, 4, 8>(a, s);   // 256x256, 8 waves x (128x64)
       if (tile == 44) return launch_variant<T, MA, MB, 2, 4, 4>(a, s);
       if (tile == 24) return launch_variant<T, MA, MB, 2, 2, 4>(a, s);
       if (tile == 42) return launch_variant<T, MA, MB, 2, 4, 2>(a, s);
