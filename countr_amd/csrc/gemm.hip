@@ -206,22 +206,39 @@ template <int MODE, int ROWS, int NW> struct DmaLoader;
 
 template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_ROW, ROWS, NW> {
   static constexpr int PASSES = ROWS / (8 * NW);
+  static constexpr bool HAS_FAST = true;
   const char* rp[PASSES];
   int kc[PASSES];  // swizzled k-chunk (elements)
+  uint32_t voff[PASSES];   // fast path: byte offset of this lane's chunk from the operand base (row clamped into the matrix)
+  const char* ubase;
   __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
+    ubase = d.ptr;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
       const int rl = (i * NW + wave) * 8 + (lane >> 3);
       kc[i] = ((lane & 7) ^ swz_row(rl)) * 8;
       const int r = row0 + rl;
       rp[i] = (r < d.rows) ? d.ptr + (int64_t)r * d.ld * 2 : nullptr;
+      voff[i] = (uint32_t)(((int64_t)min(r, d.rows - 1) * d.ld + kc[i]) * 2);
     }
+  }
+  // Fast path (full k-tiles, operand < 4 GiB): the per-tile address is a UNIFORM base (SGPR pair, advanced with scalar adds)
+  // plus a loop-invariant 32-bit lane offset -> no per-piece vector address arithmetic or bounds selects in the loop.  Rows
+  // past the matrix are clamped to its last row: they only feed output rows / columns that the epilogue never stores.
+  __device__ __forceinline__ void issue_fast(int k0, char* lds, int wave) {
+    const char* ub = ubase + (int64_t)k0 * 2;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) dma16(ub + voff[i], lds + (i * NW + wave) * 1024);
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
+#if defined(COUNTR_ABL) && COUNTR_ABL == 4   // timing experiment: no per-tile address arithmetic (always the first k-tile)
+      const void* src = (const void*)rp[i];
+#else
       const int k = k0 + kc[i];
       const void* src = ((k + 8) <= kend && rp[i]) ? (const void*)(rp[i] + (int64_t)k * 2) : (const void*)g_zero_page;
+#endif
       dma16(src, lds + (i * NW + wave) * 1024);
     }
   }
@@ -230,17 +247,27 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_ROW, ROWS, NW> {
 template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_COL, ROWS, NW> {
   static_assert(ROWS == 128, "K-strided operands are only staged as 128-row tiles");
   static constexpr int PASSES = 16 / NW;
+  static constexpr bool HAS_FAST = true;
   const char* base[PASSES];
   int krow[PASSES];
   int64_t ldb;
+  uint32_t voff[PASSES];
+  const char* ubase;
   __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ldb = d.ld * 2;
+    ubase = d.ptr;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
       krow[i] = (i * NW + wave) * 4 + (lane >> 4);
       const int r0 = row0 + ((lane & 15) ^ swz_col(krow[i])) * 8;
       base[i] = (r0 + 8 <= d.rows) ? d.ptr + (int64_t)r0 * 2 : nullptr;
+      voff[i] = (uint32_t)((int64_t)krow[i] * ldb + (int64_t)min(r0, d.rows - 8) * 2);
     }
+  }
+  __device__ __forceinline__ void issue_fast(int k0, char* lds, int wave) {   // see the row-like loader
+    const char* ub = ubase + (int64_t)k0 * ldb;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) dma16(ub + voff[i], lds + (i * NW + wave) * 1024);
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
 #pragma unroll
@@ -254,6 +281,8 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_COL, ROWS, NW> {
 
 template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2ROW, ROWS, NW> {
   static constexpr int PASSES = ROWS / (8 * NW);
+  static constexpr bool HAS_FAST = false;   // zero padding needs the per-lane zero-page select
+  __device__ __forceinline__ void issue_fast(int, char*, int) {}
   const char* ptr;
   int pix[PASSES], py[PASSES], px[PASSES], kc[PASSES];
   int H, W, C;
@@ -286,6 +315,8 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2ROW, ROWS, NW> {
 template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2COL, ROWS, NW> {
   static_assert(ROWS == 128, "K-strided operands are only staged as 128-row tiles");
   static constexpr int PASSES = 16 / NW;
+  static constexpr bool HAS_FAST = false;
+  __device__ __forceinline__ void issue_fast(int, char*, int) {}
   const char* ptr;
   int py[PASSES], px[PASSES], krow[PASSES], ci[PASSES], dy[PASSES], dx[PASSES];
   int H, W, C;
@@ -467,6 +498,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
     DmaLoader<MB, BNt, NW> lb;
     la.init(dA, m0, kstart, wv, lane);
     lb.init(dB, n0, kstart, wv, lane);
+    // uniform-base addressing when every k-tile of this launch is full and the operands span < 4 GiB (see DmaLoader); the
+    // whole main loop is instantiated twice so that the fast variant carries no per-lane pointer selects
+    const bool fullk = ((kend - kstart) % BK) == 0;
+    const bool okA = !decltype(la)::HAS_FAST || (((int64_t)g.M * dA.ld * 2 < (int64_t)0xffff0000ll) && (MA != COUNTR_OP_COL || (int64_t)g.K * dA.ld * 2 < (int64_t)0xffff0000ll));
+    const bool okB = !decltype(lb)::HAS_FAST || (((int64_t)g.N * dB.ld * 2 < (int64_t)0xffff0000ll) && (MB != COUNTR_OP_COL || (int64_t)g.K * dB.ld * 2 < (int64_t)0xffff0000ll));
+    const bool fast_addr = fullk && okA && okB && (decltype(la)::HAS_FAST || decltype(lb)::HAS_FAST);
 #ifndef COUNTR_ABL
 #define COUNTR_ABL 0   // ablation builds (tools/ablate_gemm.sh): 1 = no MFMA, 2 = no fragment reads, 3 = DMA only for tile 0
 #endif
@@ -534,12 +571,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
         step(std::integral_constant<int, 3>{});
       }
     };
+    auto main_loop = [&](auto FAST) {
+      constexpr bool fast = decltype(FAST)::value;
+      auto issueA = [&](int k0, char* lds) {
+        if constexpr (fast && decltype(la)::HAS_FAST) la.issue_fast(k0, lds, wv); else la.issue(k0, kend, lds, wv);
+      };
+      auto issueB = [&](int k0, char* lds) {
+        if constexpr (fast && decltype(lb)::HAS_FAST) lb.issue_fast(k0, lds, wv); else lb.issue(k0, kend, lds, wv);
+      };
     if constexpr (STAGES == 1) {
       // Single LDS stage (32 KB): up to 5 workgroups stay resident per CU and hide each other's DMA latency.
       // Chosen by the host for big grids (>= ~3 workgroups per CU), where it beats per-workgroup double buffering.
       for (int t = 0; t < ntiles; ++t) {
-        la.issue(ktile(t), kend, smem, wv);
-        lb.issue(ktile(t), kend, smem + SA, wv);
+        issueA(ktile(t), smem);
+        issueB(ktile(t), smem + SA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mma_tile(smem, smem + SA);
@@ -554,8 +599,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
 #pragma unroll
       for (int s = 0; s < STAGES - 1; ++s)
         if (s < ntiles) {
-          la.issue(ktile(s), kend, smem + s * (SA + SB), wv);
-          lb.issue(ktile(s), kend, smem + s * (SA + SB) + SA, wv);
+          issueA(ktile(s), smem + s * (SA + SB));
+          issueB(ktile(s), smem + s * (SA + SB) + SA);
         }
       int slot = 0, islot = STAGES - 1;
       for (int t = 0; t < ntiles; ++t) {
@@ -564,8 +609,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
         __builtin_amdgcn_s_barrier();   // tile t visible to all waves; every wave is done with the slot refilled below
         if (t + STAGES - 1 < ntiles) {
           char* nxt = smem + islot * (SA + SB);
-          la.issue(ktile(t + STAGES - 1), kend, nxt, wv);
-          lb.issue(ktile(t + STAGES - 1), kend, nxt + SA, wv);
+          issueA(ktile(t + STAGES - 1), nxt);
+          issueB(ktile(t + STAGES - 1), nxt + SA);
         }
         mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
         slot = (slot + 1 == STAGES) ? 0 : slot + 1;
@@ -574,8 +619,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
     } else {
       // Two stages (64 KB, 2 workgroups per CU): tile t+1 streams in while tile t is multiplied.
       if (ntiles > 0) {
-        la.issue(ktile(0), kend, smem, wv);
-        lb.issue(ktile(0), kend, smem + SA, wv);
+        issueA(ktile(0), smem);
+        issueB(ktile(0), smem + SA);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -583,14 +628,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
         const int cur = t & 1;
         if (t + 1 < ntiles && (COUNTR_ABL != 3)) {
           char* nxt = smem + (cur ^ 1) * (SA + SB);
-          la.issue(ktile(t + 1), kend, nxt, wv);
-          lb.issue(ktile(t + 1), kend, nxt + SA, wv);
+          issueA(ktile(t + 1), nxt);
+          issueB(ktile(t + 1), nxt + SA);
         }
         mma_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
     }
+    };
+    if (fast_addr) main_loop(std::true_type{}); else main_loop(std::false_type{});
     if (do_rowsum && (lane >> 4) == 0) {
 #pragma unroll
       for (int tm = 0; tm < TMW; ++tm) {
