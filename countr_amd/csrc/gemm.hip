@@ -281,11 +281,12 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_COL, ROWS, NW> {
 
 template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2ROW, ROWS, NW> {
   static constexpr int PASSES = ROWS / (8 * NW);
-  static constexpr bool HAS_FAST = false;   // zero padding needs the per-lane zero-page select
-  __device__ __forceinline__ void issue_fast(int, char*, int) {}
+  static constexpr bool HAS_FAST = true;
   const char* ptr;
   int pix[PASSES], py[PASSES], px[PASSES], kc[PASSES];
   int H, W, C;
+  int64_t voff[PASSES];     // fast path: byte offset of (pixel, k-chunk) from the tensor base
+  uint32_t vmask[PASSES];   // fast path: bit t set <=> tap t of this lane's pixel lies inside the image (zero padding otherwise)
   __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ptr = d.ptr; H = d.H; W = d.W; C = d.C;
 #pragma unroll
@@ -296,6 +297,28 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2ROW, ROWS, NW> {
       pix[i] = (m < d.rows) ? m : -1;
       px[i] = m % W;
       py[i] = (m / W) % H;
+      voff[i] = ((int64_t)m * C + kc[i]) * 2;
+      uint32_t vm = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = py[i] + t / 3 - 1, xx = px[i] + t % 3 - 1;
+        if (m < d.rows && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) vm |= 1u << t;
+      }
+      vmask[i] = vm;
+    }
+  }
+  // Fast path (full k-tiles): uniform base = tensor + tap shift + channel chunk (scalar arithmetic), loop-invariant lane offset,
+  // and one bit test per piece for the zero padding instead of recomputing the tap geometry per lane.
+  __device__ __forceinline__ void issue_fast(int k0, char* lds, int wave) {
+    const int tap = k0 / C;
+    const int cbase = k0 - tap * C;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const char* ub = ptr + ((int64_t)(dy * W + dx) * C + cbase) * 2;
+    const uint32_t bit = 1u << tap;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const void* src = (vmask[i] & bit) ? (const void*)(ub + voff[i]) : (const void*)g_zero_page;
+      dma16(src, lds + (i * NW + wave) * 1024);
     }
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {
