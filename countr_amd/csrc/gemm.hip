@@ -7,6 +7,7 @@
 // Reference call sites: models_crossvit.py:62,65,84-92,115-127; models_mae_cross.py:47-100,138,152.
 #include "common.cuh"
 #include <type_traits>
+#include <utility>
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 
@@ -387,6 +388,20 @@ constexpr bool is_rowlike(int mode) { return mode == COUNTR_OP_ROW || mode == CO
 typedef __attribute__((address_space(3))) const char* lds_cptr_t;
 __device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(lds_cptr_t)p; }
 
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// row-like fragment read with the tile-row displacement in the instruction's offset field: for the permuted row order the swizzle
+// term of a lane is the same for all 16-row tiles of a wave (they differ in row bits 2, 3 and 6 only), so one base address per
+// (operand, k-step) serves every tile -> ~4 instead of ~24 vector adds per k-tile.
+template <int OFF> __device__ __forceinline__ bf16x8_t lds_read_b128_off(uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+
 template <int MODE> struct FragReads { static constexpr int N = is_rowlike(MODE) ? 1 : 2; };  // LDS instructions per fragment
 
 template <int MODE>
@@ -548,13 +563,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
 #if COUNTR_ABL == 2
         for (int q = 0; q < 4; ++q) { xf[s & 1][q] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, q, kk, 1)); if (h == 0) wf[kk][q] = xf[s & 1][q]; }
 #else
+        if constexpr (MPERM) {
+          const int r0 = mrow(0);
+          const uint32_t xa = sa + r0 * 128 + (((kk * 4 + (lane >> 4)) ^ swz_row(r0)) << 4);
+          static_for<4>([&](auto TM) { constexpr int tm = decltype(TM)::value; xf[s & 1][tm] = lds_read_b128_off<(h * 64 + tm * 4) * 128>(xa); });
+        } else {
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-          xf[s & 1][tm] = frag_bf16<MA>(sa, mrow(h * 4 + tm), wm0 + (h * 4 + tm) * 16 + (li & 3) * 4, kk, lane);
+          for (int tm = 0; tm < 4; ++tm)
+            xf[s & 1][tm] = frag_bf16<MA>(sa, mrow(h * 4 + tm), wm0 + (h * 4 + tm) * 16 + (li & 3) * 4, kk, lane);
+        }
         if constexpr (h == 0) {
+          if constexpr (is_rowlike(MB)) {
+            const uint32_t wa = sb + nrow_base * 128 + (((kk * 4 + (lane >> 4)) ^ swz_row(nrow_base)) << 4);
+            static_for<4>([&](auto TN) { constexpr int tn = decltype(TN)::value; wf[kk][tn] = lds_read_b128_off<tn * 4 * 128>(wa); });
+          } else {
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn)
-            wf[kk][tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
+            for (int tn = 0; tn < 4; ++tn)
+              wf[kk][tn] = frag_bf16<MB>(sb, nrow_base + tn * 4, nrow4_base + tn * 4, kk, lane);
+          }
         }
 #endif
       };
