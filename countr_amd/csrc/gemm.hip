@@ -454,16 +454,23 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
 
 // TMW = 16-row MFMA tiles per wave along M (4: 64x64 wave tile, 8: 128x64 wave tile -> half the staged bytes and 25 % fewer
 // fragment reads per MFMA; used for the 256x256 workgroup tile).
-template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
+// SPEC = wave specialisation: the workgroup gets WM*WN extra LOADER waves (wave w + WM*WN shares its SIMD with compute wave w)
+// that do nothing but stream tiles into a STAGES-deep LDS ring, while the compute waves only read fragments and issue MFMAs.  A
+// 1-KiB LDS-DMA piece costs its wave ~60 issue cycles, about as much per k-tile as the tile's MFMAs: in one instruction stream
+// the two serialise, in two streams on the same SIMD they overlap.
+template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, bool SPEC = false>
+__global__ __launch_bounds__((SPEC ? 128 : 64) * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
   static_assert(TMW == 4 || TMW == 8, "wave tile is 64x64 or 128x64");
+  static_assert(!SPEC || (sizeof(T) == 2 && STAGES >= 3), "wave specialisation: bf16 path, >= 3 LDS stages");
   constexpr int BMt = 16 * TMW * WM, BNt = 64 * WN, NW = WM * WN;
   constexpr int SA = BMt * 128, SB = BNt * 128;  // bf16 stage bytes per operand
   constexpr int BK = Cfg<T>::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // stage s: A tile at smem + 2*s*OP_BYTES, B tile right behind it
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool loader_wave = SPEC && (tid >> 6) >= WM * WN;
+  const int wave = SPEC ? ((tid >> 6) % (WM * WN)) : (tid >> 6);   // index inside its role
   const int tilesN = (g.N + BNt - 1) / BNt;
   // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed; speed only).  Give every XCD one contiguous range
   // of the (tile_m, tile_n) space so the tiles sharing an A row-panel / B panel sit behind the same L2 instead of being
@@ -639,6 +646,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
         mma_tile(smem, smem + SA);
         __builtin_amdgcn_s_barrier();  // all fragment reads of this tile are consumed before it is overwritten
       }
+    } else if constexpr (SPEC) {
+      // loader waves: wait for tile t (counted vmcnt, loads retire in order) -> barrier -> refill the slot that tile t-1 used;
+      // compute waves: barrier -> multiply tile t.  One workgroup barrier per k-tile orders both hand-offs: a compute wave
+      // arrives only after it issued tile t-1's MFMAs (their fragments were read), a loader only after tile t has landed.
+      constexpr int PER = DmaLoader<MA, BMt, NW>::PASSES + DmaLoader<MB, BNt, NW>::PASSES;
+      static_assert((STAGES - 2) * PER <= 63, "vmcnt immediate");
+      if (loader_wave) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+          if (s < ntiles) {
+            issueA(ktile(s), smem + s * (SA + SB));
+            issueB(ktile(s), smem + s * (SA + SB) + SA);
+          }
+        int islot = STAGES - 1;
+        for (int t = 0; t < ntiles; ++t) {
+          if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (t + STAGES - 1 < ntiles) {
+            char* nxt = smem + islot * (SA + SB);
+            issueA(ktile(t + STAGES - 1), nxt);
+            issueB(ktile(t + STAGES - 1), nxt + SA);
+          }
+          islot = (islot + 1 == STAGES) ? 0 : islot + 1;
+        }
+      } else {
+        int slot = 0;
+        for (int t = 0; t < ntiles; ++t) {
+          __builtin_amdgcn_s_barrier();
+          mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
+          slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+        }
+      }
     } else if constexpr (STAGES >= 3) {
       // Deep pipeline for SMALL grids (<= 1 workgroup per CU, nothing else to hide the DMA round trip): STAGES-1 tiles are in
       // flight while one is multiplied.  Counted vmcnt: DMA loads retire in order, so "at most (STAGES-2) tiles' worth of
@@ -687,6 +727,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
     }
     };
     if (fast_addr) main_loop(std::true_type{}); else main_loop(std::false_type{});
+    if (loader_wave) return;   // no barrier after this point
     if (do_rowsum && (lane >> 4) == 0) {
 #pragma unroll
       for (int tm = 0; tm < TMW; ++tm) {
@@ -803,7 +844,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const countr_gemm_ar
   }
 }
 
-template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4>
+template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, bool SPEC = false>
 int launch_variant(const countr_gemm_args& a, hipStream_t s) {
   constexpr int BMt = 16 * TMW * WM, BNt = 64 * WN;
   constexpr int lds_bytes = sizeof(T) == 2 ? STAGES * (BMt + BNt) * 128 : 4 * OP_BYTES;
@@ -812,13 +853,13 @@ int launch_variant(const countr_gemm_args& a, hipStream_t s) {
   dim3 grid(tilesM * tilesN, 1, zdim);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, SPEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
   static const int skew = [] { const char* e = getenv("COUNTR_GEMM_SKEW"); return e ? atoi(e) : 0; }();
   static const int korder = [] { const char* e = getenv("COUNTR_CONV_KORDER"); return e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW>), grid, dim3(64 * WM * WN), lds_bytes, s, a, skew, korder);
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, SPEC>), grid, dim3((SPEC ? 128 : 64) * WM * WN), lds_bytes, s, a, skew, korder);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
@@ -856,10 +897,17 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
     if (force == 2) return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
     if (force == 3) return launch_variant<T, MA, MB, 3, 2, 2>(a, s);
     if (force == 4) return launch_variant<T, MA, MB, 4, 2, 2>(a, s);
+    if (force == 6) return launch_variant<T, MA, MB, 3, 2, 2, 4, true>(a, s);   // loader/compute wave specialisation, 3-stage ring
+    if (force == 7) return launch_variant<T, MA, MB, 4, 2, 2, 4, true>(a, s);
     // Double-buffered everywhere: since the fragment reads are opaque to the compiler (no implicit vmcnt(0) in front of
     // them) tile t+1 really streams in under tile t's MFMAs, and the single-stage variant loses on every measured shape
     // (tools/bench_gemm.py: conv wgrad 192x192 502 vs 681 us, conv fwd 429 vs 467 us).
-    (void)t128; (void)ktiles;
+    // ... and launches that cannot give every CU a second workgroup anyway (<= 256 workgroups: the N = 768 / 512 projections,
+    // fc2, most dgrads, the 24x24 convolution) run wave-specialised: 4 loader + 4 compute waves per workgroup on a 3-stage ring
+    // (fc2 4608x768x3072 37.4 -> 28.3 us, (row, col) dgrads -20...-25 %, conv 24x24 54.6 -> 34.8 us; with two workgroups per CU
+    // available the plain kernel is faster: fc1 35 vs 43 us).
+    static const int spec_max = [] { const char* e = getenv("COUNTR_GEMM_SPEC_MAX"); return e ? atoi(e) : 256; }();
+    if (t128 <= spec_max && ktiles >= 3) return launch_variant<T, MA, MB, 3, 2, 2, 4, true>(a, s);
   }
   return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
 }
