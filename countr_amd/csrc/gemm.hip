@@ -458,8 +458,9 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
 // that do nothing but stream tiles into a STAGES-deep LDS ring, while the compute waves only read fragments and issue MFMAs.  A
 // 1-KiB LDS-DMA piece costs its wave ~60 issue cycles, about as much per k-tile as the tile's MFMAs: in one instruction stream
 // the two serialise, in two streams on the same SIMD they overlap.
-template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, bool SPEC = false>
-__global__ __launch_bounds__((SPEC ? 128 : 64) * WM * WN) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
+template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, int NLD = 0>
+__global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
+  constexpr bool SPEC = NLD > 0;   // NLD loader waves behind the WM*WN compute waves
   static_assert(TMW == 4 || TMW == 8, "wave tile is 64x64 or 128x64");
   static_assert(!SPEC || (sizeof(T) == 2 && STAGES >= 3), "wave specialisation: bf16 path, >= 3 LDS stages");
   constexpr int BMt = 16 * TMW * WM, BNt = 64 * WN, NW = WM * WN;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__((SPEC ? 128 : 64) * WM * WN) void gemm_kernel(const
 
   const int tid = threadIdx.x, lane = tid & 63;
   const bool loader_wave = SPEC && (tid >> 6) >= WM * WN;
-  const int wave = SPEC ? ((tid >> 6) % (WM * WN)) : (tid >> 6);   // index inside its role
+  const int wave = loader_wave ? (tid >> 6) - WM * WN : (tid >> 6);   // index inside its role
   const int tilesN = (g.N + BNt - 1) / BNt;
   // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed; speed only).  Give every XCD one contiguous range
   // of the (tile_m, tile_n) space so the tiles sharing an A row-panel / B panel sit behind the same L2 instead of being
@@ -539,8 +540,9 @@ __global__ __launch_bounds__((SPEC ? 128 : 64) * WM * WN) void gemm_kernel(const
       if (conv_order) { const int c = t / 9, tap = t - c * 9; return kstart + (tap * nchunk + c) * BK; }
       int tt = t + kskew; if (tt >= ntiles) tt -= ntiles; return kstart + tt * BK;
     };
-    DmaLoader<MA, BMt, NW> la;
-    DmaLoader<MB, BNt, NW> lb;
+    constexpr int NLW = SPEC ? NLD : NW;   // waves that stage tiles
+    DmaLoader<MA, BMt, NLW> la;
+    DmaLoader<MB, BNt, NLW> lb;
     la.init(dA, m0, kstart, wv, lane);
     lb.init(dB, n0, kstart, wv, lane);
     // uniform-base addressing when every k-tile of this launch is full and the operands span < 4 GiB (see DmaLoader); the
@@ -650,7 +652,7 @@ __global__ __launch_bounds__((SPEC ? 128 : 64) * WM * WN) void gemm_kernel(const
       // loader waves: wait for tile t (counted vmcnt, loads retire in order) -> barrier -> refill the slot that tile t-1 used;
       // compute waves: barrier -> multiply tile t.  One workgroup barrier per k-tile orders both hand-offs: a compute wave
       // arrives only after it issued tile t-1's MFMAs (their fragments were read), a loader only after tile t has landed.
-      constexpr int PER = DmaLoader<MA, BMt, NW>::PASSES + DmaLoader<MB, BNt, NW>::PASSES;
+      constexpr int PER = DmaLoader<MA, BMt, NLW>::PASSES + DmaLoader<MB, BNt, NLW>::PASSES;
       static_assert((STAGES - 2) * PER <= 63, "vmcnt immediate");
       if (loader_wave) {
 #pragma unroll
@@ -844,7 +846,7 @@ __global__ __launch_bounds__((SPEC ? 128 : 64) * WM * WN) void gemm_kernel(const
   }
 }
 
-template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, bool SPEC = false>
+template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, int NLD = 0>
 int launch_variant(const countr_gemm_args& a, hipStream_t s) {
   constexpr int BMt = 16 * TMW * WM, BNt = 64 * WN;
   constexpr int lds_bytes = sizeof(T) == 2 ? STAGES * (BMt + BNt) * 128 : 4 * OP_BYTES;
@@ -853,13 +855,13 @@ int launch_variant(const countr_gemm_args& a, hipStream_t s) {
   dim3 grid(tilesM * tilesN, 1, zdim);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, SPEC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, NLD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
   static const int skew = [] { const char* e = getenv("COUNTR_GEMM_SKEW"); return e ? atoi(e) : 0; }();
   static const int korder = [] { const char* e = getenv("COUNTR_CONV_KORDER"); return e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, SPEC>), grid, dim3((SPEC ? 128 : 64) * WM * WN), lds_bytes, s, a, skew, korder);
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, NLD>), grid, dim3(64 * (WM * WN + NLD)), lds_bytes, s, a, skew, korder);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
@@ -881,11 +883,13 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       // measured (tools/bench_gemm.py, COUNTR_GEMM_TILE=22|24|42|44): 256-wide tiles lose to 128x128 with this loop
       // structure (8-wave variants drop to one workgroup per CU, the 16-wave 256x256 one spills), so 22 stays the default
       (void)t256; (void)t128x256;
-      // ... except on very large grids (the 192x192 density-head convolutions, 4608 tiles): there the 8-wave 128x256 tile's
-      // halved operand traffic per MFMA is worth +7 % (420 vs 450 us); at <= ~1000 tiles it loses to the tail.
+      // ... except on very large grids (the 192x192 density-head convolutions, 4608 tiles): there a 128x256 tile with 8 compute +
+      // 4 loader waves on a 3-stage ring wins (358 vs 395 us, 0.97 PF/s); at <= ~1000 tiles it loses to the tail.
       static const int big = [] { const char* e = getenv("COUNTR_GEMM_BIGTILE"); return e ? atoi(e) : 4096; }();
-      if (!tile) tile = (t128 >= big && a.N >= 256) ? 24 : 22;
+      if (!tile) tile = (t128 >= big && a.N >= 256) ? 124 : 22;
       if (tile == 88) return launch_variant<T, MA, MB, 2, 2, 4, 8>(a, s);   // 256x256, 8 waves x (128x64)
+      if (tile == 124) return launch_variant<T, MA, MB, 3, 2, 4, 4, 4>(a, s);   // 128x256, 8 compute + 4 loader waves, 3-stage ring
+      if (tile == 128) return launch_variant<T, MA, MB, 3, 2, 4, 4, 8>(a, s);   // 128x256, 8 compute + 8 loader waves
       if (tile == 44) return launch_variant<T, MA, MB, 2, 4, 4>(a, s);
       if (tile == 24) return launch_variant<T, MA, MB, 2, 2, 4>(a, s);
       if (tile == 42) return launch_variant<T, MA, MB, 2, 4, 2>(a, s);
@@ -897,8 +901,8 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
     if (force == 2) return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
     if (force == 3) return launch_variant<T, MA, MB, 3, 2, 2>(a, s);
     if (force == 4) return launch_variant<T, MA, MB, 4, 2, 2>(a, s);
-    if (force == 6) return launch_variant<T, MA, MB, 3, 2, 2, 4, true>(a, s);   // loader/compute wave specialisation, 3-stage ring
-    if (force == 7) return launch_variant<T, MA, MB, 4, 2, 2, 4, true>(a, s);
+    if (force == 6) return launch_variant<T, MA, MB, 3, 2, 2, 4, 4>(a, s);   // loader/compute wave specialisation, 3-stage ring
+    if (force == 7) return launch_variant<T, MA, MB, 4, 2, 2, 4, 4>(a, s);
     // Double-buffered everywhere: since the fragment reads are opaque to the compiler (no implicit vmcnt(0) in front of
     // them) tile t+1 really streams in under tile t's MFMAs, and the single-stage variant loses on every measured shape
     // (tools/bench_gemm.py: conv wgrad 192x192 502 vs 681 us, conv fwd 429 vs 467 us).
@@ -907,7 +911,7 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
     // (fc2 4608x768x3072 37.4 -> 28.3 us, (row, col) dgrads -20...-25 %, conv 24x24 54.6 -> 34.8 us; with two workgroups per CU
     // available the plain kernel is faster: fc1 35 vs 43 us).
     static const int spec_max = [] { const char* e = getenv("COUNTR_GEMM_SPEC_MAX"); return e ? atoi(e) : 256; }();
-    if (t128 <= spec_max && ktiles >= 3) return launch_variant<T, MA, MB, 3, 2, 2, 4, true>(a, s);
+    if (t128 <= spec_max && ktiles >= 3) return launch_variant<T, MA, MB, 3, 2, 2, 4, 4>(a, s);
   }
   return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
 }
