@@ -302,8 +302,10 @@ class Engine:
                    lda=K, ldb=K, ldc=N, ldres=N, M=M, N=N, K=K, res_mod=res_mod, act=act, out_bf16=int(out_bf16))
 
     def _splitk(self, tiles, ktiles):
-        sk = max(1, min(64, ktiles, int(round(512.0 / max(tiles, 1)))))
-        return sk
+        """Split-K factor of a wgrad GEMM: as many slabs as keep the launch within 256 workgroups, i.e. one wave-specialised
+        workgroup per CU (measured against the former 512-workgroup target: finetune step -2 %, pretrain step -6 %, and fewer
+        fp32 slabs to reduce)."""
+        return max(1, min(64, ktiles, 256 // max(tiles, 1)))
 
     # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
     def _linear_wgrad(self, ops, dy, x, wname, M, N, K, lddy=None, ldx=None, bias_name=None):
