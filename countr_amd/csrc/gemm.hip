@@ -339,14 +339,16 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2ROW, ROWS, NW> {
 template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2COL, ROWS, NW> {
   static_assert(ROWS == 128, "K-strided operands are only staged as 128-row tiles");
   static constexpr int PASSES = 16 / NW;
-  static constexpr bool HAS_FAST = false;
-  __device__ __forceinline__ void issue_fast(int, char*, int) {}
+  static constexpr bool HAS_FAST = true;
   const char* ptr;
   int py[PASSES], px[PASSES], krow[PASSES], ci[PASSES], dy[PASSES], dx[PASSES];
   int H, W, C;
   bool colok[PASSES];
+  int64_t voff[PASSES];   // fast path: byte offset of (k-row, tap shift, channel chunk) from the pixel-block base
+  int stepx, stepy;       // 64 pixels further = (stepy rows, stepx columns)
   __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ptr = d.ptr; H = d.H; W = d.W; C = d.C;
+    stepy = 64 / W; stepx = 64 - stepy * W;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
       krow[i] = (i * NW + wave) * 4 + (lane >> 4);
@@ -358,6 +360,22 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2COL, ROWS, NW> {
       const int p = kstart + krow[i];
       px[i] = p % W;
       py[i] = (p / W) % H;
+      voff[i] = ((int64_t)(krow[i] + dy[i] * W + dx[i]) * C + ci[i]) * 2;
+    }
+  }
+  // Fast path (full k-tiles, sequential k order): uniform base = first pixel of the k-tile, loop-invariant lane offset; the pixel
+  // coordinates advance by a fixed (rows, columns) step with one conditional wrap each instead of a data-dependent loop.
+  __device__ __forceinline__ void issue_fast(int k0, char* lds, int wave) {
+    const char* ub = ptr + (int64_t)k0 * C * 2;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int yy = py[i] + dy[i], xx = px[i] + dx[i];
+      const bool ok = colok[i] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const void* src = ok ? (const void*)(ub + voff[i]) : (const void*)g_zero_page;
+      dma16(src, lds + (i * NW + wave) * 1024);
+      px[i] += stepx; py[i] += stepy;
+      if (px[i] >= W) { px[i] -= W; py[i] += 1; }
+      if (py[i] >= H) py[i] -= H;
     }
   }
   __device__ void issue(int k0, int kend, char* lds, int wave) {

@@ -52,7 +52,7 @@ for Hs, Cin in ((192, 256), (96, 256), (24, 512)):
     a = base(); a.A, a.B, a.C = xx.data_ptr(), w.data_ptr(), y.data_ptr(); a.ldb, a.ldc = 9 * Cin, 256
     a.M, a.N, a.K = B * Hs * Hs, 256, 9 * Cin; a.H = a.W = Hs; a.Cin = Cin; a.out_bf16 = 1
     run("conv fwd %dx%d Cin%d" % (Hs, Hs, Cin), a, 1, 2, 0, 2.0 * B * Hs * Hs * 256 * 9 * Cin)
-    dyc = mk(B * Hs * Hs, 256); sk = 21 if Hs == 192 else 16
+    dyc = mk(B * Hs * Hs, 256); sk = max(1, 256 // (2 * (9 * Cin // 128)))   # engine policy: <= 256 workgroups
     part = torch.empty((sk, 256, 9 * Cin), device="cuda")
     a = base(); a.A, a.B, a.partial = dyc.data_ptr(), xx.data_ptr(), part.data_ptr(); a.lda, a.ldc = 256, 9 * Cin
     a.M, a.N, a.K = 256, 9 * Cin, B * Hs * Hs; a.H = a.W = Hs; a.Cin = Cin; a.splitk = sk
