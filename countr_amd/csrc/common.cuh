@@ -102,6 +102,22 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// bf16 mode: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16 resolution) with hardware rcp / exp2 --
+// about a third of the instructions of libm erff, which matters in the fc1 GEMM epilogue (14 M evaluations per encoder layer).
+// One exponential exp(-x^2/2) serves both the cdf (erf(x/sqrt2)) and the pdf of the derivative.  fp32 parity mode keeps erff.
+__device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);   // exp(-x^2 / 2)
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float half_tail = 0.5f * poly * e;                      // 0.5 * erfc(|x| / sqrt2)
+  cdf = x >= 0.f ? 1.f - half_tail : half_tail;
+}
+__device__ __forceinline__ float gelu_fast(float x) { float c, e; gelu_fast_parts(x, c, e); return x * c; }
+__device__ __forceinline__ float gelu_fast_grad(float x) { float c, e; gelu_fast_parts(x, c, e); return fmaf(x * 0.3989422804014327f, e, c); }
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x); }
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { if constexpr (sizeof(T) == 2) return gelu_fast_grad(x); else return gelu_erf_grad(x); }
+
 // Error plumbing shared by all translation units (defined in api.hip).
 extern "C" void countr_set_error(const char* msg);
 int countr_check_launch(const char* what);

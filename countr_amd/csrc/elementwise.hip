@@ -230,7 +230,7 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ 
     ld8<T>(dh + i * 8, d);
     ld8<T>(pre + i * 8, p);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_erf_grad(p[e]);
+    for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_grad_t<T>(p[e]);
     st8<T>(dpre + i * 8, o);
   }
 }

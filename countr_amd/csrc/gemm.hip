@@ -843,14 +843,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         if (g.out_bf16) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(g.C2) + crow + n, h);
         else ld4<float>(reinterpret_cast<const float*>(g.C2) + crow + n, h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(h[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(h[e]);
       } else if (g.C2) {
         if (g.out_bf16) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C2) + crow + n, v);
         else st4<float>(reinterpret_cast<float*>(g.C2) + crow + n, v);
       }
       if (g.act == COUNTR_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
       }
       if (rrow) {
         float r[4];
