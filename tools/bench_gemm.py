@@ -47,6 +47,15 @@ run("dgrad 4608x512x2048 (row,col)", a, 1, 0, 1, 2.0 * M * N * K)
 x = mk(M, K); part = torch.empty((8, N, K), device="cuda")
 a = base(); a.A, a.B, a.partial = dy.data_ptr(), x.data_ptr(), part.data_ptr(); a.lda, a.ldb, a.ldc = N, K, K; a.M, a.N, a.K = N, K, M; a.splitk = 8
 run("wgrad 2048x512x4608 sk8 (col,col)", a, 1, 1, 1, 2.0 * M * N * K)
+# MAE pretrain wgrad shapes (K = 2304 kept tokens): dW[N_lin, K_lin] = dy^T x, 128x128 tiles x split-K
+for name, Nl, Kl in (("pre wgrad fc1 3072x768", 3072, 768), ("pre wgrad qkv 2304x768", 2304, 768), ("pre wgrad proj 768x768", 768, 768)):
+    dyp, xp = mk(Mp, Nl), mk(Mp, Kl)
+    tiles = (Nl // 128) * (Kl // 128)
+    for sk in sorted({1, 2, max(1, 256 // tiles), max(1, round(512 / tiles))}):
+        part = torch.empty((sk, Nl, Kl), device="cuda")
+        a = base(); a.A, a.B, a.partial = dyp.data_ptr(), xp.data_ptr(), part.data_ptr(); a.lda, a.ldb, a.ldc = Nl, Kl, Kl
+        a.M, a.N, a.K = Nl, Kl, Mp; a.splitk = sk
+        run("%s x2304 sk%d (%d wgs)" % (name, sk, tiles * sk), a, 1, 1, 1, 2.0 * Mp * Nl * Kl)
 for Hs, Cin in ((192, 256), (96, 256), (24, 512)):
     xx = mk(B, Hs, Hs, Cin); w = mk(256, 9 * Cin); y = torch.empty((B * Hs * Hs, 256), device="cuda", dtype=torch.bfloat16)
     a = base(); a.A, a.B, a.C = xx.data_ptr(), w.data_ptr(), y.data_ptr(); a.ldb, a.ldc = 9 * Cin, 256
