@@ -58,15 +58,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // Backward: dx (+)= rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)); per-block partial dgamma / dbeta.
-// Grid = NB blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NB, ...
+// Grid = NB blocks of LNB_WAVES waves (8: two resident waves per SIMD hide the row-to-row latency; 4 measured 15 vs ~10 us);
+// wave w of block b walks rows (b*LNB_WAVES+w), +LNB_WAVES*NB, ...
+constexpr int LNB_WAVES = 8;
 template <typename TI>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             bf16_t* __restrict__ dx_bf16, float* __restrict__ partial, int rows,
                                                             int D, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem_ln[];
-  float* sm = reinterpret_cast<float*>(smem_ln);  // [4 waves][2][D]
+  float* sm = reinterpret_cast<float*>(smem_ln);  // [LNB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int MAXV = 8;
   float dg[MAXV][4], db[MAXV][4];
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
     const float mu = mean[row], rs = rstd[row];
     const TI* dyr = dy + (int64_t)row * D;
     const float* xr = x + (int64_t)row * D;
@@ -125,11 +127,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+  for (int c = threadIdx.x; c < 2 * D; c += 64 * LNB_WAVES) {
     const int which = c / D, col = c - which * D;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += sm[(w * 2 + which) * D + col];
+    for (int w = 0; w < LNB_WAVES; ++w) s += sm[(w * 2 + which) * D + col];
     partial[((int64_t)blockIdx.x * 2 + which) * D + col] = s;
   }
 }
@@ -649,9 +651,15 @@ extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float*
                                     int dy_bf16, int accumulate_dx, int accumulate_dgb, void* dx_bf16, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace || D % 4 || D > 2048) { countr_set_error("countr_layernorm_bwd: bad args"); return -1; }
   const int nb = 256;
-  const size_t lds = (size_t)4 * 2 * D * sizeof(float);
-  if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
+  const size_t lds = (size_t)LNB_WAVES * 2 * D * sizeof(float);
+  static bool attr_set = false;   // D > 1024 needs more than the default 64 KiB of dynamic LDS
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
+    attr_set = true;
+  }
+  if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(64 * LNB_WAVES), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(64 * LNB_WAVES), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
   // workspace rows are {dgamma[D], dbeta[D]} per block; adjacent outputs (the flat gradient buffer) finish in one launch
   if (dgamma && dbeta == dgamma + D) {
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, 2 * D, (int64_t)2 * D, accumulate_dgb);
