@@ -898,8 +898,8 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * zdim;
       const long t128x256 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256) * zdim;
       int tile = ftile;
-      // measured (tools/bench_gemm.py, COUNTR_GEMM_TILE=22|24|42|44): 256-wide tiles lose to 128x128 with this loop
-      // structure (8-wave variants drop to one workgroup per CU, the 16-wave 256x256 one spills), so 22 stays the default
+      // measured (tools/bench_gemm.py, COUNTR_GEMM_TILE=22|24|42|88): plain 256-wide tiles lose to 128x128 with this loop
+      // structure (one workgroup per CU, too few tiles at M = 4608), so 22 stays the default
       (void)t256; (void)t128x256;
       // ... except on very large grids (the 192x192 density-head convolutions, 4608 tiles): there a 128x256 tile with 8 compute +
       // 4 loader waves on a 3-stage ring wins (358 vs 395 us, 0.97 PF/s); at <= ~1000 tiles it loses to the tail.
@@ -907,8 +907,6 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       if (!tile) tile = (t128 >= big && a.N >= 256) ? 124 : 22;
       if (tile == 88) return launch_variant<T, MA, MB, 2, 2, 4, 8>(a, s);   // 256x256, 8 waves x (128x64)
       if (tile == 124) return launch_variant<T, MA, MB, 3, 2, 4, 4, 4>(a, s);   // 128x256, 8 compute + 4 loader waves, 3-stage ring
-      if (tile == 128) return launch_variant<T, MA, MB, 3, 2, 4, 4, 8>(a, s);   // 128x256, 8 compute + 8 loader waves
-      if (tile == 44) return launch_variant<T, MA, MB, 2, 4, 4>(a, s);
       if (tile == 24) return launch_variant<T, MA, MB, 2, 2, 4>(a, s);
       if (tile == 42) return launch_variant<T, MA, MB, 2, 4, 2>(a, s);
     }
