@@ -19,7 +19,9 @@ namespace {
 constexpr int FA_BQ = 128;   // query rows per workgroup
 constexpr int FA_BKV = 64;   // keys per tile
 
-template <int DH, int BKV, bool RAGGED>
+// QT = 16-query MFMA tiles per wave (2: 128 query rows per workgroup; 1: 64 rows -> twice the waves in flight, which is what a
+// small launch such as B = 8 x 12 heads needs to hide LDS / barrier latency, at twice the K/V fragment reads per MFMA)
+template <int DH, int BKV, bool RAGGED, int QT>
 __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                              float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
   constexpr int KS = DH / 32;          // k-steps over head dim for QK^T
@@ -33,7 +35,8 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];  // stage s: K at s*2*TILE, V behind it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int qblocks = (N + FA_BQ - 1) / FA_BQ;
+  constexpr int BQ = 64 * QT;         // query rows per workgroup
+  const int qblocks = (N + BQ - 1) / BQ;
   // XCD-aware mapping: workgroup id b runs on XCD b % 8 (observed dispatch order; affects speed only).  All query
   // blocks of one (batch, head) are given ids congruent mod 8 so that its K/V tiles are fetched into ONE XCD's L2
   // instead of once per query block (PMC: 78 MB -> 21 MB fabric reads per launch at B=8, H=12).
@@ -52,11 +55,11 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
   const bf16_t* qp = qkv + (int64_t)b * N * rs + h * DH;
   const bf16_t* kp = qp + H * DH;
   const bf16_t* vp = kp + H * DH;
-  const int q0 = qb * FA_BQ + wave * 32;
+  const int q0 = qb * BQ + wave * (16 * QT);
 
-  bf16x8_t qf[2][KS];
+  bf16x8_t qf[QT][KS];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 16 + li;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -66,10 +69,14 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     }
   }
 
-  f32x4_t o[DT][2];
+  f32x4_t o[DT][QT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4_t{0, 0, 0, 0}; o[dt][1] = f32x4_t{0, 0, 0, 0}; }
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4_t{0, 0, 0, 0};
+  float m[QT], l[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
 
   const int ntiles = (N + BKV - 1) / BKV;
   uint4 kreg[PASSES], vreg[PASSES];
@@ -108,17 +115,19 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     const char* Vs = Ks + TILE;
 
     // ---- S^T[kt][qt] : 16 keys x 16 queries per MFMA tile
-    f32x4_t s[KT][2];
+    f32x4_t s[KT][QT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) { s[kt][0] = f32x4_t{0, 0, 0, 0}; s[kt][1] = f32x4_t{0, 0, 0, 0}; }
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4_t{0, 0, 0, 0};
 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
-        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
-        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
       }
 
     if (RAGGED && (t + 1) * BKV > N) {  // ragged last tile: keys >= N do not exist (variant only built for N % BKV != 0)
@@ -126,13 +135,16 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (t * BKV + kt * 16 + g * 4 + r >= N) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+          if (t * BKV + kt * 16 + g * 4 + r >= N) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt][r] = -INFINITY;
+          }
     }
 
     // ---- online softmax (exp2 domain), P packed straight into PV operands
-    bf16x8_t pf[2][PS];
+    bf16x8_t pf[QT][PS];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
         vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
         vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vv);
-        o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][ps], o[dt][0], 0, 0, 0);
-        o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ps], o[dt][1], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ps], o[dt][qt], 0, 0, 0);
       }
 
 
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 
   // ---- epilogue: normalise and store; lane (li, g) owns query q and channels dt*16 + 4g .. +3
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
@@ -224,22 +236,30 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream) {
   if (!qkv || !out || B <= 0 || N <= 0 || H <= 0) { countr_set_error("countr_attn_fwd: bad args"); return -1; }
   const float c = scale * 1.4426950408889634f;
-  const int qblocks = (N + FA_BQ - 1) / FA_BQ;
-  dim3 grid(B * H * qblocks), block(256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool ragged = (N % 64) != 0;
-#define COUNTR_FA_LAUNCH(DHV, RG)                                                                                              \
-  hipLaunchKernelGGL((flash_attn_fwd_kernel<DHV, 64, RG>), grid, block, 4 * 64 * (DHV * 2 + 16), s, (const bf16_t*)qkv, (bf16_t*)out, \
-                     lse, N, H, c)
-  if (dh == 64) {
-    if (ragged) COUNTR_FA_LAUNCH(64, true); else COUNTR_FA_LAUNCH(64, false);
-  } else if (dh == 32) {
-    if (ragged) COUNTR_FA_LAUNCH(32, true); else COUNTR_FA_LAUNCH(32, false);
-#undef COUNTR_FA_LAUNCH
-  } else {
+  // 64 query rows per workgroup for small dh = 32 launches (measured at B = 8: 17.3 vs 18.3 us); dh = 64 is faster with 128
+  // rows at every batch size (B = 8: 20.4 vs 21.8 us, B = 32: 64.8 vs 69.6 us)
+  static const int force_qt = [] { const char* e = getenv("COUNTR_ATTN_QT"); return e ? atoi(e) : 0; }();
+  const long wg128 = (long)B * H * ((N + 127) / 128);
+  const int qt = force_qt ? force_qt : ((dh == 32 && wg128 < 768) ? 1 : 2);
+  dim3 grid(B * H * ((N + 64 * qt - 1) / (64 * qt))), block(256);
+#define COUNTR_FA_LAUNCH(DHV, RG, QTV)                                                                                         \
+  hipLaunchKernelGGL((flash_attn_fwd_kernel<DHV, 64, RG, QTV>), grid, block, 4 * 64 * (DHV * 2 + 16), s, (const bf16_t*)qkv,   \
+                     (bf16_t*)out, lse, N, H, c)
+#define COUNTR_FA_DISPATCH(DHV)                                                                                                \
+  do {                                                                                                                         \
+    if (qt == 1) { if (ragged) COUNTR_FA_LAUNCH(DHV, true, 1); else COUNTR_FA_LAUNCH(DHV, false, 1); }                       \
+    else { if (ragged) COUNTR_FA_LAUNCH(DHV, true, 2); else COUNTR_FA_LAUNCH(DHV, false, 2); }                               \
+  } while (0)
+  if (dh == 64) COUNTR_FA_DISPATCH(64);
+  else if (dh == 32) COUNTR_FA_DISPATCH(32);
+  else {
     countr_set_error("countr_attn_fwd: head_dim must be 32 or 64");
     return -1;
   }
+#undef COUNTR_FA_DISPATCH
+#undef COUNTR_FA_LAUNCH
   COUNTR_LAUNCH_CHECK("countr_attn_fwd");
 }
 
