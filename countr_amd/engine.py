@@ -110,7 +110,8 @@ class Plan:
     def __init__(self):
         self.fwd = []
         self.bwd_head = []   # backward until bucket 0 (head + decoder_norm) gradients are final
-        self.bwd_rest = []
+        self.bwd_rest = []   # ... until bucket 1 (decoder blocks + decoder_embed) is final
+        self.bwd_tok = []    # exemplar tokens: exemplar CNN (bucket 2) or shot_token (bucket 3)
         self.buf = {}
 
 
@@ -694,6 +695,7 @@ class Engine:
         # ---- decoder_embed (no dgrad: the encoder is frozen)
         self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
         # ---- exemplar tokens
+        ops = p.bwd_tok
         if S == 0:
             ws = self._shared("colsum", 256 * 4096)
             self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, 0)
@@ -740,6 +742,7 @@ class Engine:
         p.buf["dout"].copy_(dout, non_blocking=True)
         self.run(p.bwd_head)
         self.run(p.bwd_rest)
+        self.run(p.bwd_tok)
 
     def adam_ranges(self, S, weight_decay):
         return self.layout.adam_ranges(S, weight_decay)

@@ -2,9 +2,9 @@
 all-reduce at util/misc.py:424-432).
 
 The path shards by images (pure data parallel; IN/GN/LN statistics are per sample) and has ONE exchange step per
-iteration: a sum all-reduce of the flat fp32 decoder-gradient buffer, split in two buckets so the first
-(density head + decoder_norm, final when ~3/4 of backward is done) overlaps the rest of backward on a side
-stream.  Averaging (1/world) is folded into the fused AdamW (grad_scale).  The frozen encoder is never
+iteration: a sum all-reduce of the flat fp32 decoder-gradient buffer, split in buckets ordered by backward completion
+(density head + decoder_norm, then decoder blocks + decoder_embed, then the exemplar CNN / shot_token) so that every
+bucket but the last overlaps the rest of backward on a side stream.  Averaging (1/world) is folded into the fused AdamW (grad_scale).  The frozen encoder is never
 communicated (the reference's DDP buckets all 98.9 M parameters).  Device-agnostic: the same code runs over
 RCCL on GPUs and over gloo in the CPU tests.
 """
@@ -27,22 +27,29 @@ def shared_shot_num(step, seed=0, allow_zero=True):
 
 
 class GradSync:
-    """Two-bucket all-reduce of a flat gradient buffer."""
+    """Bucketed sum all-reduce of a flat gradient buffer.  Buckets are contiguous [start, end) slices ordered by the time their
+    gradients become final in the backward pass; start(i) launches bucket i on a side stream as soon as the caller's stream
+    has produced it (the collective then overlaps the rest of backward), finish() reduces what was not started and joins."""
 
-    def __init__(self, flat_grad, bucket0, bucket_rest, group=None):
+    def __init__(self, flat_grad, bucket0, bucket_rest=None, group=None, buckets=None):
         self.g = flat_grad
-        self.b0, self.b1 = bucket0, bucket_rest
+        self.buckets = list(buckets) if buckets is not None else [tuple(bucket0), tuple(bucket_rest)]
         self.group = group
         self.world = world_size(group)
         self.stream = None
+        self._started = set()
         if self.world > 1 and flat_grad.is_cuda:
             self.stream = torch.cuda.Stream(device=flat_grad.device)
 
-    def start_bucket0(self):
-        """Call when the gradients in bucket 0 are final; returns immediately on GPU (side stream)."""
+    def start(self, i):
+        """Call when the gradients of bucket i are final; returns immediately on GPU (side stream)."""
+        self._started.add(i)
         if self.world == 1:
             return
-        view = self.g[self.b0[0]:self.b0[1]]
+        s, e = self.buckets[i]
+        if e <= s:
+            return
+        view = self.g[s:e]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.g.device))
             with torch.cuda.stream(self.stream):
@@ -50,11 +57,27 @@ class GradSync:
         else:
             dist.all_reduce(view, group=self.group)
 
-    def finish(self):
-        """Call after the rest of backward: reduces bucket 1 and joins the side stream."""
+    def start_bucket0(self):
+        self.start(0)
+
+    def finish(self, skip=()):
+        """Call after the last backward kernel: reduces the buckets not started yet (except `skip`: buckets whose parameters have
+        no gradient this step) in one collective per contiguous run, then joins the side stream."""
+        pending = [i for i in range(len(self.buckets)) if i not in self._started and i not in skip]
+        self._started = set()
         if self.world == 1:
             return
-        dist.all_reduce(self.g[self.b1[0]:self.b1[1]], group=self.group)
+        runs = []
+        for i in pending:
+            s, e = self.buckets[i]
+            if e <= s:
+                continue
+            if runs and runs[-1][1] == s:
+                runs[-1][1] = e
+            else:
+                runs.append([s, e])
+        for s, e in runs:
+            dist.all_reduce(self.g[s:e], group=self.group)
         if self.stream is not None:
             torch.cuda.current_stream(self.g.device).wait_stream(self.stream)
 

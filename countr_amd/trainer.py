@@ -36,11 +36,20 @@ class _GraphStep:
         lay = self.eng.layout
         self.bucket0 = lay.bucket_range(0)
         self.bucket_rest = (self.bucket0[1], lay.n_train)
-        self.sync = GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
+        self.sync = self._make_sync(process_group)
         self.world = self.sync.world
         self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._ring_ev = [None] * 16
         self.grad_scale = 1.0
+
+    def _make_sync(self, process_group):
+        return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
+
+    def _phase_b2(self, S):     # optional third backward phase (finetune: exemplar tokens)
+        pass
+
+    def _skip(self, key):
+        return ()
 
     def _phase_c(self, S):
         self.eng.adamw_launch(S, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper)
@@ -90,9 +99,12 @@ class _GraphStep:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
             self._run_phase("a", self._phase_a, key)
-            self.sync.start_bucket0()          # overlaps with the rest of backward
+            self.sync.start(0)                 # overlaps with the rest of backward
             self._run_phase("b", self._phase_b, key)
-            self.sync.finish()
+            if len(self.sync.buckets) > 2:
+                self.sync.start(1)             # overlaps with the last backward phase
+                self._run_phase("b2", self._phase_b2, key)
+            self.sync.finish(skip=self._skip(key))
             self._upload_hyper()
             self._run_phase("c", self._phase_c, key)
         torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
@@ -121,15 +133,19 @@ class FinetuneStep(_GraphStep):
                                            sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
         eng.run(p.bwd_head)
 
+    def _make_sync(self, process_group):
+        lay = self.eng.layout   # buckets in backward-completion order: head | decoder blocks + embed | exemplar CNN | shot_token
+        return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
+
+    def _skip(self, S):
+        """Parameters without a gradient for this shot_num are neither reduced nor stepped (as torch AdamW skips grad None)."""
+        return (2,) if S == 0 else (3,)
+
     def _phase_b(self, S):
-        p = self.eng.plan(self.B, S, True)
-        if S == 0:  # exemplar-CNN gradients are absent for this shot_num: keep the bucket well-defined
-            s, e = self.eng.layout.bucket_range(2)
-            self.eng.G[s:e].zero_()
-        else:
-            s, e = self.eng.layout.bucket_range(3)
-            self.eng.G[s:e].zero_()
-        self.eng.run(p.bwd_rest)
+        self.eng.run(self.eng.plan(self.B, S, True).bwd_rest)
+
+    def _phase_b2(self, S):
+        self.eng.run(self.eng.plan(self.B, S, True).bwd_tok)
 
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):

@@ -43,6 +43,18 @@ def _worker(rank, world, port, out):
         other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)), dtype=torch.float64)
         other[s0:e0] = 0
         assert torch.allclose(flat, g_local + other, atol=1e-12)
+        # the finetune step's schedule: four buckets in backward-completion order, the first two started early, the bucket
+        # without gradients for this shot_num skipped (it keeps its local, unreduced content and AdamW never reads it)
+        flat4 = g_local.clone()
+        sync4 = GradSync(flat4, None, None, buckets=[lay.bucket_range(b) for b in range(4)])
+        sync4.start(0); sync4.start(1)
+        skip = 2 if S == 0 else 3
+        sync4.finish(skip=(skip,))
+        for b in range(4):
+            lo, hi = lay.bucket_range(b)
+            want = g_local[lo:hi] if b == skip else (g_local + other)[lo:hi]
+            assert torch.allclose(flat4[lo:hi], want, atol=1e-12), b
+        assert [lay.bucket_range(b)[1] for b in range(3)] == [lay.bucket_range(b + 1)[0] for b in range(3)]
         # AdamW with grad_scale = 1/world == AdamW on the averaged gradient, only on the ranges with gradients
         p = torch.zeros(n, dtype=torch.float64) + 0.1
         m = torch.zeros(n, dtype=torch.float64); v = torch.zeros(n, dtype=torch.float64)
