@@ -8,7 +8,7 @@ pre-allocated buffers, hipGraph-replayable), different graph: the whole model tr
   forward_decoder  models_mae_noct.py:159-179   unshuffle = one row gather with mask_token as default row (+ pos embed)
   forward_loss     models_mae_noct.py:181-198   countr_patch_mse (all-patch MSE, optional norm_pix)
   backward         autograd of the above        encoder + decoder ViT blocks (flash attention backward in bf16 mode)
-Gradient buckets: 0 = decoder side (final first), 1 = encoder side.
+Gradient buckets: 0 = decoder side (final first), 1..3 = encoder thirds from the top (mae_bucket_fn).
 """
 import math
 
@@ -24,20 +24,32 @@ def mae_trainable(name):
     return name not in ("pos_embed", "decoder_pos_embed")
 
 
-def mae_bucket(name):
-    return 0 if name.startswith(("decoder_", "mask_token")) else 1
+def mae_bucket_fn(depth):
+    """Gradient buckets in backward-completion order: 0 = decoder side + mask_token, then the encoder in thirds from the top:
+    1 = norm + upper blocks, 2 = middle blocks, 3 = lower blocks + patch_embed (each all-reduce overlaps the next phase)."""
+    lo, hi = depth // 3, depth - depth // 3
+
+    def bucket(name):
+        if name.startswith(("decoder_", "mask_token")):
+            return 0
+        if name.startswith("blocks."):
+            i = int(name.split(".")[1])
+            return 1 if i >= hi else (2 if i >= lo else 3)
+        return 1 if name.startswith("norm.") else 3   # patch_embed
+
+    return bucket
 
 
 class MaePlan(Plan):
     def __init__(self):
         super().__init__()
         self.bwd_dec = self.bwd_head
-        self.bwd_enc = self.bwd_rest
+        self.bwd_enc = [self.bwd_rest, self.bwd_tok, []]   # encoder backward in three phases (buckets 1, 2, 3)
 
 
 class MaeEngine(Engine):
     def _make_layout(self, named_shapes):
-        return ParamLayout(named_shapes, trainable=mae_trainable, bucket=mae_bucket)
+        return ParamLayout(named_shapes, trainable=mae_trainable, bucket=mae_bucket_fn(self.depth))
 
     def _conv_names(self):
         return []
@@ -194,11 +206,14 @@ class MaeEngine(Engine):
         dlat = A("dlat", (rk, D), T)
         self._linear_bwd(ops, ge, latent, "decoder_embed.weight", rk, Dd, D, dx=dlat)
 
-        ops = p.bwd_enc
+        bucket = mae_bucket_fn(self.depth)
+        ops = p.bwd_enc[0]
         se = self._bwd_scratch(p, "enc", rk, D)
         g_t = self._layernorm_bwd(ops, dlat, x_enc_out, "norm", mE, rE, se["gx"], rk, D, accumulate=False, dx_t=se["gxT"])
         for i in reversed(range(self.depth)):
+            ops = p.bwd_enc[bucket("blocks.%d.norm1.weight" % i) - 1]
             g_t = self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H, g_t)
+        ops = p.bwd_enc[2]
         self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
         return p
 
@@ -240,4 +255,5 @@ class MaeEngine(Engine):
     def backward(self, B, len_keep):
         p = self.plan(B, int(len_keep), True)
         self.run(p.bwd_dec)
-        self.run(p.bwd_enc)
+        for ops in p.bwd_enc:
+            self.run(ops)

@@ -45,8 +45,8 @@ class _GraphStep:
     def _make_sync(self, process_group):
         return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
 
-    def _phase_b2(self, S):     # optional third backward phase (finetune: exemplar tokens)
-        pass
+    def _phases(self):          # [(graph key, launcher)]: forward + loss + first backward part, then the remaining backward parts
+        return [("a", self._phase_a), ("b", self._phase_b)]
 
     def _skip(self, key):
         return ()
@@ -92,18 +92,18 @@ class _GraphStep:
         self._ring_ev[slot] = ev
 
     def _step(self, key):
-        """phase a -> bucket-0 all-reduce overlapped with phase b -> all-reduce of the rest -> fused AdamW."""
+        """backward phases in bucket order: after phase i the gradients of bucket i are final and its all-reduce starts on the
+        side stream, overlapping phase i+1; the last phase's bucket(s) are reduced by finish(); then the fused AdamW."""
         eng = self.eng
         with torch.cuda.stream(self.stream):
             if eng.M is None:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
-            self._run_phase("a", self._phase_a, key)
-            self.sync.start(0)                 # overlaps with the rest of backward
-            self._run_phase("b", self._phase_b, key)
-            if len(self.sync.buckets) > 2:
-                self.sync.start(1)             # overlaps with the last backward phase
-                self._run_phase("b2", self._phase_b2, key)
+            phases = self._phases()
+            for i, (name, fn) in enumerate(phases):
+                self._run_phase(name, fn, key)
+                if i + 1 < len(phases):
+                    self.sync.start(i)
             self.sync.finish(skip=self._skip(key))
             self._upload_hyper()
             self._run_phase("c", self._phase_c, key)
@@ -147,6 +147,9 @@ class FinetuneStep(_GraphStep):
     def _phase_b2(self, S):
         self.eng.run(self.eng.plan(self.B, S, True).bwd_tok)
 
+    def _phases(self):
+        return [("a", self._phase_a), ("b", self._phase_b), ("b2", self._phase_b2)]
+
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
         """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream."""
@@ -189,8 +192,13 @@ class PretrainStep(_GraphStep):
         eng.loss_launch(p, self.B, self.model.norm_pix_loss)
         eng.run(p.bwd_dec)
 
-    def _phase_b(self, K):
-        self.eng.run(self.eng.plan(self.B, K, True).bwd_enc)
+    def _make_sync(self, process_group):
+        lay = self.eng.layout   # decoder side | encoder thirds from the top (mae_engine.mae_bucket_fn)
+        return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
+
+    def _phases(self):
+        enc = lambda j: (lambda K: self.eng.run(self.eng.plan(self.B, K, True).bwd_enc[j]))
+        return [("a", self._phase_a), ("b", enc(0)), ("b2", enc(1)), ("b3", enc(2))]
 
     def load(self, imgs, ids_shuffle=None):
         cur = torch.cuda.current_stream(self.eng.device)

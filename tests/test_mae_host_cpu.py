@@ -45,20 +45,24 @@ def test_patchify_roundtrip_matches_oracle():
 
 def test_mae_layout_buckets_cover_all_trainable_parameters():
     from countr_amd.engine import ParamLayout, no_weight_decay
-    from countr_amd.mae_engine import mae_bucket, mae_trainable
+    from countr_amd.mae_engine import mae_bucket_fn, mae_trainable
     shapes = [(n, s) for n, s, _ in W.schema_mae()]
+    mae_bucket = mae_bucket_fn(12)
     lay = ParamLayout(shapes, trainable=mae_trainable, bucket=mae_bucket)
     assert lay.frozen_names == ["pos_embed", "decoder_pos_embed"]
-    b0, b1 = lay.bucket_range(0), lay.bucket_range(1)
-    assert b0[0] == 0 and b0[1] == b1[0] and b1[1] == lay.n_train                 # two contiguous RCCL buckets
+    rng = [lay.bucket_range(b) for b in range(4)]
+    assert rng[0][0] == 0 and rng[3][1] == lay.n_train and all(rng[b][1] == rng[b + 1][0] for b in range(3))   # contiguous RCCL buckets
+    assert mae_bucket("decoder_pred.weight") == 0 and mae_bucket("mask_token") == 0 and mae_bucket("norm.weight") == 1
+    assert [mae_bucket("blocks.%d.attn.qkv.weight" % i) for i in range(12)] == [3] * 4 + [2] * 4 + [1] * 4   # backward order
+    assert mae_bucket("patch_embed.proj.weight") == 3
     for n in lay.train_names:
         o = lay.off[n] - lay.train_start
-        lo, hi = (b0 if mae_bucket(n) == 0 else b1)
+        lo, hi = rng[mae_bucket(n)]
         assert lo <= o and o + int(np.prod(lay.shapes[n])) <= hi, n
         assert lay.off[n] % 64 == 0
-    # segments alternate (bucket, no-decay first); every trainable element is in exactly one AdamW range
+    # segments alternate (bucket, no-decay first); every trainable element is in exactly one AdamW range (<= 8 ranges)
     keys = [tuple(k) for k, _, _ in lay.segments]
-    assert keys == [(0, True), (0, False), (1, True), (1, False)]
+    assert keys == [(b, nd) for b in range(4) for nd in (True, False)]
     covered = sum(e - s for _, s, e in lay.segments)
     assert covered == lay.n_train
     for (bk, nodecay), s, e in lay.segments:
@@ -93,16 +97,16 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from countr_amd.engine import ParamLayout
-        from countr_amd.mae_engine import mae_bucket, mae_trainable
+        from countr_amd.mae_engine import mae_bucket_fn, mae_trainable
         from countr_amd.parallel import GradSync
-        lay = ParamLayout([(n, s) for n, s, _ in W.schema_mae("tiny_test")], trainable=mae_trainable, bucket=mae_bucket)
+        lay = ParamLayout([(n, s) for n, s, _ in W.schema_mae("tiny_test")], trainable=mae_trainable, bucket=mae_bucket_fn(2))
         n = lay.n_train
         mine = torch.randn(n, generator=torch.Generator().manual_seed(50 + rank), dtype=torch.float64)
         other = torch.randn(n, generator=torch.Generator().manual_seed(50 + (1 - rank)), dtype=torch.float64)
         flat = mine.clone()
-        b0 = lay.bucket_range(0)
-        sync = GradSync(flat, b0, (b0[1], n))
-        sync.start_bucket0()                       # decoder-side bucket: overlaps the encoder backward in PretrainStep
+        sync = GradSync(flat, None, None, buckets=[lay.bucket_range(b) for b in range(4)])
+        for b in range(3):                         # PretrainStep: bucket b starts while the next backward phase runs
+            sync.start(b)
         assert sync.grad_scale == 0.5
         sync.finish()
         assert torch.allclose(flat, mine + other, atol=1e-12)
