@@ -113,7 +113,7 @@ def main(args):
                 imgs, gt, _n, boxes, _pos, _m, _ids = next(it_data)
                 # loss mask: Bernoulli(0.8) per pixel, one mask per batch (FSC_finetune_cross.py:290-292)
                 mask = (torch.rand(384, 384, device=device, generator=loss_mask_gen) < 0.8).float()
-                imgs, gt, boxes = (t.to(device, non_blocking=True) for t in (imgs, gt, boxes))
+                # host tensors go straight to load(): it stages them over PCIe on a copy stream while the previous step computes
             else:
                 imgs, boxes, gt, mask = make_batch(args.batch_size, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
             step.load(imgs, boxes, gt, mask, S)

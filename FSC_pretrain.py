@@ -112,7 +112,7 @@ def main(args):
         for it in range(n_iter):
             lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)        # :258-259
             if it_data is not None:
-                imgs = next(it_data).to(device, non_blocking=True)
+                imgs = next(it_data)     # host tensor: load() stages it over PCIe on a copy stream while the previous step computes
             else:
                 imgs = torch.rand(args.batch_size, 3, 384, 384, device=device, generator=g)
             step.load(imgs)

@@ -45,6 +45,39 @@ class _GraphStep:
     def _make_sync(self, process_group):
         return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
 
+    def _to_device(self, tensors):
+        """Host batches (the DataLoader's pinned tensors) go host -> device on a dedicated copy stream into staging buffers, so the
+        PCIe transfer of batch t+1 overlaps the compute of step t; the step stream then only does device-to-device copies into
+        the plan's input buffers.  Device tensors pass through.  Returns device tensors valid on the step's stream."""
+        if all(t.is_cuda for t in tensors):
+            return tensors
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream = torch.cuda.Stream(device=self.eng.device)
+            self._staging = {}
+            self._staged_ev = torch.cuda.Event()
+            self._consumed_ev = None
+        out = []
+        with torch.cuda.stream(self._copy_stream):
+            if self._consumed_ev is not None:
+                self._copy_stream.wait_event(self._consumed_ev)      # the previous batch has been copied out of the staging
+            for i, t in enumerate(tensors):
+                if t.is_cuda:
+                    out.append(t)
+                    continue
+                key = (i, tuple(t.shape), t.dtype)
+                if key not in self._staging:
+                    self._staging[key] = torch.empty(t.shape, dtype=t.dtype, device=self.eng.device)
+                self._staging[key].copy_(t, non_blocking=True)
+                out.append(self._staging[key])
+            self._staged_ev.record(self._copy_stream)
+        self.stream.wait_event(self._staged_ev)
+        return out
+
+    def _staging_consumed(self):
+        if hasattr(self, "_copy_stream"):
+            self._consumed_ev = torch.cuda.Event()
+            self._consumed_ev.record(self.stream)
+
     def _phases(self):          # [(graph key, launcher)]: forward + loss + first backward part, then the remaining backward parts
         return [("a", self._phase_a), ("b", self._phase_b)]
 
@@ -155,12 +188,15 @@ class FinetuneStep(_GraphStep):
         """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream."""
         cur = torch.cuda.current_stream(self.eng.device)
         self.stream.wait_stream(cur)           # producers of the inputs ran on the caller's stream
+        src = (imgs, boxes, gt, mask)
+        imgs, boxes, gt, mask = self._to_device(src)
         with torch.cuda.stream(self.stream):
             p = self.eng.plan(self.B, S, True)
             self.eng._load_inputs(p, imgs, boxes, S)
             self.gt.copy_(gt, non_blocking=True)
             self.mask.copy_(mask, non_blocking=True)
-        for t in (imgs, boxes, gt, mask):      # their memory must not be recycled before our copies have run
+            self._staging_consumed()
+        for t in src:                          # their memory must not be recycled before our copies have run
             if t.is_cuda:
                 t.record_stream(self.stream)
 
@@ -203,14 +239,17 @@ class PretrainStep(_GraphStep):
     def load(self, imgs, ids_shuffle=None):
         cur = torch.cuda.current_stream(self.eng.device)
         self.stream.wait_stream(cur)
+        src = imgs
+        (imgs,) = self._to_device((imgs,))
         with torch.cuda.stream(self.stream):
             p = self.eng.plan(self.B, self.K, True)
             p.buf["img"].copy_(imgs, non_blocking=True)
+            self._staging_consumed()
             if ids_shuffle is None:
                 ids_shuffle = self.model.draw_masking(self.B, self.eng.device)
             self.eng.set_masking(p, ids_shuffle)
-        if imgs.is_cuda:
-            imgs.record_stream(self.stream)
+        if src.is_cuda:
+            src.record_stream(self.stream)
 
     def step(self, lr=None):
         """One optimisation step on the batch last given to load(); returns the device loss tensor [1] (no host sync).
