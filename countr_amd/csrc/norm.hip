@@ -3,6 +3,7 @@
 //   GroupNorm(8)+ReLU      : decode_head*                     models_mae_cross.py:80-100   (NHWC maps)
 //   InstanceNorm+ReLU+pool : decoder_proj1-4                  models_mae_cross.py:47-71    (NHWC maps)
 #include "common.cuh"
+#include <stdlib.h>
 #include "../../include/countr_hip.h"
 
 namespace {
@@ -442,30 +443,35 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restr
 // InstanceNorm2d (affine=False, eps, biased var) + ReLU + MaxPool2 (or global average pool) on NHWC
 // [S, H, W, C].  One block per (sample, 64-channel chunk): thread = (8-channel vector, pixel slot).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float reduce_same_cv8(float v, float* sm /* [4][8] */) {
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+// sum over the threads of a 256-thread block that share (threadIdx.x % NCV); every thread gets its group's sum
+template <int NCV>
+__device__ __forceinline__ float reduce_same_cv(float v, float* sm /* [4][NCV] */) {
+#pragma unroll
+  for (int o = NCV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
-  if (lane < 8) sm[wave * 8 + lane] = v;
+  if (lane < NCV) sm[wave * NCV + lane] = v;
   __syncthreads();
-  return sm[threadIdx.x & 7] + sm[8 + (threadIdx.x & 7)] + sm[16 + (threadIdx.x & 7)] + sm[24 + (threadIdx.x & 7)];
+  const int c = threadIdx.x % NCV;
+  return sm[c] + sm[NCV + c] + sm[2 * NCV + c] + sm[3 * NCV + c];
 }
 
-template <typename T>
+// NCV = 8-channel vectors per block: 8 (64 channels, 32 pixel slots) or 1 (8 channels, 256 pixel slots: 8x the blocks for the
+// 64- and 128-channel layers, whose (C/64, S) grid leaves most CUs idle)
+template <typename T, int NCV>
 __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                float* __restrict__ stats /* [S][C][2] */, int H, int W, int C,
                                                                int avgpool, float eps) {
   __shared__ float sm[32];
-  const int s = blockIdx.y, c0 = blockIdx.x * 64;
-  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;  // 32 pixel slots
+  const int s = blockIdx.y, c0 = blockIdx.x * (NCV * 8);
+  constexpr int NSLOT = 256 / NCV;
+  const int cv = threadIdx.x % NCV, slot = threadIdx.x / NCV;
   const int HW = H * W;
   const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
   float sum[8], sq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
-  for (int p = slot; p < HW; p += 32) {
+  for (int p = slot; p < HW; p += NSLOT) {
     float v[8];
     ld8<T>(xs + (int64_t)p * C, v);
 #pragma unroll
@@ -473,15 +479,15 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
   }
   float mean[8], rstd[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mean[e] = reduce_same_cv8(sum[e], sm) / HW;
-  for (int p = slot; p < HW; p += 32) {
+  for (int e = 0; e < 8; ++e) mean[e] = reduce_same_cv<NCV>(sum[e], sm) / HW;
+  for (int p = slot; p < HW; p += NSLOT) {
     float v[8];
     ld8<T>(xs + (int64_t)p * C, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float d = v[e] - mean[e]; sq[e] += d * d; }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) rstd[e] = rsqrtf(reduce_same_cv8(sq[e], sm) / HW + eps);
+  for (int e = 0; e < 8; ++e) rstd[e] = rsqrtf(reduce_same_cv<NCV>(sq[e], sm) / HW + eps);
   if (slot == 0 && stats) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
   if (!avgpool) {
     const int Ho = H / 2, Wo = W / 2;
     T* ys = y + (int64_t)s * Ho * Wo * C + c0 + cv * 8;
-    for (int po = slot; po < Ho * Wo; po += 32) {
+    for (int po = slot; po < Ho * Wo; po += NSLOT) {
       const int oy = po / Wo, ox = po - oy * Wo;
       float m[8];
 #pragma unroll
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int p = slot; p < HW; p += 32) {
+    for (int p = slot; p < HW; p += NSLOT) {
       float v[8];
       ld8<T>(xs + (int64_t)p * C, v);
 #pragma unroll
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
     }
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = reduce_same_cv8(acc[e], sm) / HW;
+    for (int e = 0; e < 8; ++e) o[e] = reduce_same_cv<NCV>(acc[e], sm) / HW;
     if (slot == 0) st8<T>(y + (int64_t)s * C + c0 + cv * 8, o);
   }
 }
@@ -526,13 +532,14 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
 // Backward of the same block: dyp is the gradient of the pooled output ([S,H/2,W/2,C] or [S,C]).
 // g = routed gradient (first max of the 2x2 window as in torch, or dy/HW for the average pool),
 // gated by relu; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)).
-template <typename T>
+template <typename T, int NCV>
 __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
                                                                const float* __restrict__ stats, T* __restrict__ dx, int H,
                                                                int W, int C, int avgpool) {
   __shared__ float sm[32];
-  const int s = blockIdx.y, c0 = blockIdx.x * 64;
-  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int s = blockIdx.y, c0 = blockIdx.x * (NCV * 8);
+  constexpr int NSLOT = 256 / NCV;
+  const int cv = threadIdx.x % NCV, slot = threadIdx.x / NCV;
   const int HW = H * W, Ho = H / 2, Wo = W / 2;
   const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
   T* dxs = dx + (int64_t)s * HW * C + c0 + cv * 8;
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
   }
   // pass 1: sums of g and g*xhat.  Work is organised per pooled window (4 input pixels).
   const int nwin = avgpool ? HW : Ho * Wo;
-  for (int po = slot; po < nwin; po += 32) {
+  for (int po = slot; po < nwin; po += NSLOT) {
     if (avgpool) {
       float v[8];
       ld8<T>(xs + (int64_t)po * C, v);
@@ -586,11 +593,11 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    s1[e] = reduce_same_cv8(s1[e], sm) / HW;
-    s2[e] = reduce_same_cv8(s2[e], sm) / HW;
+    s1[e] = reduce_same_cv<NCV>(s1[e], sm) / HW;
+    s2[e] = reduce_same_cv<NCV>(s2[e], sm) / HW;
   }
   // pass 2: write dx
-  for (int po = slot; po < nwin; po += 32) {
+  for (int po = slot; po < nwin; po += NSLOT) {
     if (avgpool) {
       float v[8], o[8];
       ld8<T>(xs + (int64_t)po * C, v);
@@ -676,7 +683,14 @@ extern "C" int countr_colsum_partials(const float* partial, float* out, int npar
   COUNTR_LAUNCH_CHECK("countr_colsum_partials");
 }
 
-static int gn_splits(int HW) { int ns = HW / 576; if (ns < 1) ns = 1; if (ns > 64) ns = 64; return ns; }
+// pixel splits of the GroupNorm statistics / backward reductions: enough blocks to hide the cold-miss latency of the small
+// maps (24x24: 4 splits, 48x48: 16; bwd 38 -> 21 us, 56 -> 35 us) without multiplying the partials of the big ones
+// (96x96: 16, 192x192: 64; more splits there were measured slower)
+static int gn_splits(int HW) {
+  const int a = HW / 144 < 16 ? HW / 144 : 16, b = HW / 576 < 64 ? HW / 576 : 64;
+  const int ns = a > b ? a : b;
+  return ns < 1 ? 1 : ns;
+}
 extern "C" int countr_groupnorm_nsplit(int HW) { return gn_splits(HW); }
 
 extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
@@ -729,20 +743,30 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_bwd");
 }
 
+// 8-channel blocks only pay for the 64-channel layer (S blocks otherwise; 57.6 -> 43.9 us forward at S = 24): with more channels
+// the 16-byte-per-row accesses cost more than the extra blocks bring (C = 128: 18.6 -> 19.7 us, backward 15.7 -> 24 us)
+static bool in_narrow(int C, int S) { return C == 64 && S < 128; }
+
 extern "C" int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C, int avgpool,
                                              float eps, int dtype, void* stream) {
   if (!x || !y || C % 64 || (H & 1) || (W & 1)) { countr_set_error("countr_instnorm_relu_pool_fwd: bad args (C % 64, even H/W)"); return -1; }
-  dim3 grid(C / 64, S), block(256);
-  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(in_relu_pool_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, stats, H, W, C, avgpool, eps);
-  else hipLaunchKernelGGL(in_relu_pool_fwd_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, (float*)y, stats, H, W, C, avgpool, eps);
+  const bool narrow = in_narrow(C, S);
+  dim3 grid(narrow ? C / 8 : C / 64, S), block(256);
+#define IN_FWD(TT, NCVV) hipLaunchKernelGGL((in_relu_pool_fwd_kernel<TT, NCVV>), grid, block, 0, STREAM(stream), (const TT*)x, (TT*)y, stats, H, W, C, avgpool, eps)
+  if (dtype == COUNTR_BF16) { if (narrow) IN_FWD(bf16_t, 1); else IN_FWD(bf16_t, 8); }
+  else { if (narrow) IN_FWD(float, 1); else IN_FWD(float, 8); }
+#undef IN_FWD
   COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_fwd");
 }
 
 extern "C" int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H, int W,
                                              int C, int avgpool, int dtype, void* stream) {
   if (!x || !dyp || !stats || !dx || C % 64) { countr_set_error("countr_instnorm_relu_pool_bwd: bad args"); return -1; }
-  dim3 grid(C / 64, S), block(256);
-  if (dtype == COUNTR_BF16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, (bf16_t*)dx, H, W, C, avgpool);
-  else hipLaunchKernelGGL(in_relu_pool_bwd_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, (float*)dx, H, W, C, avgpool);
+  const bool narrow = in_narrow(C, S);
+  dim3 grid(narrow ? C / 8 : C / 64, S), block(256);
+#define IN_BWD(TT, NCVV) hipLaunchKernelGGL((in_relu_pool_bwd_kernel<TT, NCVV>), grid, block, 0, STREAM(stream), (const TT*)x, (const TT*)dyp, stats, (TT*)dx, H, W, C, avgpool)
+  if (dtype == COUNTR_BF16) { if (narrow) IN_BWD(bf16_t, 1); else IN_BWD(bf16_t, 8); }
+  else { if (narrow) IN_BWD(float, 1); else IN_BWD(float, 8); }
+#undef IN_BWD
   COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_bwd");
 }
