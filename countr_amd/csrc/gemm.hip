@@ -808,11 +808,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
   // consecutive columns nb .. nb+15 (acc[tm][tn][reg] -> column nb + tn*4 + reg).
   const int gq = lane >> 4;
   const int nb = n0 + wn0 + gq * 16;
+  if (split) {
 #pragma unroll
-  for (int tm = 0; tm < TMW; ++tm) {
-    const int m = m0 + mrow(tm);
-    if (m >= g.M) continue;
-    if (split) {
+    for (int tm = 0; tm < TMW; ++tm) {
+      const int m = m0 + mrow(tm);
+      if (m >= g.M) continue;
       float* dst = g.partial + ((int64_t)z * g.M + m) * g.N + nb;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
@@ -821,46 +821,77 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           st4<float>(dst + tn * 4, v);
         }
       }
-      continue;
     }
-    const int64_t crow = offC + (int64_t)m * g.ldc;
-    const float* rrow = nullptr;
-    if (g.resid) rrow = g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres;
+    return;
+  }
+  // The epilogue is instantiated for the option combinations the engines use (bias / residual / GELU / output type as
+  // compile-time flags) plus one fully general version: with every option tested at run time inside the (row, column) loops the
+  // compiler produced ~4400 instructions of branches and waits, and a plain bias add cost 9 us on a 30-us GEMM.
+  auto epilogue = [&](auto BIAS_, auto RESID_, auto ACT_, auto OBF_, auto GENERIC_) {
+    constexpr bool GENERIC = decltype(GENERIC_)::value;
+    constexpr bool BIASC = decltype(BIAS_)::value, RESIDC = decltype(RESID_)::value, OBFC = decltype(OBF_)::value;
+    constexpr int ACTC = decltype(ACT_)::value;
+    const bool has_bias = GENERIC ? (g.bias != nullptr) : BIASC;
+    const bool has_resid = GENERIC ? (g.resid != nullptr) : RESIDC;
+    const int act = GENERIC ? g.act : ACTC;
+    const bool obf = GENERIC ? (g.out_bf16 != 0) : OBFC;
+    float bv[4][4];
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
-      const int n = nb + tn * 4;
-      if (n >= g.N) continue;
-      float v[4] = {acc[tm][tn][0] * g.alpha, acc[tm][tn][1] * g.alpha, acc[tm][tn][2] * g.alpha,
-                    acc[tm][tn][3] * g.alpha};
-      if (g.bias) {
-        float b[4];
-        ld4<float>(g.bias + n, b);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b[e];
-      }
-      if (g.act == COUNTR_ACT_GELU_BWD) {   // dgrad of fc2 fused with GELU': C2 is the saved pre-activation (INPUT, layout of C)
-        float h[4];
-        if (g.out_bf16) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(g.C2) + crow + n, h);
-        else ld4<float>(reinterpret_cast<const float*>(g.C2) + crow + n, h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(h[e]);
-      } else if (g.C2) {
-        if (g.out_bf16) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C2) + crow + n, v);
-        else st4<float>(reinterpret_cast<float*>(g.C2) + crow + n, v);
-      }
-      if (g.act == COUNTR_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
-      }
-      if (rrow) {
-        float r[4];
-        ld4<float>(rrow + n, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += r[e];
-      }
-      if (g.out_bf16) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + crow + n, v);
-      else st4<float>(reinterpret_cast<float*>(g.C) + crow + n, v);
+      bv[tn][0] = bv[tn][1] = bv[tn][2] = bv[tn][3] = 0.f;
+      if (has_bias && nb + tn * 4 < g.N) ld4<float>(g.bias + nb + tn * 4, bv[tn]);
     }
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm) {
+      const int m = m0 + mrow(tm);
+      if (m >= g.M) continue;
+      const int64_t crow = offC + (int64_t)m * g.ldc;
+      const float* rrow = has_resid ? g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres : nullptr;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = nb + tn * 4;
+        if (n >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[tm][tn][e] * g.alpha + bv[tn][e];
+        if (act == COUNTR_ACT_GELU_BWD) {   // dgrad of fc2 fused with GELU': C2 is the saved pre-activation (INPUT, layout of C)
+          float h[4];
+          if (obf) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(g.C2) + crow + n, h);
+          else ld4<float>(reinterpret_cast<const float*>(g.C2) + crow + n, h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(h[e]);
+        } else if (g.C2) {                  // pre-activation copy (training fc1): rare, tested at run time in every version
+          if (obf) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C2) + crow + n, v);
+          else st4<float>(reinterpret_cast<float*>(g.C2) + crow + n, v);
+        }
+        if (act == COUNTR_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+        }
+        if (has_resid) {
+          float r[4];
+          ld4<float>(rrow + n, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        if (obf) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + crow + n, v);
+        else st4<float>(reinterpret_cast<float*>(g.C) + crow + n, v);
+      }
+    }
+  };
+  using std::true_type; using std::false_type;
+  using A0 = std::integral_constant<int, COUNTR_ACT_NONE>; using A1 = std::integral_constant<int, COUNTR_ACT_GELU>;
+  const bool hb = g.bias != nullptr, hr = g.resid != nullptr;
+  if (g.out_bf16) {
+    if (g.act == COUNTR_ACT_NONE && !hr) { if (hb) epilogue(true_type{}, false_type{}, A0{}, true_type{}, false_type{}); else epilogue(false_type{}, false_type{}, A0{}, true_type{}, false_type{}); }
+    else if (g.act == COUNTR_ACT_GELU && hb && !hr) epilogue(true_type{}, false_type{}, A1{}, true_type{}, false_type{});
+    else epilogue(false_type{}, false_type{}, A0{}, false_type{}, true_type{});
+  } else {
+    if (g.act == COUNTR_ACT_NONE && hb && hr) epilogue(true_type{}, true_type{}, A0{}, false_type{}, false_type{});
+    else if (g.act == COUNTR_ACT_NONE && hb && !hr) epilogue(true_type{}, false_type{}, A0{}, false_type{}, false_type{});
+    else if (g.act == COUNTR_ACT_NONE && !hb && !hr) epilogue(false_type{}, false_type{}, A0{}, false_type{}, false_type{});
+    else if (g.act == COUNTR_ACT_NONE && !hb && hr) epilogue(false_type{}, true_type{}, A0{}, false_type{}, false_type{});
+    else epilogue(false_type{}, false_type{}, A0{}, false_type{}, true_type{});
   }
 }
 
@@ -898,27 +929,19 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * zdim;
       const long t128x256 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256) * zdim;
       int tile = ftile;
-      // measured (tools/bench_gemm.py, COUNTR_GEMM_TILE=22|24|42|88): plain 256-wide tiles lose to 128x128 with this loop
-      // structure (one workgroup per CU, too few tiles at M = 4608), so 22 stays the default
+      // measured (tools/bench_gemm.py): plain 256-wide tiles lose to 128x128 with this loop structure (one workgroup per CU,
+      // too few tiles at M = 4608), so 128x128 stays the default
       (void)t256; (void)t128x256;
       // ... except on very large grids (the 192x192 density-head convolutions, 4608 tiles): there a 128x256 tile with 8 compute +
       // 4 loader waves on a 3-stage ring wins (358 vs 395 us, 0.97 PF/s); at <= ~1000 tiles it loses to the tail.
       static const int big = [] { const char* e = getenv("COUNTR_GEMM_BIGTILE"); return e ? atoi(e) : 4096; }();
       if (!tile) tile = (t128 >= big && a.N >= 256) ? 124 : 22;
-      if (tile == 88) return launch_variant<T, MA, MB, 2, 2, 4, 8>(a, s);   // 256x256, 8 waves x (128x64)
       if (tile == 124) return launch_variant<T, MA, MB, 3, 2, 4, 4, 4>(a, s);   // 128x256, 8 compute + 4 loader waves, 3-stage ring
-      if (tile == 24) return launch_variant<T, MA, MB, 2, 2, 4>(a, s);
-      if (tile == 42) return launch_variant<T, MA, MB, 2, 4, 2>(a, s);
     }
-    if constexpr (is_rowlike(MA)) {
-      if (ftile == 12) return force >= 3 ? launch_variant<T, MA, MB, 4, 1, 2>(a, s) : launch_variant<T, MA, MB, 2, 1, 2>(a, s);
-    }
-    if (force == 1) return launch_variant<T, MA, MB, 1, 2, 2>(a, s);
+    // tuning aids (the other variants this round measured -- 1/3/4 LDS stages, 64x128 / 256x128 / 256x256 tiles, a 4-stage and a
+    // 2-workgroup specialised ring -- lost everywhere and were removed to keep the build short; DESIGN.md section 7 has the numbers)
     if (force == 2) return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
-    if (force == 3) return launch_variant<T, MA, MB, 3, 2, 2>(a, s);
-    if (force == 4) return launch_variant<T, MA, MB, 4, 2, 2>(a, s);
     if (force == 6) return launch_variant<T, MA, MB, 3, 2, 2, 4, 4>(a, s);   // loader/compute wave specialisation, 3-stage ring
-    if (force == 7) return launch_variant<T, MA, MB, 4, 2, 2, 4, 4>(a, s);
     // Double-buffered everywhere: since the fragment reads are opaque to the compiler (no implicit vmcnt(0) in front of
     // them) tile t+1 really streams in under tile t's MFMAs, and the single-stage variant loses on every measured shape
     // (tools/bench_gemm.py: conv wgrad 192x192 502 vs 681 us, conv fwd 429 vs 467 us).
