@@ -71,3 +71,27 @@ def test_pretrain_cli_on_files_and_synthetic_fallback(fake_fsc, tmp_path):
     assert "With optim & sched!" in log
     lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
     assert [l["epoch"] for l in lines] == [1, 1]
+
+
+def test_bench_contract_line():
+    """bench.py prints exactly one JSON line with the driver's contract keys, the roofline and (at N = 1) the CPU baseline."""
+    out = run(["bench.py", "--steps", "3", "--warmup", "2"])
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 2 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["vs_baseline"] is None and j["dtype"] == "bf16" and j["data"] == "synthetic" and j["unit"] == "images/sec"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 8 * 1e3 / j["ms_per_step"]) < 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak"] == 2500.0 and 0.02 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 0)
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/sec" and c["sample"]
+    # the pretraining workload is selected explicitly and is labelled as such
+    out = run(["bench.py", "--workload", "pretrain", "--steps", "2", "--warmup", "2"])
+    p = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert "pretrain" in p["metric"] and p["value"] > 0 and p["n_gpus"] == 1
