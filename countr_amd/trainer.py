@@ -15,8 +15,8 @@ from .parallel import GradSync
 
 
 class _GraphStep:
-    """Shared machinery of the optimisation steps: dedicated stream, per-phase hipGraph capture/replay, two-bucket gradient
-    all-reduce, device-side AdamW scalars."""
+    """Shared machinery of the optimisation steps: dedicated stream, per-phase hipGraph capture/replay, bucketed gradient
+    all-reduce behind the backward phases, host-batch staging on a copy stream, device-side AdamW scalars."""
 
     def __init__(self, model, batch, lr, weight_decay, betas, eps, use_graph, process_group):
         self.model = model

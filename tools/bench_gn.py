@@ -31,3 +31,12 @@ for H, Cc, avg in ((64, 64, 0), (32, 128, 0), (16, 256, 0), (8, 512, 1)):
     f = lambda: L.countr_instnorm_relu_pool_fwd(P(x), P(y), P(stats), S, H, H, Cc, avg, 1e-5, 1, st())
     bw = lambda: L.countr_instnorm_relu_pool_bwd(P(x), P(dyp), P(stats), P(dx), S, H, H, Cc, avg, 1, st())
     print("IN %2dx%2d C%3d: fwd %6.1f us   bwd %6.1f us" % (H, H, Cc, timeit(f), timeit(bw)), flush=True)
+# first exemplar conv (3 -> 64, direct) forward / wgrad
+S, H = 24, 64
+x = torch.rand(S, 3, H, H, device="cuda"); w = torch.randn(64, 3, 3, 3, device="cuda") * 0.1; b = torch.zeros(64, device="cuda")
+y = torch.empty(S, H, H, 64, device="cuda", dtype=torch.bfloat16); dy = torch.randn(S, H, H, 64, device="cuda").bfloat16()
+dw = torch.empty(64, 27, device="cuda"); dbias = torch.empty(64, device="cuda")
+ws = torch.empty(L.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28, device="cuda")
+f = lambda: L.countr_conv3x3_c3_fwd(P(x), P(w), P(b), P(y), S, H, H, 1, st())
+bw = lambda: L.countr_conv3x3_c3_wgrad(P(x), P(dy), P(dw), P(dbias), P(ws), S, H, H, 1, 0, st())
+print("conv 3->64 64x64 x24: fwd %6.1f us   wgrad %6.1f us" % (timeit(f), timeit(bw)), flush=True)
