@@ -186,6 +186,27 @@ __device__ __forceinline__ float reduce_same_chanvec(float v, float* sm /* [8][3
   return r;
 }
 
+// the same for NV values at once: two barriers in total instead of two per value (a block's reduction tail was 32-48 barriers)
+template <int NV>
+__device__ __forceinline__ void reduce_vec_same_chanvec(float (&v)[NV], float* sm /* [4][32][NV] */) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm[(wave * 32 + lane) * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) r += sm[(w * 32 + (threadIdx.x & 31)) * NV + i];
+    v[i] = r;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part /* [B][ns][G][2] */,
                                                        int HW, int G) {
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ partial,
                                                                  int HW, int G) {
-  __shared__ float sm[128];
+  __shared__ float smv[4 * 32 * 8];
   const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
   const int per = (HW + ns - 1) / ns;
   const int p0 = split * per, p1 = min(HW, p0 + per);
@@ -357,15 +378,15 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
     }
   }
   float* o = partial + ((int64_t)b * ns + split) * 3 * GN_C;
+  reduce_vec_same_chanvec<8>(sg, smv);
+  reduce_vec_same_chanvec<8>(sgx, smv);
+  if (w1) reduce_vec_same_chanvec<8>(sw, smv);
+  if (threadIdx.x < 32) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float a = reduce_same_chanvec(sg[e], sm);
-    const float c = reduce_same_chanvec(sgx[e], sm);
-    const float d = w1 ? reduce_same_chanvec(sw[e], sm) : 0.f;
-    if (threadIdx.x < 32) {
-      o[cv * 8 + e] = a;
-      o[GN_C + cv * 8 + e] = c;
-      o[2 * GN_C + cv * 8 + e] = d;
+    for (int e = 0; e < 8; ++e) {
+      o[cv * 8 + e] = sg[e];
+      o[GN_C + cv * 8 + e] = sgx[e];
+      o[2 * GN_C + cv * 8 + e] = w1 ? sw[e] : 0.f;
     }
   }
 }
@@ -443,17 +464,25 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restr
 // InstanceNorm2d (affine=False, eps, biased var) + ReLU + MaxPool2 (or global average pool) on NHWC
 // [S, H, W, C].  One block per (sample, 64-channel chunk): thread = (8-channel vector, pixel slot).
 // ------------------------------------------------------------------------------------------
-// sum over the threads of a 256-thread block that share (threadIdx.x % NCV); every thread gets its group's sum
+// sums over the threads of a 256-thread block that share (threadIdx.x % NCV), for 8 values at once (two barriers in total);
+// every thread gets its group's sums
 template <int NCV>
-__device__ __forceinline__ float reduce_same_cv(float v, float* sm /* [4][NCV] */) {
+__device__ __forceinline__ void reduce8_same_cv(float (&v)[8], float* sm /* [4][NCV][8] */) {
 #pragma unroll
-  for (int o = NCV; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int o = NCV; o < 64; o <<= 1) v[i] += __shfl_xor(v[i], o, 64);
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
-  if (lane < NCV) sm[wave * NCV + lane] = v;
+  if (lane < NCV) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[(wave * NCV + lane) * 8 + i] = v[i];
+  }
   __syncthreads();
   const int c = threadIdx.x % NCV;
-  return sm[c] + sm[NCV + c] + sm[2 * NCV + c] + sm[3 * NCV + c];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = sm[c * 8 + i] + sm[(NCV + c) * 8 + i] + sm[(2 * NCV + c) * 8 + i] + sm[(3 * NCV + c) * 8 + i];
 }
 
 // NCV = 8-channel vectors per block: 8 (64 channels, 32 pixel slots) or 1 (8 channels, 256 pixel slots: 8x the blocks for the
@@ -462,7 +491,7 @@ template <typename T, int NCV>
 __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                float* __restrict__ stats /* [S][C][2] */, int H, int W, int C,
                                                                int avgpool, float eps) {
-  __shared__ float sm[32];
+  __shared__ float sm[4 * 8 * 8];
   const int s = blockIdx.y, c0 = blockIdx.x * (NCV * 8);
   constexpr int NSLOT = 256 / NCV;
   const int cv = threadIdx.x % NCV, slot = threadIdx.x / NCV;
@@ -478,16 +507,18 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
     for (int e = 0; e < 8; ++e) sum[e] += v[e];
   }
   float mean[8], rstd[8];
+  reduce8_same_cv<NCV>(sum, sm);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mean[e] = reduce_same_cv<NCV>(sum[e], sm) / HW;
+  for (int e = 0; e < 8; ++e) mean[e] = sum[e] / HW;
   for (int p = slot; p < HW; p += NSLOT) {
     float v[8];
     ld8<T>(xs + (int64_t)p * C, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float d = v[e] - mean[e]; sq[e] += d * d; }
   }
+  reduce8_same_cv<NCV>(sq, sm);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) rstd[e] = rsqrtf(reduce_same_cv<NCV>(sq[e], sm) / HW + eps);
+  for (int e = 0; e < 8; ++e) rstd[e] = rsqrtf(sq[e] / HW + eps);
   if (slot == 0 && stats) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -523,8 +554,9 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
       for (int e = 0; e < 8; ++e) acc[e] += fmaxf((v[e] - mean[e]) * rstd[e], 0.f);
     }
     float o[8];
+    reduce8_same_cv<NCV>(acc, sm);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = reduce_same_cv<NCV>(acc[e], sm) / HW;
+    for (int e = 0; e < 8; ++e) o[e] = acc[e] / HW;
     if (slot == 0) st8<T>(y + (int64_t)s * C + c0 + cv * 8, o);
   }
 }
@@ -536,7 +568,7 @@ template <typename T, int NCV>
 __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
                                                                const float* __restrict__ stats, T* __restrict__ dx, int H,
                                                                int W, int C, int avgpool) {
-  __shared__ float sm[32];
+  __shared__ float sm[4 * 8 * 8];
   const int s = blockIdx.y, c0 = blockIdx.x * (NCV * 8);
   constexpr int NSLOT = 256 / NCV;
   const int cv = threadIdx.x % NCV, slot = threadIdx.x / NCV;
@@ -591,11 +623,10 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
       }
     }
   }
+  reduce8_same_cv<NCV>(s1, sm);
+  reduce8_same_cv<NCV>(s2, sm);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    s1[e] = reduce_same_cv<NCV>(s1[e], sm) / HW;
-    s2[e] = reduce_same_cv<NCV>(s2[e], sm) / HW;
-  }
+  for (int e = 0; e < 8; ++e) { s1[e] /= HW; s2[e] /= HW; }
   // pass 2: write dx
   for (int po = slot; po < nwin; po += NSLOT) {
     if (avgpool) {
