@@ -669,6 +669,171 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
   }
 }
 
+
+// ---- pixel-band variants for the wide maps of the first exemplar layers ((C/64) x S blocks leave most CUs idle and one CU cannot
+// stream a 0.5-MB sample fast enough): the map is cut into NS bands of pooled rows; band statistics are combined with Chan's
+// formula (forward) or plain sums (backward) by every block of the second kernel.  partial layout: [S][C/64][NS][2][64] floats.
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_split_kernel(const T* __restrict__ x, float* __restrict__ partial, int H, int W, int C) {
+  __shared__ float sm[4 * 8 * 8];
+  const int s = blockIdx.y, cb = blockIdx.x, split = blockIdx.z, NS = gridDim.z;
+  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int rows = H / NS, p0 = split * rows * W, n = rows * W;
+  const T* xs = x + ((int64_t)s * H * W + p0) * C + cb * 64 + cv * 8;
+  float sum[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
+  for (int p = slot; p < n; p += 32) {
+    float v[8];
+    ld8<T>(xs + (int64_t)p * C, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] += v[e];
+  }
+  reduce8_same_cv<8>(sum, sm);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum[e] /= n;   // band mean
+  for (int p = slot; p < n; p += 32) {
+    float v[8];
+    ld8<T>(xs + (int64_t)p * C, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - sum[e]; sq[e] += d * d; }
+  }
+  reduce8_same_cv<8>(sq, sm);
+  if (slot == 0) {
+    float* o = partial + ((((int64_t)s * gridDim.x + cb) * NS + split) * 2) * 64 + cv * 8;
+    st8<float>(o, sum);
+    st8<float>(o + 64, sq);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_split_kernel(const T* __restrict__ x, const float* __restrict__ partial, T* __restrict__ y,
+                                                             float* __restrict__ stats, int H, int W, int C, float eps) {
+  const int s = blockIdx.y, cb = blockIdx.x, split = blockIdx.z, NS = gridDim.z;
+  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int HW = H * W, n = HW / NS;
+  const float* pp = partial + (((int64_t)s * gridDim.x + cb) * NS * 2) * 64 + cv * 8;
+  float mean[8], rstd[8], m2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mean[e] = 0.f; m2[e] = 0.f; }
+  for (int q = 0; q < NS; ++q) {
+    float a[8];
+    ld8<float>(pp + q * 128, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mean[e] += a[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mean[e] /= NS;
+  for (int q = 0; q < NS; ++q) {
+    float a[8], b[8];
+    ld8<float>(pp + q * 128, a);
+    ld8<float>(pp + q * 128 + 64, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = a[e] - mean[e]; m2[e] += b[e] + n * d * d; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rstd[e] = rsqrtf(m2[e] / HW + eps);
+  const int c0 = cb * 64;
+  if (split == 0 && slot == 0 && stats) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      stats[((int64_t)s * C + c0 + cv * 8 + e) * 2] = mean[e];
+      stats[((int64_t)s * C + c0 + cv * 8 + e) * 2 + 1] = rstd[e];
+    }
+  }
+  const int Ho = H / 2, Wo = W / 2, orow = Ho / NS;
+  const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  T* ys = y + (int64_t)s * Ho * Wo * C + c0 + cv * 8;
+  for (int po = split * orow * Wo + slot; po < (split + 1) * orow * Wo; po += 32) {
+    const int oy = po / Wo, ox = po - oy * Wo;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = 0.f;  // relu floor
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[8];
+      ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (v[e] - mean[e]) * rstd[e]);
+    }
+    st8<T>(ys + (int64_t)po * C, m);
+  }
+}
+
+// backward, max-pool case only: APPLY = false -> band sums of g and g * xhat; true -> dx of the band
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void in_bwd_split_kernel(const T* __restrict__ x, const T* __restrict__ dyp, const float* __restrict__ stats,
+                                                           float* __restrict__ partial, T* __restrict__ dx, int H, int W, int C) {
+  __shared__ float sm[4 * 8 * 8];
+  const int s = blockIdx.y, cb = blockIdx.x, split = blockIdx.z, NS = gridDim.z;
+  const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3, c0 = cb * 64;
+  const int HW = H * W, Ho = H / 2, Wo = W / 2, orow = Ho / NS;
+  const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  T* dxs = dx + (int64_t)s * HW * C + c0 + cv * 8;
+  float mean[8], rstd[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mean[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2];
+    rstd[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2 + 1];
+    s1[e] = 0.f; s2[e] = 0.f;
+  }
+  float* pp = partial + (((int64_t)s * gridDim.x + cb) * NS * 2) * 64 + cv * 8;
+  if (APPLY) {
+    for (int q = 0; q < NS; ++q) {
+      float a[8], b[8];
+      ld8<float>(pp + q * 128, a);
+      ld8<float>(pp + q * 128 + 64, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += a[e]; s2[e] += b[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] /= HW; s2[e] /= HW; }
+  }
+  for (int po = split * orow * Wo + slot; po < (split + 1) * orow * Wo; po += 32) {
+    const int oy = po / Wo, ox = po - oy * Wo;
+    float d[8], v[4][8], best[8];
+    int arg[8];
+    ld8<T>(dyp + ((int64_t)s * Ho * Wo + po) * C + c0 + cv * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v[q]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (v[q][e] > best[e]) { best[e] = v[q][e]; arg[e] = q; }
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (best[e] - mean[e]) * rstd[e];
+        const float g = xh > 0.f ? d[e] : 0.f;
+        s1[e] += g; s2[e] += g * xh;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[q][e] - mean[e]) * rstd[e];
+          const float g = (arg[e] == q && xh > 0.f) ? d[e] : 0.f;
+          o[e] = rstd[e] * (g - s1[e] - xh * s2[e]);
+        }
+        st8<T>(dxs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, o);
+      }
+    }
+  }
+  if (!APPLY) {
+    reduce8_same_cv<8>(s1, sm);
+    reduce8_same_cv<8>(s2, sm);
+    if (slot == 0) {
+      st8<float>(pp + split * 128, s1);
+      st8<float>(pp + split * 128 + 64, s2);
+    }
+  }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -774,30 +939,55 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_bwd");
 }
 
-// 8-channel blocks only pay for the 64-channel layer (S blocks otherwise; 57.6 -> 43.9 us forward at S = 24): with more channels
-// the 16-byte-per-row accesses cost more than the extra blocks bring (C = 128: 18.6 -> 19.7 us, backward 15.7 -> 24 us)
-static bool in_narrow(int C, int S) { return C == 64 && S < 128; }
+// bands of pooled rows for the split path (0 = one-kernel path): only for the big maps whose (C/64) x S blocks cannot fill the chip
+static int in_splits(int S, int H, int C, int avgpool) {
+  static const int minh = [] { const char* e = getenv("COUNTR_IN_SPLIT_MINH"); return e ? atoi(e) : 32; }();
+  if (avgpool || (C / 64) * S >= 128 || H < minh) return 0;
+  const int Ho = H / 2;
+  int ns = Ho >= 32 ? 16 : 8;
+  while (ns > 1 && (Ho % ns)) ns >>= 1;
+  return ns > 1 ? ns : 0;
+}
+extern "C" int countr_instnorm_workspace_floats(int S, int C) { return S * C * 16 * 2; }
 
 extern "C" int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C, int avgpool,
-                                             float eps, int dtype, void* stream) {
+                                             float eps, int dtype, float* workspace, void* stream) {
   if (!x || !y || C % 64 || (H & 1) || (W & 1)) { countr_set_error("countr_instnorm_relu_pool_fwd: bad args (C % 64, even H/W)"); return -1; }
-  const bool narrow = in_narrow(C, S);
-  dim3 grid(narrow ? C / 8 : C / 64, S), block(256);
-#define IN_FWD(TT, NCVV) hipLaunchKernelGGL((in_relu_pool_fwd_kernel<TT, NCVV>), grid, block, 0, STREAM(stream), (const TT*)x, (TT*)y, stats, H, W, C, avgpool, eps)
-  if (dtype == COUNTR_BF16) { if (narrow) IN_FWD(bf16_t, 1); else IN_FWD(bf16_t, 8); }
-  else { if (narrow) IN_FWD(float, 1); else IN_FWD(float, 8); }
-#undef IN_FWD
+  const int ns = workspace ? in_splits(S, H, C, avgpool) : 0;
+  if (ns) {
+    dim3 grid(C / 64, S, ns), block(256);
+    if (dtype == COUNTR_BF16) {
+      hipLaunchKernelGGL(in_stats_split_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, workspace, H, W, C);
+      hipLaunchKernelGGL(in_apply_split_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, workspace, (bf16_t*)y, stats, H, W, C, eps);
+    } else {
+      hipLaunchKernelGGL(in_stats_split_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, workspace, H, W, C);
+      hipLaunchKernelGGL(in_apply_split_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, workspace, (float*)y, stats, H, W, C, eps);
+    }
+    COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_fwd");
+  }
+  dim3 grid(C / 64, S), block(256);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL((in_relu_pool_fwd_kernel<bf16_t, 8>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, stats, H, W, C, avgpool, eps);
+  else hipLaunchKernelGGL((in_relu_pool_fwd_kernel<float, 8>), grid, block, 0, STREAM(stream), (const float*)x, (float*)y, stats, H, W, C, avgpool, eps);
   COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_fwd");
 }
 
 extern "C" int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H, int W,
-                                             int C, int avgpool, int dtype, void* stream) {
+                                             int C, int avgpool, int dtype, float* workspace, void* stream) {
   if (!x || !dyp || !stats || !dx || C % 64) { countr_set_error("countr_instnorm_relu_pool_bwd: bad args"); return -1; }
-  const bool narrow = in_narrow(C, S);
-  dim3 grid(narrow ? C / 8 : C / 64, S), block(256);
-#define IN_BWD(TT, NCVV) hipLaunchKernelGGL((in_relu_pool_bwd_kernel<TT, NCVV>), grid, block, 0, STREAM(stream), (const TT*)x, (const TT*)dyp, stats, (TT*)dx, H, W, C, avgpool)
-  if (dtype == COUNTR_BF16) { if (narrow) IN_BWD(bf16_t, 1); else IN_BWD(bf16_t, 8); }
-  else { if (narrow) IN_BWD(float, 1); else IN_BWD(float, 8); }
-#undef IN_BWD
+  const int ns = workspace ? in_splits(S, H, C, avgpool) : 0;
+  if (ns) {
+    dim3 grid(C / 64, S, ns), block(256);
+    if (dtype == COUNTR_BF16) {
+      hipLaunchKernelGGL((in_bwd_split_kernel<bf16_t, false>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, workspace, (bf16_t*)dx, H, W, C);
+      hipLaunchKernelGGL((in_bwd_split_kernel<bf16_t, true>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, workspace, (bf16_t*)dx, H, W, C);
+    } else {
+      hipLaunchKernelGGL((in_bwd_split_kernel<float, false>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, workspace, (float*)dx, H, W, C);
+      hipLaunchKernelGGL((in_bwd_split_kernel<float, true>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, workspace, (float*)dx, H, W, C);
+    }
+    COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_bwd");
+  }
+  dim3 grid(C / 64, S), block(256);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL((in_relu_pool_bwd_kernel<bf16_t, 8>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, (bf16_t*)dx, H, W, C, avgpool);
+  else hipLaunchKernelGGL((in_relu_pool_bwd_kernel<float, 8>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, (float*)dx, H, W, C, avgpool);
   COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_bwd");
 }

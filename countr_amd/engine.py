@@ -523,14 +523,15 @@ class Engine:
             stats = [A("instats%d" % (i + 1), (BS, chans[i], 2), f32) for i in range(4)]
             self._op(ops, L.countr_conv3x3_c3_fwd, boxes.data_ptr(), self._pp("decoder_proj1.0.weight"), self._pp("decoder_proj1.0.bias"),
                      c[0].data_ptr(), BS, 64, 64, code)
+            in_ws = self._shared("in_ws", L.countr_instnorm_workspace_floats(BS, Dd))
             self._op(ops, L.countr_instnorm_relu_pool_fwd, c[0].data_ptr(), pl[0].data_ptr(), stats[0].data_ptr(), BS, 64, 64, 64, 0, 1e-5,
-                     code)
+                     code, in_ws.data_ptr())
             for i in (1, 2, 3):
                 wn = "decoder_proj%d.0.weight" % (i + 1)
                 self._conv_fwd(ops, pl[i - 1], self.Wf[wn], self._pp(wn[:-6] + "bias"), c[i], BS, sizes[i], sizes[i], chans[i - 1], chans[i])
                 last = i == 3
                 self._op(ops, L.countr_instnorm_relu_pool_fwd, c[i].data_ptr(), (ytok if last else pl[i]).data_ptr(), stats[i].data_ptr(),
-                         BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code)
+                         BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code, in_ws.data_ptr())
         blk = []
         for i in range(self.ddepth):
             b = "decoder_blocks.%d" % i
@@ -707,7 +708,7 @@ class Engine:
             dpl = [A("dp%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
             for i in (3, 2, 1, 0):
                 self._op(ops, L.countr_instnorm_relu_pool_bwd, c[i].data_ptr(), (g_y if i == 3 else dpl[i]).data_ptr(), stats[i].data_ptr(),
-                         dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code)
+                         dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code, in_ws.data_ptr())
                 wn = "decoder_proj%d.0.weight" % (i + 1)
                 if i == 0:
                     ws = self._shared("c3wgrad", L.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28)

@@ -120,10 +120,13 @@ int countr_groupnorm_relu_bwd(const void* x, const void* dy, const float* d1, co
 
 /* -------- InstanceNorm2d(affine=False) + ReLU + MaxPool2d(2) | AdaptiveAvgPool2d(1) on NHWC
  * (decoder_proj1-4: models_mae_cross.py:47-71).  stats: fp32 [S][C][2]. */
+/* workspace (optional, fp32 [countr_instnorm_workspace_floats(S, C)]): lets the wide first layers (few (sample, 64-channel)
+ * blocks) run as two pixel-band kernels with Chan-combined statistics; NULL = single-kernel path. */
+int countr_instnorm_workspace_floats(int S, int C);
 int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C,
-                                  int avgpool, float eps, int dtype, void* stream);
+                                  int avgpool, float eps, int dtype, float* workspace, void* stream);
 int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H,
-                                  int W, int C, int avgpool, int dtype, void* stream);
+                                  int W, int C, int avgpool, int dtype, float* workspace, void* stream);
 
 /* -------- fused self-attention forward (Attention.forward, models_crossvit.py:82-94 == timm Attention):
  * out = softmax(q k^T * scale) v on a packed bf16 qkv [B, N, 3, H, dh] (dh = 32 or 64) -> bf16 [B, N, H*dh].

@@ -127,16 +127,18 @@ def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
     assert relerr(dw1, w1r.grad) < 2e-3 and relerr(db1, b1r.grad) < 1e-4
 
 
-@pytest.mark.parametrize("H,Cc,avg", [(64, 64, 0), (16, 256, 0), (8, 512, 1)])
+@pytest.mark.parametrize("use_ws", [False, True])   # True: pixel-band two-kernel path where the shape qualifies
+@pytest.mark.parametrize("H,Cc,avg", [(64, 64, 0), (32, 128, 0), (16, 256, 0), (8, 512, 1)])
 @pytest.mark.parametrize("tdt,code,tol", DT)
-def test_instnorm_relu_pool(hip, H, Cc, avg, tdt, code, tol):
+def test_instnorm_relu_pool(hip, H, Cc, avg, tdt, code, tol, use_ws):
     S = 3
     x = (rnd((S, H, H, Cc), 11, 1.3) + 0.1).to(tdt)
     xd = x.cuda()
     oshape = (S, Cc) if avg else (S, H // 2, H // 2, Cc)
     y = torch.empty(oshape, device="cuda", dtype=tdt)
     stats = torch.empty((S, Cc, 2), device="cuda")
-    _lib.check(hip.countr_instnorm_relu_pool_fwd(P(xd), P(y), P(stats), S, H, H, Cc, avg, 1e-5, code, st()))
+    ws = torch.empty(hip.countr_instnorm_workspace_floats(S, Cc), device="cuda") if use_ws else None
+    _lib.check(hip.countr_instnorm_relu_pool_fwd(P(xd), P(y), P(stats), S, H, H, Cc, avg, 1e-5, code, P(ws) if use_ws else None, st()))
     xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
     a = R.instance_norm_relu(xr)
     yr = a.mean((2, 3)) if avg else R.max_pool2(a).permute(0, 2, 3, 1)
@@ -144,7 +146,7 @@ def test_instnorm_relu_pool(hip, H, Cc, avg, tdt, code, tol):
     dyp = rnd(oshape, 12).to(tdt)
     dx = torch.empty_like(xd)
     dypd = dyp.cuda()
-    _lib.check(hip.countr_instnorm_relu_pool_bwd(P(xd), P(dypd), P(stats), P(dx), S, H, H, Cc, avg, code, st()))
+    _lib.check(hip.countr_instnorm_relu_pool_bwd(P(xd), P(dypd), P(stats), P(dx), S, H, H, Cc, avg, code, P(ws) if use_ws else None, st()))
     yr.backward(dyp.double())
     assert relerr(dx, xr.grad.permute(0, 2, 3, 1)) < (tol if code else 5e-4)
 
