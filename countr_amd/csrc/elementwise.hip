@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
 }
 
 // wgrad of the same conv: partial[block][64*27] (+ bias grad partial[block][64] behind it).
-// Each thread owns 7 of the 1728+64 outputs (padded) and walks the block's pixel range through LDS tiles.
+// Each thread owns 7 of the 64 x 28 outputs (one channel, seven taps) and walks the block's pixel range through LDS tiles.
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __restrict__ in, const T* __restrict__ dy,
                                                                float* __restrict__ partial, int S, int H, int W) {
@@ -104,21 +104,19 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
       s_in[pp][k] = v;
     }
     __syncthreads();
+    // thread = (output channel co, group kq of 7 taps): per pixel one conflict-free read of dy and seven wave-uniform
+    // (broadcast) reads of the taps feed seven FMAs (the first version paired unrelated (co, k) per thread: 14 reads per 7 FMAs)
+    const int co = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    for (int pp = 0; pp < 64; ++pp) {
+      const float d = s_dy[pp][co];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int o = threadIdx.x + 256 * i;  // output id = co*28 + k
-      if (o < 64 * 28) {
-        const int co = o / 28, k = o - co * 28;
-        float a = 0.f;
-        for (int pp = 0; pp < 64; ++pp) a += s_dy[pp][co] * s_in[pp][k];
-        acc[i] += a;
-      }
+      for (int i = 0; i < 7; ++i) acc[i] = fmaf(d, s_in[pp][kq * 7 + i], acc[i]);
     }
   }
+  {
+    const int co = threadIdx.x & 63, kq = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int o = threadIdx.x + 256 * i;
-    if (o < 64 * 28) partial[(int64_t)blockIdx.x * (64 * 28) + o] = acc[i];
+    for (int i = 0; i < 7; ++i) partial[(int64_t)blockIdx.x * (64 * 28) + co * 28 + kq * 7 + i] = acc[i];
   }
 }
 
@@ -414,7 +412,7 @@ extern "C" int countr_conv3x3_c3_wgrad_nblocks(void) { return 256; }
 extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* dw, float* db, float* workspace, int S, int H,
                                        int W, int dtype, int accumulate, void* stream) {
   if (!in || !dy || !dw || !db || !workspace) { countr_set_error("countr_conv3x3_c3_wgrad: null"); return -1; }
-  const int nb = 256;
+  const int nb = countr_conv3x3_c3_wgrad_nblocks();
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const bf16_t*)dy, workspace, S, H, W);
   else hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const float*)dy, workspace, S, H, W);
   hipLaunchKernelGGL(conv3x3_c3_wgrad_finish_kernel, dim3((64 * 28 + 63) / 64), dim3(256), 0, STREAM(stream), workspace, dw, db, nb, accumulate);
