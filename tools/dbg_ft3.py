@@ -1,3 +1,4 @@
+"""Reproducer kept for the record: a hipMemsetAsync node + float atomics inside a captured region gave wrong loss sums under graph replay (ROCm 7.2); the fix is the deterministic two-stage reduction (see countr_amd/trainer.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np

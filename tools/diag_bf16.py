@@ -1,3 +1,4 @@
+"""bf16 vs fp32 engine: error of the density map and counts per shot_num on the golden inputs (numbers quoted in tests/test_model_gpu.py)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

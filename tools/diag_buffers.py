@@ -1,3 +1,4 @@
+"""Per-buffer rms error of the bf16 engine against the fp32 engine along the forward pass (shows where the final 256->1 conv amplifies)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, 'tests')

@@ -1,3 +1,4 @@
+"""Per-tensor gradient error of the bf16 engine against the fp32 oracle gradients."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, 'tests')
