@@ -158,7 +158,11 @@ def test_gemm_batched_and_splitk(hip, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Bsz,H,W,Cin,Cout", [(2, 24, 24, 128, 256), (1, 12, 20, 64, 128), (3, 8, 8, 256, 512)])
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout", [(2, 24, 24, 128, 256), (1, 12, 20, 64, 128), (3, 8, 8, 256, 512),
+                                              # odd geometry for the im2col fast paths: widths below / above / not dividing the 64-pixel
+                                              # k-step, a single row, more channels than one 64-chunk, > 256 workgroups (plain kernel)
+                                              (1, 5, 7, 64, 64), (2, 33, 17, 192, 72), (1, 1, 40, 128, 136), (1, 70, 66, 64, 256),
+                                              (2, 96, 96, 64, 128)])
 def test_conv3x3_implicit_gemm(hip, dt, Bsz, H, W, Cin, Cout):
     x = _mk((Bsz, Cin, H, W), dt, 10)            # logical NCHW
     w = _mk((Cout, Cin, 3, 3), dt, 11) * 0.1
@@ -225,3 +229,69 @@ def test_wgrad_with_fused_bias_gradient(hip):
         assert (dW.double() - dY.double().t() @ X.double()).abs().max().item() <= 2e-4 * (dY.double().t() @ X.double()).abs().max().item()
         ref_b = dY.double().sum(0)
         assert (db.double() - ref_b).abs().max().item() <= 1e-4 * ref_b.abs().max().item() + 1e-4
+
+
+def test_gemm_randomised_shapes_strides_and_options(hip):
+    """Seeded sweep over operand modes, ragged and padded shapes (leading dimensions larger than the row), both dtypes, bias /
+    residual / GELU / output-type options, split-K and grid sizes on both sides of the kernel-selection thresholds (256 workgroups:
+    wave-specialised vs plain; K a multiple of 64 or not: uniform-base vs per-lane addressing)."""
+    import random
+    rng = random.Random(1234)
+    checked = 0
+    for it in range(72):
+        dt = torch.bfloat16 if it % 3 else torch.float32
+        code = 1 if dt == torch.bfloat16 else 0
+        chunk = 8 if code else 4
+        ma, mb = rng.choice([(0, 0), (0, 1), (1, 1), (1, 0)])
+        big = it % 9 == 0
+        M = rng.choice([8, 24, 72, 200, 576, 1000]) if not big else rng.choice([2304, 4608])
+        N = rng.choice([8, 64, 136, 256, 512, 768]) if not big else rng.choice([768, 1536])
+        K = rng.choice([8, 64, 96, 128, 192, 320, 768])
+        M, N = -(-M // chunk) * chunk, -(-N // chunk) * chunk
+        pad = rng.choice([0, chunk, 5 * chunk])
+        A, B = _mk((M, K), dt, 100 + it), _mk((N, K), dt, 200 + it)
+        As = torch.zeros((M, K + pad) if ma == 0 else (K, M + pad), device="cuda", dtype=dt)
+        Bs = torch.zeros((N, K + pad) if mb == 0 else (K, N + pad), device="cuda", dtype=dt)
+        (As[:, :K] if ma == 0 else As[:, :M]).copy_(A if ma == 0 else A.t())
+        (Bs[:, :K] if mb == 0 else Bs[:, :N]).copy_(B if mb == 0 else B.t())
+        a = _lib.GemmArgs()
+        a.alpha = rng.choice([1.0, 0.5]); a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        a.A, a.B = As.data_ptr(), Bs.data_ptr()
+        a.lda, a.ldb = As.shape[1], Bs.shape[1]
+        a.M, a.N, a.K = M, N, K
+        ref = a.alpha * (A.double() @ B.double().t())
+        if it % 4 == 3:   # split-K slabs + deterministic reduce
+            sk = rng.choice([1, 2, 3, 5])
+            part = torch.empty((sk, M, N), device="cuda")
+            out = torch.zeros((M, N), device="cuda")
+            a.partial, a.splitk, a.ldc, a.alpha = part.data_ptr(), sk, N, 1.0
+            ref = A.double() @ B.double().t()
+            _lib.check(hip.countr_gemm(C.byref(a), code, ma, mb, _stream()), "gemm")
+            _lib.check(hip.countr_splitk_reduce(part.data_ptr(), out.data_ptr(), sk, M, N, 0, 0, None, None, _stream()), "reduce")
+            tol = 2e-4
+        else:
+            obf = code == 1 and rng.random() < 0.5
+            ldc = N + rng.choice([0, 8])
+            out = torch.zeros((M, ldc), device="cuda", dtype=torch.bfloat16 if obf else torch.float32)
+            a.C, a.ldc, a.out_bf16 = out.data_ptr(), ldc, int(obf)
+            opt = rng.choice(["plain", "bias", "bias+gelu", "bias+resid", "resid"])
+            if "bias" in opt:
+                bias = _mk((N,), torch.float32, 300 + it)
+                a.bias = bias.data_ptr()
+                ref = ref + bias.double()
+            if "gelu" in opt:
+                a.act = _lib.ACT_GELU
+                ref = torch.nn.functional.gelu(ref)
+            if "resid" in opt:
+                rmod = rng.choice([0, max(chunk, M // 2)])
+                res = _mk((rmod if rmod else M, N), torch.float32, 400 + it)
+                a.resid, a.ldres, a.res_mod = res.data_ptr(), N, rmod
+                ref = ref + (res.double() if not rmod else res.double()[torch.arange(M, device="cuda") % rmod])
+            _lib.check(hip.countr_gemm(C.byref(a), code, ma, mb, _stream()), "gemm")
+            out = out[:, :N]
+            tol = 2e-2 if obf else (3e-3 if ("gelu" in opt and code) else 2e-4)   # bf16 GELU uses the 1.5e-7-accurate fast erf
+        torch.cuda.synchronize()
+        err = (out.double() - ref).abs().max().item()
+        assert err <= tol * max(ref.abs().max().item(), 1e-3) + 1e-5, (it, dt, ma, mb, M, N, K, pad, err)
+        checked += 1
+    assert checked == 72
