@@ -349,6 +349,7 @@ template <int ROWS, int NW> struct DmaLoader<COUNTR_OP_IM2COL, ROWS, NW> {
   __device__ void init(const OpDesc& d, int row0, int kstart, int wave, int lane) {
     ptr = d.ptr; H = d.H; W = d.W; C = d.C;
     stepy = 64 / W; stepx = 64 - stepy * W;
+    stepy %= H;   // rows wrap per image: with the step reduced modulo H one conditional subtraction per advance is enough
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
       krow[i] = (i * NW + wave) * 4 + (lane >> 4);

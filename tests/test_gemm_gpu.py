@@ -162,7 +162,10 @@ def test_gemm_batched_and_splitk(hip, dt):
                                               # odd geometry for the im2col fast paths: widths below / above / not dividing the 64-pixel
                                               # k-step, a single row, more channels than one 64-chunk, > 256 workgroups (plain kernel)
                                               (1, 5, 7, 64, 64), (2, 33, 17, 192, 72), (1, 1, 40, 128, 136), (1, 70, 66, 64, 256),
-                                              (2, 96, 96, 64, 128)])
+                                              (2, 96, 96, 64, 128),
+                                              # maps smaller than one 64-pixel k-step with several k-steps (row counter wraps
+                                              # more than once per step)
+                                              (8, 4, 4, 64, 64), (8, 3, 8, 128, 64), (16, 2, 6, 64, 72)])
 def test_conv3x3_implicit_gemm(hip, dt, Bsz, H, W, Cin, Cout):
     x = _mk((Bsz, Cin, H, W), dt, 10)            # logical NCHW
     w = _mk((Cout, Cin, 3, 3), dt, 11) * 0.1
