@@ -73,7 +73,7 @@ def test_layernorm_fwd_bwd(hip, D, tdt, code, tol):
     assert relerr(dx, xr.grad) < 1e-4
 
 
-@pytest.mark.parametrize("HW", [24 * 24, 96 * 96])
+@pytest.mark.parametrize("HW", [24 * 24, 96 * 96, 35 * 35, 100])   # incl. pixel counts that do not divide into the splits
 @pytest.mark.parametrize("tdt,code,tol", DT)
 def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
     B, Cc, G = 2, 256, 8
@@ -128,7 +128,7 @@ def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
 
 
 @pytest.mark.parametrize("use_ws", [False, True])   # True: pixel-band two-kernel path where the shape qualifies
-@pytest.mark.parametrize("H,Cc,avg", [(64, 64, 0), (32, 128, 0), (16, 256, 0), (8, 512, 1)])
+@pytest.mark.parametrize("H,Cc,avg", [(64, 64, 0), (32, 128, 0), (16, 256, 0), (8, 512, 1), (40, 64, 0), (12, 128, 0)])   # 40, 12: odd band counts
 @pytest.mark.parametrize("tdt,code,tol", DT)
 def test_instnorm_relu_pool(hip, H, Cc, avg, tdt, code, tol, use_ws):
     S = 3
