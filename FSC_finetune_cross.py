@@ -85,8 +85,14 @@ def main(args):
         args.lr = args.blr * eff_batch / 256     # :218-221
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95))
-    if ckpt is not None and args.do_resume and "epoch" in ckpt:
+    if ckpt is not None and args.do_resume and "epoch" in ckpt:      # util/misc.py:400-421: optimizer / epoch only with --do_resume
         args.start_epoch = ckpt["epoch"] + 1
+        opt = ckpt.get("optimizer")
+        if isinstance(opt, dict) and opt.get("exp_avg") is not None and opt["exp_avg"].numel() == step.eng.G.numel():
+            step.eng.M = opt["exp_avg"].to(device)               # our flat AdamW state (a reference optimizer dict is per-tensor
+            step.eng.V = opt["exp_avg_sq"].to(device)            # and in a different order: not convertible without its param groups)
+            step.eng.step_count = int(opt["step"])
+            print("With optim & sched!")
     from countr_amd.data import fsc147
     loader = None
     if args.synthetic_steps <= 0 and fsc147.available(args):

@@ -49,6 +49,11 @@ def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
     assert len(lines) == 2 and all(np.isfinite(l["loss"]) for l in lines)          # 4 images / batch 2, drop_last
     ckpt = os.path.join(out, "checkpoint__finetuning_last.pth")
     assert os.path.exists(ckpt)
+    # --do_resume restores epoch and the flat AdamW state and continues with epoch 1
+    log = run(["FSC_finetune_cross.py", "--data_path", "/nonexistent", "--synthetic_steps", "2", "--batch_size", "2", "--epochs", "2",
+               "--warmup_epochs", "0", "--output_dir", out, "--resume", ckpt, "--do_resume", "--log_every", "1"])
+    assert "With optim & sched!" in log
+    assert [json.loads(l)["epoch"] for l in log.splitlines() if l.startswith("{")] == [1, 1]
     log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "test", "--box_bound", "3"])
     res = json.loads([l for l in log.splitlines() if l.startswith("{")][-1])
     assert res["images"] == 2 and np.isfinite(res["MAE"]) and np.isfinite(res["RMSE"])
