@@ -71,7 +71,6 @@ def get_args_parser():
 
 def main(args):
     misc.init_distributed_mode(args)
-    assert args.accum_iter == 1, "gradient accumulation is not implemented in the fused step"
     device = torch.device("cuda", args.gpu)
     torch.cuda.set_device(device)
     seed = args.seed + misc.get_rank()          # FSC_finetune_cross.py:168-170
@@ -84,7 +83,8 @@ def main(args):
     if args.lr is None:
         args.lr = args.blr * eff_batch / 256     # :218-221
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
-    step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95))
+    step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95),
+                        accum_iter=args.accum_iter)
     if ckpt is not None and args.do_resume and "epoch" in ckpt:      # util/misc.py:400-421: optimizer / epoch only with --do_resume
         args.start_epoch = ckpt["epoch"] + 1
         opt = ckpt.get("optimizer")
@@ -113,7 +113,8 @@ def main(args):
             loader.sampler.set_epoch(epoch)                                             # :260-261
         it_data = iter(loader) if loader is not None else None
         for it in range(n_iter):
-            lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)        # :271
+            if it % args.accum_iter == 0:                                               # :270-271 (per accumulation window)
+                lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
             S = shared_shot_num(epoch * n_iter + it, seed=args.seed)                   # :278-284 (shared across ranks)
             if it_data is not None:
                 imgs, gt, _n, boxes, _pos, _m, _ids = next(it_data)

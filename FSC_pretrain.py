@@ -67,7 +67,6 @@ def get_args_parser():
 
 def main(args):
     misc.init_distributed_mode(args)
-    assert args.accum_iter == 1, "gradient accumulation is not implemented in the fused step"
     device = torch.device("cuda", args.gpu)
     torch.cuda.set_device(device)
     seed = args.seed + misc.get_rank()          # FSC_pretrain.py:150-152
@@ -81,7 +80,7 @@ def main(args):
         args.lr = args.blr * eff_batch / 256     # :211-212
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = PretrainStep(model, batch=args.batch_size, mask_ratio=args.mask_ratio, lr=args.lr, weight_decay=args.weight_decay,
-                        betas=(0.9, 0.95))
+                        betas=(0.9, 0.95), accum_iter=args.accum_iter)
     if ckpt is not None and isinstance(ckpt.get("optimizer"), dict) and "exp_avg" in ckpt["optimizer"] and "epoch" in ckpt:
         opt = ckpt["optimizer"]                  # our flat AdamW state (reference optimizer dicts are not convertible)
         step.eng.M = opt["exp_avg"].to(device)
@@ -110,7 +109,8 @@ def main(args):
             loader.sampler.set_epoch(epoch)                                             # :236-237
         it_data = iter(loader) if loader is not None else None
         for it in range(n_iter):
-            lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)        # :258-259
+            if it % args.accum_iter == 0:                                               # :258-259 (per accumulation window)
+                lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
             if it_data is not None:
                 imgs = next(it_data)     # host tensor: load() stages it over PCIe on a copy stream while the previous step computes
             else:

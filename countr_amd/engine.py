@@ -80,12 +80,15 @@ class ParamLayout:
         segs = [s for s in self.segments if s[0][0] == bucket]
         return (segs[0][1], segs[-1][2]) if segs else (0, 0)
 
-    def adam_ranges(self, S, weight_decay):
+    def adam_ranges(self, S, weight_decay, skip=None):
         """(start, end, wd) ranges of the trainable region touched when shot_num == S: parameters whose gradient is
-        None in the reference are skipped by torch AdamW (exemplar CNN for S == 0, shot_token otherwise)."""
+        None in the reference are skipped by torch AdamW (exemplar CNN for S == 0, shot_token otherwise).  `skip` (a set of
+        buckets) overrides the shot_num rule: an accumulation window may have touched both."""
+        if skip is None:
+            skip = (2,) if S == 0 else (3,)
         out = []
         for (bucket, nodecay), s, e in self.segments:
-            if (bucket == 2 and S == 0) or (bucket == 3 and S > 0):
+            if bucket in skip:
                 continue
             out.append((s, e, 0.0 if nodecay else weight_decay))
         return out
@@ -112,6 +115,7 @@ class Plan:
         self.bwd_head = []   # backward until bucket 0 (head + decoder_norm) gradients are final
         self.bwd_rest = []   # ... until bucket 1 (decoder blocks + decoder_embed) is final
         self.bwd_tok = []    # exemplar tokens: exemplar CNN (bucket 2) or shot_token (bucket 3)
+        self.acc = None      # the same three lists with parameter gradients ACCUMULATED (micro-steps 2.. of gradient accumulation)
         self.buf = {}
 
 
@@ -154,6 +158,7 @@ class Engine:
         self._ws = {}
         self._need = {}
         self._sizing = False
+        self._acc = 0                # accumulate flag baked into the parameter-gradient launches being built (gradient accumulation)
         self.generation = 0
         self._sides = None
         self.parallel_lanes = False  # measured on MI355X: fork/join of the small backward branches is a wash (9.62 vs 9.56 ms)
@@ -201,6 +206,8 @@ class Engine:
     def _alloc(self, plan, key, shape, dtype):
         if self._sizing:
             return _Fake(dtype)
+        if key in plan.buf:          # the backward lists are built twice (overwrite / accumulate) over the same buffers
+            return plan.buf[key]
         t = torch.empty(shape, device=self.device, dtype=dtype)
         plan.buf[key] = t
         return t
@@ -325,14 +332,14 @@ class Engine:
         self._gemm(ops, self.code, OP_COL, OP_COL, A=dy.data_ptr() if not isinstance(dy, int) else dy,
                    B=x.data_ptr() if not isinstance(x, int) else x, partial=part.data_ptr(), lda=lddy, ldb=ldx, ldc=K,
                    M=N, N=K, K=M, splitk=sk, rowsum_partial=(rs.data_ptr() if fuse_bias else None))
-        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, 0,
+        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, self._acc,
                  rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
         if bias_name is not None and not fuse_bias:
             self._bias_grad(ops, dy, bias_name, M, N)
 
     def _bias_grad(self, ops, dy, bname, M, N):
         ws = self._shared("colsum", 256 * 4096)
-        self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, 0)
+        self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, self._acc)
 
     def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None):
         """dx[M,K] = dy[M,N] W[N,K] (+ resid)."""
@@ -367,7 +374,7 @@ class Engine:
         ws = self._shared("lnbwd", 256 * 2 * 2048)
         self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
                  rstd.data_ptr(), dx.data_ptr(), self._gp(name + ".weight"), self._gp(name + ".bias"), ws.data_ptr(), rows, D,
-                 int(dy.dtype == torch.bfloat16), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
+                 int(dy.dtype == torch.bfloat16), int(accumulate), self._acc, dx_t.data_ptr() if dx_t is not None else None)
         return dx if self.code == F32 else dx_t
 
     # unfused self-attention forward on a packed qkv [rows, 3*Dm]
@@ -445,7 +452,7 @@ class Engine:
         self._gemm(ops, self.code, OP_COL, OP_IM2COL, A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout,
                    ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W, Cin=Cin, splitk=sk,
                    rowsum_partial=(rs.data_ptr() if fuse_bias else None))
-        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, 0,
+        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, self._acc,
                  rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
         if bias_name is not None and not fuse_bias:
             self._bias_grad(ops, dy, bias_name, Kp, Cout)
@@ -608,117 +615,121 @@ class Engine:
         if not train:
             return p
 
-        # =========================== backward (decoder side only) ===========================
-        ops = p.bwd_head
-        dout = A("dout", (B, 2 * hs[3], 2 * hs[3]), f32)
-        d1 = A("d1", (B, hs[3] * hs[3]), f32)
-        self._op(ops, L.countr_upsample2x_bwd, dout.data_ptr(), d1.data_ptr(), B, hs[3], hs[3], 1, F32)
-        # gradient scratch for maps: dpre (grad of conv output), dup (grad of conv input)
-        dpre = self._shared("dpre", B * hs[3] * hs[3] * 256, T)
-        dup = self._shared("dup", B * hs[3] * hs[3] * 256, T)
-        dact = self._shared("dact", B * hs[2] * hs[2] * 256, T)
-        ddn = A("ddn", (rows, Dd), T)
-        for i in (3, 2, 1, 0):
-            hn = "decode_head%d" % i
-            HW = hs[i] * hs[i]
-            if i == 3:
-                self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), None, d1.data_ptr(), self._pp(hn + ".3.weight"),
-                         hstats[i].data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(),
-                         self._gp(hn + ".1.weight"), self._gp(hn + ".1.bias"), self._gp(hn + ".3.weight"), self._gp(hn + ".3.bias"),
-                         gn_ws.data_ptr(), B, HW, 256, 8, code, 0)
-            else:
-                self._op(ops, L.countr_upsample2x_bwd, dup.data_ptr(), dact.data_ptr(), B, hs[i], hs[i], 256, code)
-                self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), dact.data_ptr(), None, None, hstats[i].data_ptr(),
-                         self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), self._gp(hn + ".1.weight"),
-                         self._gp(hn + ".1.bias"), None, None, gn_ws.data_ptr(), B, HW, 256, 8, code, 0)
-            big = hs[i] >= 96   # each of these kernels fills the GPU on its own: forking only adds contention
-            if not big:
-                self._fork(ops)
-                self._lane(ops, 1)
-            self._conv_wgrad(ops, dpre, hin[i], hn + ".0.weight", B, hs[i], hs[i], cin[i], 256, bias_name=hn + ".0.bias")
-            # dgrad == forward conv of dpre with the dgrad-form weights (Cin_gemm = 256 output channels)
-            if not big:
-                self._lane(ops, 0)
-            tgt = dup if i > 0 else ddn
-            self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dpre.data_ptr(), B=self.Wd[hn + ".0.weight"].data_ptr(), C=tgt.data_ptr(),
-                       ldb=9 * 256, ldc=cin[i], M=B * HW, N=cin[i], K=9 * 256, H=hs[i], W=hs[i], Cin=256,
-                       out_bf16=int(code == BF16))
-            if not big:
-                self._join(ops)
-        gx = A("gx", (rows, Dd), f32)
-        gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
-        g_t = self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False, dx_t=gxT)
-
-        ops = p.bwd_rest
-        dh = A("dh", (rows, 4 * Dd), T)
-        dn_t = A("dn_t", (rows, Dd), T)      # grad wrt a LayerNorm output
-        dproj_in = A("dproj_in", (rows, Dd), T)
-        dqkv = A("dqkv", (rows, 3 * Dd), T)
-        dq = A("dq", (rows, Dd), T)
-        dk = A("dk", (B * Sy, Dd), f32)
-        dv = A("dv", (B * Sy, Dd), f32)
-        dkT = A("dkT", (B * Sy, Dd), T) if code == BF16 else None
-        dvT = A("dvT", (B * Sy, Dd), T) if code == BF16 else None
-        dy_tok = A("dy_tok", (B * Sy, Dd), f32)
-        xws = self._shared("xattn", L.countr_xattn_bwd_workspace_floats(B, N, Sy, Dd))
-        first_tok = True
-        for i in reversed(range(self.ddepth)):
-            b = "decoder_blocks.%d" % i
-            d = blk[i]
-            # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))  (g_t = bf16/fp32 operand view of gx, emitted by the LN backward)
-            self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh)
-            self._op(ops, L.countr_gelu_bwd, dh.data_ptr(), d["hpre"].data_ptr(), dh.data_ptr(), rows * 4 * Dd, code)
-            self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t)
-            g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=gxT)
-            # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
-            self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
-            self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
-                     dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code)
-            self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
-            g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=gxT)
-            dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
-            dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
-            for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
-                self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
-                self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,
-                                   resid=(None if first_tok else dy_tok), out_bf16=False)
-                first_tok = False
-            # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
-            self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
-            if d["lse"] is not None:
-                dlt = self._shared("attn_delta", B * Hd * N)
-                self._op(ops, L.countr_attn_bwd, d["qkv"].data_ptr(), d["att"].data_ptr(), dproj_in.data_ptr(), d["lse"].data_ptr(),
-                         dlt.data_ptr(), dqkv.data_ptr(), B, N, Hd, Dd // Hd, (Dd // Hd) ** -0.5)
-            else:
-                self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
-            self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t)
-            g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=gxT)
-        # ---- decoder_embed (no dgrad: the encoder is frozen)
-        self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
-        # ---- exemplar tokens
-        ops = p.bwd_tok
-        if S == 0:
-            ws = self._shared("colsum", 256 * 4096)
-            self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, 0)
-        else:
-            BS = B * S
-            dyt = A("dyt", (BS, Dd), T) if code == BF16 else None
-            g_y = self._cast(ops, dy_tok, dyt, BS * Dd)
-            dc = [A("dc%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)]
-            dpl = [A("dp%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
+        p.acc = Plan()
+        for acc, lists in ((0, p), (1, p.acc)):
+            self._acc = acc
+            # =========================== backward (decoder side only) ===========================
+            ops = lists.bwd_head
+            dout = A("dout", (B, 2 * hs[3], 2 * hs[3]), f32)
+            d1 = A("d1", (B, hs[3] * hs[3]), f32)
+            self._op(ops, L.countr_upsample2x_bwd, dout.data_ptr(), d1.data_ptr(), B, hs[3], hs[3], 1, F32)
+            # gradient scratch for maps: dpre (grad of conv output), dup (grad of conv input)
+            dpre = self._shared("dpre", B * hs[3] * hs[3] * 256, T)
+            dup = self._shared("dup", B * hs[3] * hs[3] * 256, T)
+            dact = self._shared("dact", B * hs[2] * hs[2] * 256, T)
+            ddn = A("ddn", (rows, Dd), T)
             for i in (3, 2, 1, 0):
-                self._op(ops, L.countr_instnorm_relu_pool_bwd, c[i].data_ptr(), (g_y if i == 3 else dpl[i]).data_ptr(), stats[i].data_ptr(),
-                         dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code, in_ws.data_ptr())
-                wn = "decoder_proj%d.0.weight" % (i + 1)
-                if i == 0:
-                    ws = self._shared("c3wgrad", L.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28)
-                    self._op(ops, L.countr_conv3x3_c3_wgrad, boxes.data_ptr(), dc[0].data_ptr(), self._gp(wn), self._gp(wn[:-6] + "bias"),
-                             ws.data_ptr(), BS, 64, 64, code, 0)
+                hn = "decode_head%d" % i
+                HW = hs[i] * hs[i]
+                if i == 3:
+                    self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), None, d1.data_ptr(), self._pp(hn + ".3.weight"),
+                             hstats[i].data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(),
+                             self._gp(hn + ".1.weight"), self._gp(hn + ".1.bias"), self._gp(hn + ".3.weight"), self._gp(hn + ".3.bias"),
+                             gn_ws.data_ptr(), B, HW, 256, 8, code, self._acc)
                 else:
-                    self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i], bias_name=wn[:-6] + "bias")
-                    self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dc[i].data_ptr(), B=self.Wd[wn].data_ptr(), C=dpl[i - 1].data_ptr(),
-                               ldb=9 * chans[i], ldc=chans[i - 1], M=BS * sizes[i] * sizes[i], N=chans[i - 1], K=9 * chans[i],
-                               H=sizes[i], W=sizes[i], Cin=chans[i], out_bf16=int(code == BF16))
+                    self._op(ops, L.countr_upsample2x_bwd, dup.data_ptr(), dact.data_ptr(), B, hs[i], hs[i], 256, code)
+                    self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), dact.data_ptr(), None, None, hstats[i].data_ptr(),
+                             self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), self._gp(hn + ".1.weight"),
+                             self._gp(hn + ".1.bias"), None, None, gn_ws.data_ptr(), B, HW, 256, 8, code, self._acc)
+                big = hs[i] >= 96   # each of these kernels fills the GPU on its own: forking only adds contention
+                if not big:
+                    self._fork(ops)
+                    self._lane(ops, 1)
+                self._conv_wgrad(ops, dpre, hin[i], hn + ".0.weight", B, hs[i], hs[i], cin[i], 256, bias_name=hn + ".0.bias")
+                # dgrad == forward conv of dpre with the dgrad-form weights (Cin_gemm = 256 output channels)
+                if not big:
+                    self._lane(ops, 0)
+                tgt = dup if i > 0 else ddn
+                self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dpre.data_ptr(), B=self.Wd[hn + ".0.weight"].data_ptr(), C=tgt.data_ptr(),
+                           ldb=9 * 256, ldc=cin[i], M=B * HW, N=cin[i], K=9 * 256, H=hs[i], W=hs[i], Cin=256,
+                           out_bf16=int(code == BF16))
+                if not big:
+                    self._join(ops)
+            gx = A("gx", (rows, Dd), f32)
+            gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
+            g_t = self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False, dx_t=gxT)
+
+            ops = lists.bwd_rest
+            dh = A("dh", (rows, 4 * Dd), T)
+            dn_t = A("dn_t", (rows, Dd), T)      # grad wrt a LayerNorm output
+            dproj_in = A("dproj_in", (rows, Dd), T)
+            dqkv = A("dqkv", (rows, 3 * Dd), T)
+            dq = A("dq", (rows, Dd), T)
+            dk = A("dk", (B * Sy, Dd), f32)
+            dv = A("dv", (B * Sy, Dd), f32)
+            dkT = A("dkT", (B * Sy, Dd), T) if code == BF16 else None
+            dvT = A("dvT", (B * Sy, Dd), T) if code == BF16 else None
+            dy_tok = A("dy_tok", (B * Sy, Dd), f32)
+            xws = self._shared("xattn", L.countr_xattn_bwd_workspace_floats(B, N, Sy, Dd))
+            first_tok = True
+            for i in reversed(range(self.ddepth)):
+                b = "decoder_blocks.%d" % i
+                d = blk[i]
+                # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))  (g_t = bf16/fp32 operand view of gx, emitted by the LN backward)
+                self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh)
+                self._op(ops, L.countr_gelu_bwd, dh.data_ptr(), d["hpre"].data_ptr(), dh.data_ptr(), rows * 4 * Dd, code)
+                self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t)
+                g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=gxT)
+                # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
+                self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
+                self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
+                         dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code)
+                self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
+                g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=gxT)
+                dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
+                dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
+                for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
+                    self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
+                    self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,
+                                       resid=(None if first_tok else dy_tok), out_bf16=False)
+                    first_tok = False
+                # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
+                self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
+                if d["lse"] is not None:
+                    dlt = self._shared("attn_delta", B * Hd * N)
+                    self._op(ops, L.countr_attn_bwd, d["qkv"].data_ptr(), d["att"].data_ptr(), dproj_in.data_ptr(), d["lse"].data_ptr(),
+                             dlt.data_ptr(), dqkv.data_ptr(), B, N, Hd, Dd // Hd, (Dd // Hd) ** -0.5)
+                else:
+                    self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
+                self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t)
+                g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=gxT)
+            # ---- decoder_embed (no dgrad: the encoder is frozen)
+            self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
+            # ---- exemplar tokens
+            ops = lists.bwd_tok
+            if S == 0:
+                ws = self._shared("colsum", 256 * 4096)
+                self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, self._acc)
+            else:
+                BS = B * S
+                dyt = A("dyt", (BS, Dd), T) if code == BF16 else None
+                g_y = self._cast(ops, dy_tok, dyt, BS * Dd)
+                dc = [A("dc%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)]
+                dpl = [A("dp%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
+                for i in (3, 2, 1, 0):
+                    self._op(ops, L.countr_instnorm_relu_pool_bwd, c[i].data_ptr(), (g_y if i == 3 else dpl[i]).data_ptr(), stats[i].data_ptr(),
+                             dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code, in_ws.data_ptr())
+                    wn = "decoder_proj%d.0.weight" % (i + 1)
+                    if i == 0:
+                        ws = self._shared("c3wgrad", L.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28)
+                        self._op(ops, L.countr_conv3x3_c3_wgrad, boxes.data_ptr(), dc[0].data_ptr(), self._gp(wn), self._gp(wn[:-6] + "bias"),
+                                 ws.data_ptr(), BS, 64, 64, code, self._acc)
+                    else:
+                        self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i], bias_name=wn[:-6] + "bias")
+                        self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dc[i].data_ptr(), B=self.Wd[wn].data_ptr(), C=dpl[i - 1].data_ptr(),
+                                   ldb=9 * chans[i], ldc=chans[i - 1], M=BS * sizes[i] * sizes[i], N=chans[i - 1], K=9 * chans[i],
+                                   H=sizes[i], W=sizes[i], Cin=chans[i], out_bf16=int(code == BF16))
+        self._acc = 0
         return p
 
     # ------------------------------------------------------------------ execution API
@@ -745,16 +756,16 @@ class Engine:
         self.run(p.bwd_rest)
         self.run(p.bwd_tok)
 
-    def adam_ranges(self, S, weight_decay):
-        return self.layout.adam_ranges(S, weight_decay)
+    def adam_ranges(self, S, weight_decay, skip=None):
+        return self.layout.adam_ranges(S, weight_decay, skip)
 
-    def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None):
+    def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None, skip=None):
         """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[4] {lr, 1-b1^t, 1-b2^t, grad_scale}
         read by the kernel at run time, so a captured launch can be replayed with new values."""
         if self.M is None:
             self.M = torch.zeros_like(self.G)
             self.V = torch.zeros_like(self.G)
-        rng = self.adam_ranges(S, weight_decay)
+        rng = self.adam_ranges(S, weight_decay, skip)
         n = len(rng)
         starts = (C.c_int64 * n)(*[r[0] for r in rng])
         ends = (C.c_int64 * n)(*[r[1] for r in rng])

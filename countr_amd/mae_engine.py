@@ -54,7 +54,7 @@ class MaeEngine(Engine):
     def _conv_names(self):
         return []
 
-    def adam_ranges(self, S, weight_decay):
+    def adam_ranges(self, S, weight_decay, skip=None):
         return [(s, e, 0.0 if nodecay else weight_decay) for (_b, nodecay), s, e in self.layout.segments]
 
     # ------------------------------------------------------------------ timm Block (x += attn(norm1 x); x += mlp(norm2 x))
@@ -185,36 +185,40 @@ class MaeEngine(Engine):
         if not train:
             return p
 
-        # =========================== backward ===========================
-        ops = p.bwd_dec
-        dpred = A("dpred", (rn, F), T)
-        ddn = A("ddn", (rn, Dd), T)
-        sd = self._bwd_scratch(p, "dec", rn, Dd)
-        self._linear_bwd(ops, dpred, dn, "decoder_pred.weight", rn, F, Dd, dx=ddn)
-        g_t = self._layernorm_bwd(ops, ddn, x, "decoder_norm", mN, rN, sd["gx"], rn, Dd, accumulate=False, dx_t=sd["gxT"])
-        for i in reversed(range(self.ddepth)):
-            g_t = self._block_bwd(ops, "decoder_blocks.%d" % i, dec[i], sd, B, N, Dd, Hd, g_t)
-        # mask_token: sum of the gradient rows at masked positions (models_mae_noct.py:166-167)
-        if rn > rk:
-            gm = A("gmask", (rn - rk, Dd), f32)
-            ws = self._shared("colsum", 256 * 4096)
-            self._op(ops, L.countr_gather_rows, sd["gx"].data_ptr(), mask_src.data_ptr(), gm.data_ptr(), None, None, 0, rn - rk, Dd, F32,
-                     F32)
-            self._op(ops, L.countr_colsum, gm.data_ptr(), self._gp("mask_token"), ws.data_ptr(), rn - rk, Dd, F32, 0)
-        ge = A("ge", (rk, Dd), T)
-        self._op(ops, L.countr_gather_rows, sd["gx"].data_ptr(), keep_src.data_ptr(), ge.data_ptr(), None, None, 0, rk, Dd, F32, code)
-        dlat = A("dlat", (rk, D), T)
-        self._linear_bwd(ops, ge, latent, "decoder_embed.weight", rk, Dd, D, dx=dlat)
+        p.acc = MaePlan()            # the same lists with parameter gradients accumulated (gradient accumulation, micro-steps 2..)
+        for acc, lists in ((0, p), (1, p.acc)):
+            self._acc = acc
+            # =========================== backward ===========================
+            ops = lists.bwd_dec
+            dpred = A("dpred", (rn, F), T)
+            ddn = A("ddn", (rn, Dd), T)
+            sd = self._bwd_scratch(p, "dec", rn, Dd)
+            self._linear_bwd(ops, dpred, dn, "decoder_pred.weight", rn, F, Dd, dx=ddn)
+            g_t = self._layernorm_bwd(ops, ddn, x, "decoder_norm", mN, rN, sd["gx"], rn, Dd, accumulate=False, dx_t=sd["gxT"])
+            for i in reversed(range(self.ddepth)):
+                g_t = self._block_bwd(ops, "decoder_blocks.%d" % i, dec[i], sd, B, N, Dd, Hd, g_t)
+            # mask_token: sum of the gradient rows at masked positions (models_mae_noct.py:166-167)
+            if rn > rk:
+                gm = A("gmask", (rn - rk, Dd), f32)
+                ws = self._shared("colsum", 256 * 4096)
+                self._op(ops, L.countr_gather_rows, sd["gx"].data_ptr(), mask_src.data_ptr(), gm.data_ptr(), None, None, 0, rn - rk, Dd, F32,
+                         F32)
+                self._op(ops, L.countr_colsum, gm.data_ptr(), self._gp("mask_token"), ws.data_ptr(), rn - rk, Dd, F32, self._acc)
+            ge = A("ge", (rk, Dd), T)
+            self._op(ops, L.countr_gather_rows, sd["gx"].data_ptr(), keep_src.data_ptr(), ge.data_ptr(), None, None, 0, rk, Dd, F32, code)
+            dlat = A("dlat", (rk, D), T)
+            self._linear_bwd(ops, ge, latent, "decoder_embed.weight", rk, Dd, D, dx=dlat)
 
-        bucket = mae_bucket_fn(self.depth)
-        ops = p.bwd_enc[0]
-        se = self._bwd_scratch(p, "enc", rk, D)
-        g_t = self._layernorm_bwd(ops, dlat, x_enc_out, "norm", mE, rE, se["gx"], rk, D, accumulate=False, dx_t=se["gxT"])
-        for i in reversed(range(self.depth)):
-            ops = p.bwd_enc[bucket("blocks.%d.norm1.weight" % i) - 1]
-            g_t = self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H, g_t)
-        ops = p.bwd_enc[2]
-        self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
+            bucket = mae_bucket_fn(self.depth)
+            ops = lists.bwd_enc[0]
+            se = self._bwd_scratch(p, "enc", rk, D)
+            g_t = self._layernorm_bwd(ops, dlat, x_enc_out, "norm", mE, rE, se["gx"], rk, D, accumulate=False, dx_t=se["gxT"])
+            for i in reversed(range(self.depth)):
+                ops = lists.bwd_enc[bucket("blocks.%d.norm1.weight" % i) - 1]
+                g_t = self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H, g_t)
+            ops = lists.bwd_enc[2]
+            self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
+        self._acc = 0
         return p
 
     # ------------------------------------------------------------------ execution API

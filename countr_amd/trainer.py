@@ -18,8 +18,11 @@ class _GraphStep:
     """Shared machinery of the optimisation steps: dedicated stream, per-phase hipGraph capture/replay, bucketed gradient
     all-reduce behind the backward phases, host-batch staging on a copy stream, device-side AdamW scalars."""
 
-    def __init__(self, model, batch, lr, weight_decay, betas, eps, use_graph, process_group):
+    def __init__(self, model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter=1):
         self.model = model
+        self.accum = int(accum_iter)   # micro-steps per optimisation step (reference --accum_iter: loss / accum_iter, update every
+        self._micro = 0                # accum_iter-th iteration -- FSC_finetune_cross.py:300-305); gradients accumulate in eng.G
+        self._touched = set()          # conditional buckets that received a gradient in the current accumulation window
         self.eng = model._engine()
         self.B = batch
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -40,7 +43,7 @@ class _GraphStep:
         self.world = self.sync.world
         self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._ring_ev = [None] * 16
-        self.grad_scale = 1.0
+        self.grad_scale = 1.0 / self.accum
 
     def _make_sync(self, process_group):
         return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
@@ -78,16 +81,21 @@ class _GraphStep:
             self._consumed_ev = torch.cuda.Event()
             self._consumed_ev.record(self.stream)
 
-    def _phases(self):          # [(graph key, launcher)]: forward + loss + first backward part, then the remaining backward parts
-        return [("a", self._phase_a), ("b", self._phase_b)]
+    def _phases(self, key):     # [(name, launcher, graph key)]: forward + loss + first backward part, then the remaining backward parts
+        raise NotImplementedError
 
     def _skip(self, key):
         return ()
 
-    def _phase_c(self, S):
-        self.eng.adamw_launch(S, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper)
+    def _lists(self, plan, acc):
+        """The plan's backward launch lists that overwrite (first micro-step) or accumulate into (later ones) eng.G."""
+        return plan.acc if acc else plan
+
+    def _phase_c(self, skip):
+        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip)
 
     def _run_phase(self, name, fn, S):
+        """S: hashable argument of the phase; (name, S) identifies its captured graph."""
         if not self.use_graph:
             fn(S)
             return
@@ -128,33 +136,43 @@ class _GraphStep:
         """backward phases in bucket order: after phase i the gradients of bucket i are final and its all-reduce starts on the
         side stream, overlapping phase i+1; the last phase's bucket(s) are reduced by finish(); then the fused AdamW."""
         eng = self.eng
+        last = self._micro + 1 == self.accum      # only the last micro-step of a window reduces and applies the gradients
         with torch.cuda.stream(self.stream):
             if eng.M is None:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
-            phases = self._phases()
-            for i, (name, fn) in enumerate(phases):
-                self._run_phase(name, fn, key)
-                if i + 1 < len(phases):
+            phases = self._phases(key)
+            for i, (name, fn, gkey) in enumerate(phases):
+                self._run_phase(name, fn, gkey)
+                if last and i + 1 < len(phases):
                     self.sync.start(i)
-            self.sync.finish(skip=self._skip(key))
-            self._upload_hyper()
-            self._run_phase("c", self._phase_c, key)
+            if last:
+                skip = tuple(self._skip(key))
+                self.sync.finish(skip=skip)
+                self._upload_hyper()
+                self._run_phase("c", self._phase_c, skip)
         torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
-        self.model.mark_weights_synced()
+        if last:
+            self.model.mark_weights_synced()
+            self._micro = 0
+            self._touched = set()
+        else:
+            self._micro += 1
+        return last
 
 
 class FinetuneStep(_GraphStep):
     def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None):
-        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group)
+                 process_group=None, accum_iter=1):
+        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter)
         self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
         self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
 
     # ------------------------------------------------------------------ phases
-    def _phase_a(self, S):
+    def _phase_a(self, key):
         """forward + loss (+ dL/dout) + backward until the head/decoder_norm gradients (bucket 0) are final."""
+        S, acc = key
         eng = self.eng
         p = eng.plan(self.B, S, True)
         eng.run(p.fwd)
@@ -164,24 +182,31 @@ class FinetuneStep(_GraphStep):
         HW = eng.img * eng.img
         _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
                                            sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
-        eng.run(p.bwd_head)
+        eng.run(self._lists(p, acc).bwd_head)
 
     def _make_sync(self, process_group):
         lay = self.eng.layout   # buckets in backward-completion order: head | decoder blocks + embed | exemplar CNN | shot_token
         return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
 
     def _skip(self, S):
-        """Parameters without a gradient for this shot_num are neither reduced nor stepped (as torch AdamW skips grad None)."""
-        return (2,) if S == 0 else (3,)
+        """Parameters without a gradient in this window (exemplar CNN when every micro-step had shot_num 0, shot_token when none
+        had) are neither reduced nor stepped, as torch AdamW skips grad None."""
+        return tuple(b for b in (2, 3) if b not in self._touched)
 
-    def _phase_b(self, S):
-        self.eng.run(self.eng.plan(self.B, S, True).bwd_rest)
+    def _phase_b(self, key):
+        S, acc = key
+        self.eng.run(self._lists(self.eng.plan(self.B, S, True), acc).bwd_rest)
 
-    def _phase_b2(self, S):
-        self.eng.run(self.eng.plan(self.B, S, True).bwd_tok)
+    def _phase_b2(self, key):
+        S, acc = key
+        self.eng.run(self._lists(self.eng.plan(self.B, S, True), acc).bwd_tok)
 
-    def _phases(self):
-        return [("a", self._phase_a), ("b", self._phase_b), ("b2", self._phase_b2)]
+    def _phases(self, S):
+        acc = int(self._micro > 0)
+        tok = 3 if S == 0 else 2                     # the conditional bucket this shot_num writes: accumulate only if the window
+        acc_tok = int(tok in self._touched)          # already wrote it (shot_num may change between micro-steps)
+        self._touched.add(tok)
+        return [("a", self._phase_a, (S, acc)), ("b", self._phase_b, (S, acc)), ("b2", self._phase_b2, (S, acc_tok))]
 
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
@@ -201,11 +226,12 @@ class FinetuneStep(_GraphStep):
                 t.record_stream(self.stream)
 
     def step(self, S, lr=None):
-        """One optimisation step on the inputs last given to load().  Returns the device tensor
-        [loss, pred counts (B), gt counts (B)] without synchronising the host."""
+        """One (micro-)step on the inputs last given to load(): with accum_iter == k, every k-th call reduces the accumulated
+        gradients and applies AdamW (self.applied tells which).  Returns the device tensor
+        [loss, pred counts (B), gt counts (B)] of this batch without synchronising the host."""
         if lr is not None:
             self.lr = lr
-        self._step(S)
+        self.applied = self._step(S)
         return self.sums[S]
 
 
@@ -216,25 +242,26 @@ class PretrainStep(_GraphStep):
     captured region, so every replay sees fresh indices through the plan's index buffers)."""
 
     def __init__(self, model, batch, mask_ratio=0.5, lr=5e-6, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None, accum_scale=1.0):
-        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group)
+                 process_group=None, accum_iter=1):
+        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter)
         self.K = model.len_keep(mask_ratio)
-        self.grad_scale = accum_scale
 
-    def _phase_a(self, K):
+    def _phase_a(self, key):
+        K, acc = key
         eng = self.eng
         p = eng.plan(self.B, K, True)
         eng.run(p.fwd)
         eng.loss_launch(p, self.B, self.model.norm_pix_loss)
-        eng.run(p.bwd_dec)
+        eng.run(self._lists(p, acc).bwd_dec)
 
     def _make_sync(self, process_group):
         lay = self.eng.layout   # decoder side | encoder thirds from the top (mae_engine.mae_bucket_fn)
         return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
 
-    def _phases(self):
-        enc = lambda j: (lambda K: self.eng.run(self.eng.plan(self.B, K, True).bwd_enc[j]))
-        return [("a", self._phase_a), ("b", enc(0)), ("b2", enc(1)), ("b3", enc(2))]
+    def _phases(self, K):
+        acc = int(self._micro > 0)
+        enc = lambda j: (lambda key: self.eng.run(self._lists(self.eng.plan(self.B, key[0], True), key[1]).bwd_enc[j]))
+        return [("a", self._phase_a, (K, acc)), ("b", enc(0), (K, acc)), ("b2", enc(1), (K, acc)), ("b3", enc(2), (K, acc))]
 
     def load(self, imgs, ids_shuffle=None):
         cur = torch.cuda.current_stream(self.eng.device)
@@ -256,5 +283,5 @@ class PretrainStep(_GraphStep):
         pred / mask of the step stay in eng.plan(B, K, True).buf["pred" / "mask"]."""
         if lr is not None:
             self.lr = lr
-        self._step(self.K)
+        self.applied = self._step(self.K)
         return self.eng.plan(self.B, self.K, True).buf["loss"]

@@ -51,7 +51,7 @@ def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
     assert os.path.exists(ckpt)
     # --do_resume restores epoch and the flat AdamW state and continues with epoch 1
     log = run(["FSC_finetune_cross.py", "--data_path", "/nonexistent", "--synthetic_steps", "2", "--batch_size", "2", "--epochs", "2",
-               "--warmup_epochs", "0", "--output_dir", out, "--resume", ckpt, "--do_resume", "--log_every", "1"])
+               "--warmup_epochs", "0", "--output_dir", out, "--resume", ckpt, "--do_resume", "--log_every", "1", "--accum_iter", "2"])
     assert "With optim & sched!" in log
     assert [json.loads(l)["epoch"] for l in log.splitlines() if l.startswith("{")] == [1, 1]
     log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "test", "--box_bound", "3"])
@@ -72,7 +72,7 @@ def test_pretrain_cli_on_files_and_synthetic_fallback(fake_fsc, tmp_path):
     # resume from our own checkpoint (flat AdamW state restored), synthetic images
     log = run(["FSC_pretrain.py", "--data_path", "/nonexistent", "--batch_size", "2", "--epochs", "2", "--warmup_epochs", "0",
                "--synthetic_steps", "2", "--output_dir", out, "--resume", os.path.join(out, "checkpoint__pretraining_0.pth"),
-               "--log_every", "1"])
+               "--log_every", "1", "--accum_iter", "2"])
     assert "With optim & sched!" in log
     lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
     assert [l["epoch"] for l in lines] == [1, 1]

@@ -183,3 +183,36 @@ def test_pretrain_steps_match_oracle(use_graph):
         for k, p in m.named_parameters():
             d = (p.detach().cpu().double() - ref[k]).abs()
             assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (it + 1), (it, k)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pretrain_gradient_accumulation(use_graph):
+    """--accum_iter 2 (FSC_pretrain.py:283-288): two micro-batches per AdamW step, gradients averaged."""
+    from countr_amd.trainer import PretrainStep
+    from countr_amd.engine import no_weight_decay
+    from oracle import countr_ref as R
+    name = "tiny_test"
+    m, sd = build(name, "fp32", seed=5)
+    step = PretrainStep(m, batch=2, mask_ratio=0.5, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph, accum_iter=2)
+    ref = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    for w in range(3):
+        cur = {k: v.float().numpy() for k, v in ref.items()}
+        acc = {}
+        for j in range(2):
+            imgs, ids_shuffle, ids_restore, len_keep = W.make_mae_inputs(batch=2, seed=40 + 2 * w + j, mask_ratio=0.5)
+            step.load(torch.from_numpy(imgs).cuda(), torch.from_numpy(ids_shuffle).cuda())
+            loss = step.step().clone()
+            assert step.applied == (j == 1)
+            rl, _, _, rg = M.loss_and_grads(cur, imgs, ids_shuffle, ids_restore, len_keep, name)
+            assert abs(loss.item() - rl.item()) <= 1e-4 * rl.item(), (w, j)
+            for k, g in rg.items():
+                acc[k] = acc.get(k, 0) + g.double() / 2
+        torch.cuda.synchronize()
+        for k, g in acc.items():
+            wd = 0.0 if no_weight_decay(k, ref[k].shape) else 0.05
+            ref[k], m1, m2 = R.adamw_step(ref[k], g, mom[k][0], mom[k][1], w + 1, 1e-3, eps=1e-4, wd=wd)
+            mom[k] = (m1, m2)
+        for k, p in m.named_parameters():
+            d = (p.detach().cpu().double() - ref[k]).abs()
+            assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (w + 1), (w, k)

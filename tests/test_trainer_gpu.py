@@ -115,3 +115,42 @@ def test_host_batches_are_staged_and_match_device_batches():
         res[mode] = torch.stack(out)
     assert torch.equal(res["device"], res["host"])
     assert torch.isfinite(res["host"]).all()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gradient_accumulation_matches_oracle(use_graph):
+    """--accum_iter 2 (FSC_finetune_cross.py:300-305: loss / accum_iter, optimizer step every accum_iter-th iteration): the
+    accumulated gradient is the mean over the window's micro-batches; shot_num changes inside a window, so a conditional
+    parameter set (exemplar CNN / shot_token) steps iff some micro-step of the window gave it a gradient."""
+    from countr_amd.trainer import FinetuneStep
+    from countr_amd.engine import no_weight_decay
+    m, sd = make("fp32")
+    step = FinetuneStep(m, batch=2, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph, accum_iter=2)
+    ref = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    seed = 50
+    for w, shots in enumerate([(3, 0), (0, 0), (2, 3)]):
+        cur = {k: v.float().numpy() for k, v in ref.items()}
+        acc = {}
+        for j, S in enumerate(shots):
+            imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=seed)
+            seed += 1
+            step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+            sums = step.step(S).clone()
+            assert step.applied == (j == 1)
+            _, rloss, rg = R.loss_and_grads(cur, imgs, boxes, gt, mask, S, NAME)
+            assert abs(sums[0].item() - rloss.item()) <= 2e-3 * abs(rloss.item()), (w, j)   # the logged loss is not divided
+            for k, g in rg.items():
+                if g is not None:
+                    acc[k] = acc.get(k, 0) + g.double() / 2
+        torch.cuda.synchronize()
+        for k, g in acc.items():
+            wd = 0.0 if no_weight_decay(k, ref[k].shape) else 0.05
+            # the fused AdamW keeps ONE step counter (bias correction) for the whole flat buffer
+            ref[k], m1, m2 = R.adamw_step(ref[k], g, mom[k][0], mom[k][1], w + 1, 1e-3, eps=1e-4, wd=wd)
+            mom[k] = (m1, m2)
+        for k, p in m.named_parameters():
+            d = (p.detach().cpu().double() - ref[k]).abs()
+            assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (w + 1), (w, k)
+            if not k.startswith("decoder_proj"):
+                assert d.max().item() <= 0.25 * 1e-3 * (w + 1), (w, k, d.max().item())
