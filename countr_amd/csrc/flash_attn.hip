@@ -16,8 +16,30 @@
 
 namespace {
 
+// COUNTR_FA_ABL (timing experiments only, results are wrong): 1 = no MFMA, 2 = no exp2 (p = fma), 3 = K/V staged only once,
+// 4 = 3 + no per-tile barrier, 5 = no softmax at all (p = s), 6 = empty kernel, 7 = one K/V tile only
+#ifndef COUNTR_FA_ABL
+#define COUNTR_FA_ABL 0
+#endif
 constexpr int FA_BQ = 128;   // query rows per workgroup
 constexpr int FA_BKV = 64;   // keys per tile
+// Bytes per LDS row of a staged [rows][DH] bf16 tile.  Row pitch = 32 mod 64 bytes makes BOTH fragment reads conflict-free over
+// the 64 LDS banks: ds_read_b128 (16 rows x one 16-byte chunk per 16-lane group) and ds_read_b64_tr_b16 (8 rows x 4 chunks of
+// 8 bytes per 32-lane group).  The former DH*2 + 16 pitch was 2-way conflicted on both (tools/lds_banks.py enumerates them).
+#ifndef COUNTR_FA_PAD
+#define COUNTR_FA_PAD 32
+#endif
+constexpr int fa_pitch(int dh) { return dh * 2 + COUNTR_FA_PAD; }
+
+// max over the four lanes {l, l^16, l^32, l^48} on the VALU (gfx950 v_permlane16/32_swap): the ds_bpermute form of
+// __shfl_xor costs an LDS round trip and an lgkmcnt(0) that also drains the K/V fragment reads in flight.
+__device__ __forceinline__ float quad_rows_max(float x) {
+  float t;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1\n\t"
+               "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1"
+               : "+v"(x), "=&v"(t));
+  return x;
+}
 
 // QT = 16-query MFMA tiles per wave (2: 128 query rows per workgroup; 1: 64 rows -> twice the waves in flight, which is what a
 // small launch such as B = 8 x 12 heads needs to hide LDS / barrier latency, at twice the K/V fragment reads per MFMA)
@@ -26,7 +48,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
                                                              float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
   constexpr int KS = DH / 32;          // k-steps over head dim for QK^T
   constexpr int DT = DH / 16;          // 16-wide tiles of the head dim for O
-  constexpr int PITCH = DH * 2 + 16;   // bytes per LDS row
+  constexpr int PITCH = fa_pitch(DH);   // bytes per LDS row
   constexpr int TILE = BKV * PITCH;
   constexpr int KT = BKV / 16;         // 16-key MFMA tiles per staged KV tile
   constexpr int PS = BKV / 32;         // 32-key PV k-steps
@@ -35,6 +57,9 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];  // stage s: K at s*2*TILE, V behind it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+#if COUNTR_FA_ABL == 6
+  if (N > 0) return;
+#endif
   constexpr int BQ = 64 * QT;         // query rows per workgroup
   const int qblocks = (N + BQ - 1) / BQ;
   // XCD-aware mapping: workgroup id b runs on XCD b % 8 (observed dispatch order; affects speed only).  All query
@@ -78,7 +103,11 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
 
+#if COUNTR_FA_ABL == 7
+  const int ntiles = 1;
+#else
   const int ntiles = (N + BKV - 1) / BKV;
+#endif
   uint4 kreg[PASSES], vreg[PASSES];
   auto gload = [&](int t) {
 #pragma unroll
@@ -110,7 +139,11 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
+#if COUNTR_FA_ABL == 3 || COUNTR_FA_ABL == 4
+    if (more && t == 0) gload(t + 1);
+#else
     if (more) gload(t + 1);
+#endif
     const char* Ks = smem + (t & 1) * 2 * TILE;
     const char* Vs = Ks + TILE;
 
@@ -127,7 +160,13 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
       for (int kt = 0; kt < KT; ++kt) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) {
+#if COUNTR_FA_ABL == 1
+          s[kt][qt][0] += __builtin_bit_cast(float, (int)kf[0] | ((int)qf[qt][ks][0] << 16));
+#else
+          s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+#endif
+        }
       }
 
     if (RAGGED && (t + 1) * BKV > N) {  // ragged last tile: keys >= N do not exist (variant only built for N % BKV != 0)
@@ -145,13 +184,15 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     bf16x8_t pf[QT][PS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+#if COUNTR_FA_ABL == 5
+      l[qt] += s[0][qt][0];
+#else
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad_rows_max(mx);
       // deferred rescale: while the running max grows by <= 8 (log2 units) keep the old reference max -- P stays
       // <= 2^8, exact in the fp32 row sum and well inside bf16 range -- and skip the O / l rescale for this tile.
       const float mloc = mx * c;
@@ -172,11 +213,16 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#if COUNTR_FA_ABL == 2
+          const float p = __builtin_fmaf(s[kt][qt][r], c, -mref);
+#else
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c, -mref));
+#endif
           s[kt][qt][r] = p;
           rsum += p;
         }
       l[qt] += rsum;
+#endif
 #pragma unroll
       for (int ps = 0; ps < PS; ++ps) {
         const uint4 pk = make_uint4(pack2bf(s[2 * ps][qt][0], s[2 * ps][qt][1]), pack2bf(s[2 * ps][qt][2], s[2 * ps][qt][3]),
@@ -202,12 +248,26 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
         vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vv);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ps], o[dt][qt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) {
+#if COUNTR_FA_ABL == 1
+          o[dt][qt][0] += __builtin_bit_cast(float, (int)vf[0] | ((int)pf[qt][ps][0] << 16));
+#else
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ps], o[dt][qt], 0, 0, 0);
+#endif
+        }
       }
 
 
+#if COUNTR_FA_ABL == 3 || COUNTR_FA_ABL == 4
+    if (more && t == 0) lstore((t + 1) & 1);
+#else
     if (more) lstore((t + 1) & 1);
+#endif
+#if COUNTR_FA_ABL == 4
+    if (t == 0) __syncthreads();
+#else
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: normalise and store; lane (li, g) owns query q and channels dt*16 + 4g .. +3
@@ -237,20 +297,35 @@ extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   if (!qkv || !out || B <= 0 || N <= 0 || H <= 0) { countr_set_error("countr_attn_fwd: bad args"); return -1; }
   const float c = scale * 1.4426950408889634f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const bool ragged = (N % 64) != 0;
+  // keys per staged K/V tile: 128 halves the barriers / exposed waits per key (COUNTR_ATTN_BKV overrides)
+  static const int force_bkv = [] { const char* e = getenv("COUNTR_ATTN_BKV"); return e ? atoi(e) : 0; }();
+  const int bkv = force_bkv ? force_bkv : 64;
+  const bool ragged = (N % bkv) != 0;
   // 64 query rows per workgroup for small dh = 32 launches (measured at B = 8: 17.3 vs 18.3 us); dh = 64 is faster with 128
   // rows at every batch size (B = 8: 20.4 vs 21.8 us, B = 32: 64.8 vs 69.6 us)
   static const int force_qt = [] { const char* e = getenv("COUNTR_ATTN_QT"); return e ? atoi(e) : 0; }();
   const long wg128 = (long)B * H * ((N + 127) / 128);
   const int qt = force_qt ? force_qt : ((dh == 32 && wg128 < 768) ? 1 : 2);
   dim3 grid(B * H * ((N + 64 * qt - 1) / (64 * qt))), block(256);
-#define COUNTR_FA_LAUNCH(DHV, RG, QTV)                                                                                         \
-  hipLaunchKernelGGL((flash_attn_fwd_kernel<DHV, 64, RG, QTV>), grid, block, 4 * 64 * (DHV * 2 + 16), s, (const bf16_t*)qkv,   \
-                     (bf16_t*)out, lse, N, H, c)
+#define COUNTR_FA_LAUNCH(DHV, BKVV, RG, QTV)                                                                                   \
+  do {                                                                                                                         \
+    constexpr int lds_ = 4 * BKVV * fa_pitch(DHV);                                                                                \
+    if (lds_ > 65536) {                                                                                                        \
+      static const bool once_ = [] {                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel<DHV, BKVV, RG, QTV>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                           \
+        return true;                                                                                                           \
+      }();                                                                                                                     \
+      (void)once_;                                                                                                             \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((flash_attn_fwd_kernel<DHV, BKVV, RG, QTV>), grid, block, lds_, s, (const bf16_t*)qkv, (bf16_t*)out,    \
+                       lse, N, H, c);                                                                                          \
+  } while (0)
 #define COUNTR_FA_DISPATCH(DHV)                                                                                                \
   do {                                                                                                                         \
-    if (qt == 1) { if (ragged) COUNTR_FA_LAUNCH(DHV, true, 1); else COUNTR_FA_LAUNCH(DHV, false, 1); }                       \
-    else { if (ragged) COUNTR_FA_LAUNCH(DHV, true, 2); else COUNTR_FA_LAUNCH(DHV, false, 2); }                               \
+    if (bkv == 128 && qt == 2) { if (ragged) COUNTR_FA_LAUNCH(DHV, 128, true, 2); else COUNTR_FA_LAUNCH(DHV, 128, false, 2); } \
+    else if (qt == 1) { if (ragged) COUNTR_FA_LAUNCH(DHV, 64, true, 1); else COUNTR_FA_LAUNCH(DHV, 64, false, 1); }            \
+    else { if (ragged) COUNTR_FA_LAUNCH(DHV, 64, true, 2); else COUNTR_FA_LAUNCH(DHV, 64, false, 2); }                         \
   } while (0)
   if (dh == 64) COUNTR_FA_DISPATCH(64);
   else if (dh == 32) COUNTR_FA_DISPATCH(32);
@@ -282,7 +357,7 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
                                                              float scale) {
-  constexpr int KS = DH / 32, DT = DH / 16, PITCH = DH * 2 + 16, TILE = FA_BKV * PITCH, CPR = DH / 8;
+  constexpr int KS = DH / 32, DT = DH / 16, PITCH = fa_pitch(DH), TILE = FA_BKV * PITCH, CPR = DH / 8;
   constexpr int PASSES = (FA_BKV * CPR) / 256;
   constexpr int STAGE = 2 * TILE + 512;  // two streamed tiles + (MODE 1) 64 lse2 + 64 delta floats
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -514,7 +589,7 @@ int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const fl
                     int H, float scale, hipStream_t s) {
   const int rblocks = (N + FA_BQ - 1) / FA_BQ;
   dim3 grid(B * H * rblocks), block(256);
-  const size_t lds = 2 * (2 * FA_BKV * (DH * 2 + 16) + 512);
+  const size_t lds = 2 * (2 * FA_BKV * fa_pitch(DH) + 512);
   if (N % FA_BKV) {
     hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
                        lse, delta, (bf16_t*)dqkv, N, H, scale);

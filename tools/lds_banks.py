@@ -1,0 +1,33 @@
+import itertools
+G128 = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
+G128 += [[l+32 for l in g] for g in G128]
+def cycles(addr_fn, groups, width_dw, nb=64):
+    tot=0
+    for g in groups:
+        banks={}
+        for l in g:
+            a=addr_fn(l)
+            for d in range(width_dw):
+                b=(a//4+d)%nb
+                banks.setdefault(b,set()).add((a//4+d))
+        tot+=max(len(v) for v in banks.values())
+    return tot
+def kread(P, ks=0, kt=0, swz=None):
+    def f(l):
+        li=l&15; g=l>>4
+        row=kt*16+li; col=(ks*32+g*8)*2
+        if swz: col ^= swz(row)
+        return row*P+col
+    return cycles(f,G128,4)
+def vread(P, ps=0, dt=0, hi=0, swz=None):
+    def f(l):
+        li=l&15; g=l>>4
+        row=ps*32+4*g+(li>>2)+16*hi; col=(dt*16+(li&3)*4)*2
+        if swz: col ^= swz(row)
+        return row*P+col
+    return cycles(f,[list(range(32)),list(range(32,64))],2)
+for P in range(128,209,16):
+    print(P, [kread(P,ks,0) for ks in range(2)], [vread(P,0,dt,hi) for dt in range(4) for hi in range(2)])
+print("dh32")
+for P in range(64,161,16):
+    print(P, [kread(P,0,0)], [vread(P,0,dt,hi) for dt in range(2) for hi in range(2)])
