@@ -108,17 +108,19 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 #else
   const int ntiles = (N + BKV - 1) / BKV;
 #endif
-  uint4 kreg[PASSES], vreg[PASSES];
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;   // (a plain vector type: HIP's uint4 struct went to scratch here)
+  u32x4_t kreg[PASSES], vreg[PASSES];
   auto gload = [&](int t) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int cidx = tid + 256 * ps;
       const int key = t * BKV + cidx / CPR, cc = cidx % CPR;
-      kreg[ps] = make_uint4(0, 0, 0, 0);
-      vreg[ps] = make_uint4(0, 0, 0, 0);
-      if (key < N) {
-        kreg[ps] = *reinterpret_cast<const uint4*>(kp + (int64_t)key * rs + cc * 8);
-        vreg[ps] = *reinterpret_cast<const uint4*>(vp + (int64_t)key * rs + cc * 8);
+      if (!RAGGED || key < N) {   // every key exists when N % BKV == 0: no exec-mask branch in the tile loop
+        kreg[ps] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)key * rs + cc * 8);
+        vreg[ps] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)key * rs + cc * 8);
+      } else {
+        kreg[ps] = u32x4_t{0, 0, 0, 0};
+        vreg[ps] = u32x4_t{0, 0, 0, 0};
       }
     }
   };
@@ -128,8 +130,8 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
     for (int ps = 0; ps < PASSES; ++ps) {
       const int cidx = tid + 256 * ps;
       const int off = (cidx / CPR) * PITCH + (cidx % CPR) * 16;
-      *reinterpret_cast<uint4*>(ks_ + off) = kreg[ps];
-      *reinterpret_cast<uint4*>(ks_ + TILE + off) = vreg[ps];
+      *reinterpret_cast<u32x4_t*>(ks_ + off) = kreg[ps];
+      *reinterpret_cast<u32x4_t*>(ks_ + TILE + off) = vreg[ps];
     }
   };
 
@@ -270,22 +272,32 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 #endif
   }
 
-  // ---- epilogue: normalise and store; lane (li, g) owns query q and channels dt*16 + 4g .. +3
+  // ---- epilogue: normalise, stage the wave's [16*QT][DH] bf16 block through LDS (the K/V ring is free after the last barrier)
+  // and store whole rows: 16-byte chunks, 8 (dh 64) or 4 (dh 32) consecutive lanes per 128 / 64-byte row segment, instead of
+  // one 8-byte store per lane and MFMA tile at a row stride.  Lane (li, g) owns query q and channels dt*16 + 4g .. +3.
+  char* ost = smem + wave * (16 * QT) * PITCH;
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
     const int q = q0 + qt * 16 + li;
-    if (q >= N) continue;
     const float inv = 1.f / lt;
-    bf16_t* orow = out + ((int64_t)b * N + q) * (H * DH) + h * DH;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      const float v[4] = {o[dt][qt][0] * inv, o[dt][qt][1] * inv, o[dt][qt][2] * inv, o[dt][qt][3] * inv};
-      st4<bf16_t>(orow + dt * 16 + g * 4, v);
+      const uint2 pk = make_uint2(pack2bf(o[dt][qt][0] * inv, o[dt][qt][1] * inv), pack2bf(o[dt][qt][2] * inv, o[dt][qt][3] * inv));
+      *reinterpret_cast<uint2*>(ost + (qt * 16 + li) * PITCH + (dt * 16 + g * 4) * 2) = pk;
     }
-    if (lse && g == 0) lse[((int64_t)b * H + h) * N + q] = (m[qt] + log2f(lt)) * 0.6931471805599453f;
+    if (lse && g == 0 && q < N) lse[((int64_t)b * H + h) * N + q] = (m[qt] + log2f(lt)) * 0.6931471805599453f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < (16 * QT * CPR) / 64; ++j) {
+    const int idx = lane + 64 * j, r = idx / CPR, cc = idx % CPR;
+    const int q = q0 + r;
+    const uint4 v = *reinterpret_cast<const uint4*>(ost + r * PITCH + cc * 16);
+    if (q < N) *reinterpret_cast<uint4*>(out + ((int64_t)b * N + q) * (H * DH) + h * DH + cc * 8) = v;
   }
 }
 
