@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_abl
-for n in 1 2 3; do
+for n in ${ABLS:-1 2 3}; do
   if [ ! -f tools/_abl/libcountr_abl$n.so ]; then
     objs=""
     for f in api attention elementwise flash_attn mae norm; do objs="$objs countr_amd/build/$f.hip.o"; done
@@ -13,4 +13,4 @@ for n in 1 2 3; do
   fi
 done
 echo "== baseline"; python tools/bench_gemm.py "$1" 30 2>&1 | grep -v amdgpu.ids
-for n in 1 2 3; do echo "== COUNTR_ABL=$n"; COUNTR_LIB=$PWD/tools/_abl/libcountr_abl$n.so python tools/bench_gemm.py "$1" 30 2>&1 | grep -v amdgpu.ids; done
+for n in ${ABLS:-1 2 3}; do echo "== COUNTR_ABL=$n"; COUNTR_LIB=$PWD/tools/_abl/libcountr_abl$n.so python tools/bench_gemm.py "$1" 30 2>&1 | grep -v amdgpu.ids; done
