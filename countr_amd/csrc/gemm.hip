@@ -851,10 +851,12 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
       // 16-byte chunks, 8 (bf16) or 16 (fp32) consecutive lanes per 128 / 256-byte segment; the fp32 residual is read the same way.
       using OT = std::conditional_t<OBFC, bf16_t, float>;
       constexpr int ES = (int)sizeof(OT), EPC = 16 / ES, CPRW = 64 / EPC, PITCHO = 64 * ES + 16;
-      const bool al = g.C2 == nullptr && g.nbatch <= 1 && (((int64_t)g.ldc * ES) & 15) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.N % EPC) == 0 &&
+      constexpr bool C2OK = OBFC && ACTC == COUNTR_ACT_GELU;   // training fc1: bf16 pre-activation copy staged beside the output
+      const bool al = (g.C2 == nullptr || (C2OK && ((uintptr_t)g.C2 & 15) == 0)) && g.nbatch <= 1 && (((int64_t)g.ldc * ES) & 15) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.N % EPC) == 0 &&
                       (!RESIDC || ((g.ldres & 3) == 0 && ((uintptr_t)g.resid & 15) == 0));
       if (al) {
-        char* ost = smem + wave * 32 * PITCHO;
+        char* ost = smem + wave * (C2OK ? 64 : 32) * PITCHO;
+        const bool copy2 = C2OK && g.C2 != nullptr;
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 #pragma unroll
@@ -868,9 +870,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
             for (int tn = 0; tn < 4; ++tn) {
               float v[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[e] = acc[tm][tn][e] * g.alpha + bv[tn][e];
-                if (ACTC == COUNTR_ACT_GELU) v[e] = gelu_t<T>(v[e]);
+              for (int e = 0; e < 4; ++e) v[e] = acc[tm][tn][e] * g.alpha + bv[tn][e];
+              if constexpr (C2OK) {
+                if (copy2) *reinterpret_cast<uint2*>(dst + 32 * PITCHO + tn * 8) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+              }
+              if (ACTC == COUNTR_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
               }
               if constexpr (OBFC) *reinterpret_cast<uint2*>(dst + tn * 8) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
               else *reinterpret_cast<f32x4v_t*>(dst + tn * 16) = f32x4v_t{v[0], v[1], v[2], v[3]};
@@ -887,6 +893,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
               if constexpr (OBFC) {
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ost + r * PITCHO + cc * 16);
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(g.C) + offC + (int64_t)m * g.ldc + n) = v;
+                if constexpr (C2OK) {
+                  if (copy2)
+                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(g.C2) + offC + (int64_t)m * g.ldc + n) =
+                        *reinterpret_cast<const u32x4_t*>(ost + (32 + r) * PITCHO + cc * 16);
+                }
               } else {
                 f32x4v_t v = *reinterpret_cast<const f32x4v_t*>(ost + r * PITCHO + cc * 16);
                 if constexpr (RESIDC)
