@@ -13,6 +13,7 @@ the trainable decoder-side region ordered by backward completion so that gradien
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -112,6 +113,7 @@ class Plan:
 
     def __init__(self):
         self.fwd = []
+        self.fwd_par = None  # the same launches with the exemplar CNN on a side lane beside the encoder (full forward only)
         self.bwd_head = []   # backward until bucket 0 (head + decoder_norm) gradients are final
         self.bwd_rest = []   # ... until bucket 1 (decoder blocks + decoder_embed) is final
         self.bwd_tok = []    # exemplar tokens: exemplar CNN (bucket 2) or shot_token (bucket 3)
@@ -162,6 +164,10 @@ class Engine:
         self.generation = 0
         self._sides = None
         self.parallel_lanes = False  # measured on MI355X: fork/join of the small backward branches is a wash (9.62 vs 9.56 ms)
+        # forward: exemplar CNN (small launches) on a side lane beside the encoder.  Measured on MI355X at B = 8: finetune step 6.45 vs
+        # 6.20 ms serial (graph fork/join + the CNN's workgroups displacing GEMM tiles), forward only 3.13 vs 3.16 ms: off by
+        # default, COUNTR_OVERLAP_EXEMPLAR=1 enables it
+        self.overlap_exemplar = os.environ.get("COUNTR_OVERLAP_EXEMPLAR", "0") == "1"
 
     def _make_layout(self, named_shapes):
         return ParamLayout(named_shapes)
@@ -275,15 +281,20 @@ class Engine:
         used = set()
         for fn, args, _keep in ops:
             if fn is None:
-                if not self.parallel_lanes:
+                kind = args[0]
+                if kind[0] == "x":           # forward overlap of the exemplar CNN with the encoder (overlap_exemplar)
+                    if not self.overlap_exemplar:
+                        continue
+                    kind = kind[1:]
+                elif not self.parallel_lanes:
                     continue
                 sides = self._side_streams()
-                if args is self.FORK:
+                if kind == "fork":
                     self._fork_ev.record(main)
                     for sd in sides:
                         sd.wait_event(self._fork_ev)
                     used = set()
-                elif args is self.JOIN:
+                elif kind == "join":
                     for k in sorted(used):
                         self._join_ev[k].record(sides[k])
                         main.wait_event(self._join_ev[k])
@@ -521,6 +532,7 @@ class Engine:
                 self._op(ops, L.countr_cast_permute, self._pp("shot_token"), ytok.data_ptr() + b_ * Dd * ytok.element_size(), Dd, 0, 0,
                          0, 0, code)
         else:
+            ex0 = len(ops)
             BS = B * S
             boxes = A("boxes", (BS, 3, 64, 64), f32)
             chans = [64, 128, 256, Dd]
@@ -539,6 +551,7 @@ class Engine:
                 last = i == 3
                 self._op(ops, L.countr_instnorm_relu_pool_fwd, c[i].data_ptr(), (ytok if last else pl[i]).data_ptr(), stats[i].data_ptr(),
                          BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code, in_ws.data_ptr())
+            p.ex_range = (ex0, len(ops))
         blk = []
         for i in range(self.ddepth):
             b = "decoder_blocks.%d" % i
@@ -612,6 +625,13 @@ class Engine:
                 self._op(ops, L.countr_upsample2x_fwd, o1.data_ptr(), out.data_ptr(), B, hs[3], hs[3], 1, F32)
             hc.append(ci)
             hstats.append(si)
+        ex = getattr(p, "ex_range", None)
+        if ex is None:
+            p.fwd_par = p.fwd
+        else:     # [fork | lane 1: exemplar CNN | lane 0: encoder + decoder_embed | join | decoder blocks + head]
+            mark = lambda *a: (None, a, None)
+            p.fwd_par = ([mark("xfork"), mark("xlane", 1)] + p.fwd[ex[0]:ex[1]] + [mark("xlane", 0)] + p.fwd[:ex[0]] + [mark("xjoin")]
+                         + p.fwd[ex[1]:])
         if not train:
             return p
 
@@ -745,7 +765,7 @@ class Engine:
         B = imgs.shape[0]
         p = self.plan(B, int(shot_num), train)
         self._load_inputs(p, imgs, boxes, int(shot_num))
-        self.run(p.fwd)
+        self.run(p.fwd_par)
         return p.buf["out"]
 
     def backward(self, B, shot_num, dout):

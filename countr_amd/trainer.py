@@ -175,7 +175,7 @@ class FinetuneStep(_GraphStep):
         S, acc = key
         eng = self.eng
         p = eng.plan(self.B, S, True)
-        eng.run(p.fwd)
+        eng.run(p.fwd_par)
         if S not in self.sums:
             self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
         sums = self.sums[S]

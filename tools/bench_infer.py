@@ -10,15 +10,15 @@ for B, S in ((1, 3), (8, 3), (32, 0), (32, 3)):
     imgs = torch.rand(B, 3, 384, 384, device="cuda"); boxes = torch.rand(B, 3, 3, 64, 64, device="cuda")
     p = eng.plan(B, S, False)
     eng._load_inputs(p, imgs, boxes, S)
-    for _ in range(3): eng.run(p.fwd)
+    for _ in range(3): eng.run(p.fwd_par)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): eng.run(p.fwd)
+    for _ in range(20): eng.run(p.fwd_par)
     torch.cuda.synchronize(); eager = (time.perf_counter() - t0) / 20
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            eng.run(p.fwd)
+            eng.run(p.fwd_par)
         for _ in range(3): g.replay()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20): g.replay()
