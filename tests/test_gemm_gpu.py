@@ -298,3 +298,46 @@ def test_gemm_randomised_shapes_strides_and_options(hip):
         assert err <= tol * max(ref.abs().max().item(), 1e-3) + 1e-5, (it, dt, ma, mb, M, N, K, pad, err)
         checked += 1
     assert checked == 72
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (1000, 768, 128), (4608, 512, 64), (333 * 8, 2304, 64)])
+def test_gemm_staged_and_direct_epilogues(hip, M, N, K):
+    """bf16 kernels store finished values either as whole rows staged through LDS (16-byte aligned C rows) or directly from the
+    accumulator layout (any other leading dimension / base alignment): both must give the same values, honour M / N tails and
+    leave the padding of a wider C untouched; same for the fp32 residual read and the training pre-activation copy (C2)."""
+    A, B = _mk((M, K), torch.bfloat16, 11), _mk((N, K), torch.bfloat16, 12)
+    bias = _mk((N,), torch.float32, 13)
+    res = _mk((M, N), torch.float32, 14)
+    base = A.double() @ B.double().t()
+    for opt in ("plain", "bias", "bias+gelu", "bias+gelu+c2", "bias+resid", "resid"):
+        for obf in ((1,) if "gelu" in opt else (0,) if "resid" in opt else (0, 1)):
+            odt = torch.bfloat16 if obf else torch.float32
+            for ldc, off in ((N, 0), (N + 8, 0), (N + 4, 0), (N + 8, 4), (N + 4, 4)):
+                store = torch.full((M * ldc + 8,), 7.0, device="cuda", dtype=odt)
+                store2 = torch.full((M * ldc + 8,), 7.0, device="cuda", dtype=odt)
+                a = _lib.GemmArgs()
+                a.alpha = 1.0; a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+                a.A, a.B, a.lda, a.ldb = A.data_ptr(), B.data_ptr(), K, K
+                a.M, a.N, a.K = M, N, K
+                a.C, a.ldc, a.out_bf16 = store.data_ptr() + off * store.element_size(), ldc, obf
+                ref = base
+                if "bias" in opt:
+                    a.bias = bias.data_ptr(); ref = ref + bias.double()
+                pre = ref
+                if "c2" in opt:
+                    a.C2 = store2.data_ptr() + off * store2.element_size()
+                if "gelu" in opt:
+                    a.act = _lib.ACT_GELU; ref = torch.nn.functional.gelu(ref)
+                if "resid" in opt:
+                    a.resid, a.ldres = res.data_ptr(), N; ref = ref + res.double()
+                _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+                torch.cuda.synchronize()
+                tol = 2e-2 if obf else 2e-4
+                for buf, want in ((store, ref), (store2, pre if "c2" in opt else None)):
+                    view = buf[off:off + M * ldc].view(M, ldc)
+                    if want is None:
+                        assert (buf == 7.0).all()
+                        continue
+                    err = (view[:, :N].double() - want).abs().max().item()
+                    assert err <= tol * want.abs().max().item() + 1e-5, (opt, obf, ldc, off, err)
+                    assert (view[:, N:] == 7.0).all() and (buf[:off] == 7.0).all() and (buf[off + M * ldc:] == 7.0).all(), (opt, obf, ldc, off)
