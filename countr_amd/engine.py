@@ -163,7 +163,8 @@ class Engine:
         self._acc = 0                # accumulate flag baked into the parameter-gradient launches being built (gradient accumulation)
         self.generation = 0
         self._sides = None
-        self.parallel_lanes = False  # measured on MI355X: fork/join of the small backward branches is a wash (9.62 vs 9.56 ms)
+        # fork/join of the independent backward branches (wgrad | dgrad | bias grad): measured a wash (9.62 vs 9.56 ms); COUNTR_PARALLEL_LANES=1
+        self.parallel_lanes = os.environ.get("COUNTR_PARALLEL_LANES", "0") == "1"
         # forward: exemplar CNN (small launches) on a side lane beside the encoder.  Measured on MI355X at B = 8: finetune step 6.45 vs
         # 6.20 ms serial (graph fork/join + the CNN's workgroups displacing GEMM tiles), forward only 3.13 vs 3.16 ms: off by
         # default, COUNTR_OVERLAP_EXEMPLAR=1 enables it
