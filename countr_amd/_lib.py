@@ -56,6 +56,7 @@ def _declare(L):
     L.countr_version.argtypes = []
     L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
     L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.countr_reduce_table.argtypes = [vp, i32, i32, vp]
     for name, sig in _SIGS.items():
         fn = getattr(L, name)  # AttributeError here means the .so is stale: rebuild
         fn.argtypes = sig

@@ -1066,7 +1066,64 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
   out[o] = accumulate ? out[o] + s : s;
 }
 
+// Batched deferred reductions (one launch for many (partial slabs -> gradient) sums): table row e = {partial, out,
+// nslabs | accumulate << 32 | wide << 33, slab stride, count, N, taps, first block}; block b serves the entry with blk0[e] <= b < blk0[e+1].
+__global__ void reduce_table_kernel(const long long* __restrict__ tab, int n) {
+  int e = 0;
+  while (e + 1 < n && tab[(e + 1) * 8 + 7] <= (long long)blockIdx.x) ++e;   // uniform scan, n is a few dozen
+  const long long* t = tab + (long long)e * 8;
+  const float* __restrict__ partial = reinterpret_cast<const float*>(t[0]);
+  float* __restrict__ out = reinterpret_cast<float*>(t[1]);
+  const int nslabs = (int)(t[2] & 0xffffffffll), accumulate = (int)((t[2] >> 32) & 1), wide = (int)((t[2] >> 33) & 1);
+  const long long stride = t[3], count = t[4];
+  const int N = (int)t[5], taps = (int)t[6];
+  if (wide) {   // many slabs (LayerNorm block partials): 16 columns x 16 slab groups per block, LDS combine (no permutation)
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, gq = threadIdx.x >> 4;
+    const long long col = ((long long)blockIdx.x - t[7]) * 16 + c;
+    float s = 0.f;
+    if (col < count)
+      for (int z = gq; z < nslabs; z += 16) s += partial[(long long)z * stride + col];
+    red[gq][c] = s;
+    __syncthreads();
+    if (gq == 0 && col < count) {
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += red[k][c];
+      out[col] = accumulate ? out[col] + tot : tot;
+    }
+    return;
+  }
+  const long long i = ((long long)blockIdx.x - t[7]) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = 0;
+  for (; z + 4 <= nslabs; z += 4) {
+    s0 += partial[(long long)z * stride + i];
+    s1 += partial[(long long)(z + 1) * stride + i];
+    s2 += partial[(long long)(z + 2) * stride + i];
+    s3 += partial[(long long)(z + 3) * stride + i];
+  }
+  for (; z < nslabs; ++z) s0 += partial[(long long)z * stride + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  long long o = i;
+  if (taps > 0) {  // [co][tap][ci] -> [co][ci][tap]
+    const int cin = N / taps;
+    const long long co = i / N;
+    const int r = (int)(i - co * N);
+    const int tap = r / cin, ci = r - tap * cin;
+    o = co * N + (long long)ci * taps + tap;
+  }
+  out[o] = accumulate ? out[o] + s : s;
+}
+
 }  // namespace
+
+extern "C" int countr_reduce_table(const long long* table, int n, int total_blocks, void* stream) {
+  if (!table || n <= 0 || total_blocks <= 0) { countr_set_error("countr_reduce_table: bad args"); return -1; }
+  hipLaunchKernelGGL(reduce_table_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, n);
+  COUNTR_LAUNCH_CHECK("countr_reduce_table");
+}
 
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }

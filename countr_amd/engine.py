@@ -14,6 +14,7 @@ the trainable decoder-side region ordered by backward completion so that gradien
 import ctypes as C
 import math
 import os
+import re
 
 import torch
 
@@ -160,6 +161,9 @@ class Engine:
         self._ws = {}
         self._need = {}
         self._sizing = False
+        self._defer = {}             # id(ops) -> (ops, [pending reduction entries]): flushed into countr_reduce_table launches
+        self._tables = []
+        self.defer_reduce = os.environ.get("COUNTR_DEFER_REDUCE", "1") != "0"
         self._acc = 0                # accumulate flag baked into the parameter-gradient launches being built (gradient accumulation)
         self.generation = 0
         self._sides = None
@@ -312,6 +316,44 @@ class Engine:
             if rc != 0:
                 _lib.check(rc, getattr(fn, "__name__", "countr op"))
 
+    # ---- deferred reductions: the split-K slabs of a wgrad, the fused bias-gradient row sums and the LayerNorm dgamma / dbeta block
+    # partials are not finished by one ~5-9 us launch each but collected per launch list and summed by ONE table-driven launch
+    # (countr_reduce_table).  Partial buffers are shared by name with the layer index stripped, so the table is flushed when a
+    # buffer is about to be reused -- once per transformer block: the partials are still cache-resident (deferring a whole
+    # backward pass measured slower for the MAE step: 1.1 GB of partials went out to HBM and back) -- and at the end of a list.
+    @staticmethod
+    def _role(name):
+        return re.sub(r"\d+", "#", name)
+
+    def _reduce_later(self, ops, owner_ptr, partial_ptr, out_ptr, nslabs, stride, count, N=0, taps=0):
+        self._defer.setdefault(id(ops), (ops, []))[1].append((partial_ptr, out_ptr, int(nslabs), int(stride), int(count), int(N),
+                                                               int(taps), int(self._acc), owner_ptr))
+
+    def _claim(self, owner_ptr):
+        """A producer is about to overwrite the partial buffer at owner_ptr: finish the pending sums that still read it."""
+        if self._sizing:
+            return
+        for key, (_ops, entries) in list(self._defer.items()):
+            if any(e[8] == owner_ptr for e in entries):
+                self._flush_list(key)
+
+    def _flush_list(self, key):
+        ops, entries = self._defer.pop(key)
+        if self._sizing or not entries:
+            return
+        rows, blk = [], 0
+        for (pp, op, nslabs, stride, count, N, taps, acc, _owner) in entries:
+            wide = int(nslabs > 16 and taps == 0)          # LayerNorm block partials: 16 columns x 16 slab groups per block
+            rows.append([pp, op, nslabs | (acc << 32) | (wide << 33), stride, count, N, taps, blk])
+            blk += -(-count // (16 if wide else 256))
+        tab = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self._tables.append(tab)   # read by the launch at every replay
+        self._op(ops, self.L.countr_reduce_table, tab.data_ptr(), len(rows), blk)
+
+    def _flush_reductions(self, plan=None):
+        for key in list(self._defer):
+            self._flush_list(key)
+
     # linear forward: out = act(x W^T + b) (+ resid)
     def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True):
         out_bf16 = (out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
@@ -338,14 +380,22 @@ class Engine:
         bk = 64 if self.code == BF16 else 32
         tiles = -(-N // 128) * -(-K // 128)
         sk = self._splitk(tiles, -(-M // bk))
-        part = self._shared("splitk", sk * N * K)
+        defer = self.defer_reduce
+        part = self._shared(("skp." + self._role(wname)) if defer else "splitk", sk * N * K)
         fuse_bias = bias_name is not None and self.code == BF16
-        rs = self._shared("rowsum", 64 * 4096) if fuse_bias else None
+        rs = self._shared(("rsp." + self._role(wname)) if defer else "rowsum", 64 * 4096) if fuse_bias else None
+        if defer:
+            self._claim(part.data_ptr())
         self._gemm(ops, self.code, OP_COL, OP_COL, A=dy.data_ptr() if not isinstance(dy, int) else dy,
                    B=x.data_ptr() if not isinstance(x, int) else x, partial=part.data_ptr(), lda=lddy, ldb=ldx, ldc=K,
                    M=N, N=K, K=M, splitk=sk, rowsum_partial=(rs.data_ptr() if fuse_bias else None))
-        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, self._acc,
-                 rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
+        if defer:
+            self._reduce_later(ops, part.data_ptr(), part.data_ptr(), self._gp(wname), sk, N * K, N * K)
+            if fuse_bias:
+                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), sk, N, N)
+        else:
+            self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, self._acc,
+                     rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
         if bias_name is not None and not fuse_bias:
             self._bias_grad(ops, dy, bias_name, M, N)
 
@@ -383,6 +433,16 @@ class Engine:
 
     def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate, dx_t=None):
         """dx_t (bf16 mode): also emit the updated residual gradient as the bf16 operand of the next backward GEMM."""
+        if self.defer_reduce:    # per-block {dgamma, dbeta} partials stay in this LayerNorm's own workspace until the list's table launch
+            nb = self.L.countr_layernorm_bwd_nblocks()
+            ws = self._shared("lnw." + self._role(name), nb * 2 * D)
+            self._claim(ws.data_ptr())
+            self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
+                     rstd.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), rows, D,
+                     int(dy.dtype == torch.bfloat16), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
+            self._reduce_later(ops, ws.data_ptr(), ws.data_ptr(), self._gp(name + ".weight"), nb, 2 * D, D)
+            self._reduce_later(ops, ws.data_ptr(), ws.data_ptr() + 4 * D, self._gp(name + ".bias"), nb, 2 * D, D)
+            return dx if self.code == F32 else dx_t
         ws = self._shared("lnbwd", 256 * 2 * 2048)
         self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
                  rstd.data_ptr(), dx.data_ptr(), self._gp(name + ".weight"), self._gp(name + ".bias"), ws.data_ptr(), rows, D,
@@ -458,14 +518,22 @@ class Engine:
         Kp = Bn * H * W
         tiles = -(-Cout // 128) * -(-(9 * Cin) // 128)
         sk = self._splitk(tiles, -(-Kp // bk))
-        part = self._shared("splitk", sk * Cout * 9 * Cin)
+        defer = self.defer_reduce
+        part = self._shared(("skp." + self._role(wname)) if defer else "splitk", sk * Cout * 9 * Cin)
         fuse_bias = bias_name is not None and self.code == BF16
-        rs = self._shared("rowsum", 64 * 4096) if fuse_bias else None
+        rs = self._shared(("rsp." + self._role(wname)) if defer else "rowsum", 64 * 4096) if fuse_bias else None
+        if defer:
+            self._claim(part.data_ptr())
         self._gemm(ops, self.code, OP_COL, OP_IM2COL, A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout,
                    ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W, Cin=Cin, splitk=sk,
                    rowsum_partial=(rs.data_ptr() if fuse_bias else None))
-        self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, self._acc,
-                 rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
+        if defer:
+            self._reduce_later(ops, part.data_ptr(), part.data_ptr(), self._gp(wname), sk, Cout * 9 * Cin, Cout * 9 * Cin, N=9 * Cin, taps=9)
+            if fuse_bias:
+                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), sk, Cout, Cout)
+        else:
+            self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, self._acc,
+                     rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
         if bias_name is not None and not fuse_bias:
             self._bias_grad(ops, dy, bias_name, Kp, Cout)
 
@@ -750,6 +818,7 @@ class Engine:
                         self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dc[i].data_ptr(), B=self.Wd[wn].data_ptr(), C=dpl[i - 1].data_ptr(),
                                    ldb=9 * chans[i], ldc=chans[i - 1], M=BS * sizes[i] * sizes[i], N=chans[i - 1], K=9 * chans[i],
                                    H=sizes[i], W=sizes[i], Cin=chans[i], out_bf16=int(code == BF16))
+            self._flush_reductions(p)
         self._acc = 0
         return p
 

@@ -218,6 +218,7 @@ class MaeEngine(Engine):
                 g_t = self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H, g_t)
             ops = lists.bwd_enc[2]
             self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
+            self._flush_reductions(p)
         self._acc = 0
         return p
 

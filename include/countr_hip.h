@@ -88,6 +88,15 @@ int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void
 int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, int N, int perm_taps,
                          int accumulate, const float* rowsum_partial, float* rowsum_out, void* stream);
 
+/* Many deferred slab reductions in ONE launch (the wgrad / bias-gradient / LayerNorm dgamma-dbeta finishers of a backward phase;
+ * replaces the per-parameter accumulation of autograd's AccumulateGrad nodes, util/misc.py:266-280 loss_scaler -> backward()).
+ * table: device int64 [n][8] rows {partial (const float*), out (float*), nslabs | accumulate << 32 | wide << 33, slab stride
+ * (floats), count, N, perm_taps, first block}: out[perm(i)] (+)= sum_z partial[z*stride + i], i < count; entry e owns the
+ * 256-thread blocks [first_block(e), first_block(e+1)), total_blocks in all: ceil(count / 256) blocks per entry, or
+ * ceil(count / 16) for a "wide" entry (many slabs: 16 columns x 16 slab groups per block, no permutation).
+ * perm as in countr_splitk_reduce (taps > 0). */
+int countr_reduce_table(const long long* table, int n, int total_blocks, void* stream);
+
 
 /* -------- LayerNorm (nn.LayerNorm eps=1e-6: models_mae_cross.py:146,182; models_crossvit.py:153-155;
  * timm Block.norm1/norm2).  x is the fp32 residual stream [rows, D]; y is fp32 or bf16.

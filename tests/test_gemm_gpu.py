@@ -341,3 +341,37 @@ def test_gemm_staged_and_direct_epilogues(hip, M, N, K):
                     err = (view[:, :N].double() - want).abs().max().item()
                     assert err <= tol * want.abs().max().item() + 1e-5, (opt, obf, ldc, off, err)
                     assert (view[:, N:] == 7.0).all() and (buf[:off] == 7.0).all() and (buf[off + M * ldc:] == 7.0).all(), (opt, obf, ldc, off)
+
+
+def test_reduce_table_matches_individual_reductions(hip):
+    """countr_reduce_table (one launch for many deferred slab sums) against countr_splitk_reduce / plain torch sums: split-K slabs
+    with and without the conv tap permutation, accumulate on and off, a strided many-slab ("wide") entry as the LayerNorm
+    dgamma / dbeta partials use, odd counts."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *shape: torch.rand(shape, generator=g).cuda() - 0.5
+    entries, keep, blk, checks = [], [], 0, []
+    for (sk, M, N, taps, acc) in ((3, 40, 72, 0, 0), (7, 8, 9 * 64, 9, 1), (1, 130, 4, 0, 1), (5, 1, 1000, 0, 0)):
+        part = rnd(sk, M, N)
+        out0 = rnd(M, N)
+        out = out0.clone()
+        ref = out0.clone()
+        _lib.check(hip.countr_splitk_reduce(part.data_ptr(), ref.data_ptr(), sk, M, N, taps, acc, None, None, _stream()), "reduce")
+        entries.append([part.data_ptr(), out.data_ptr(), sk | (acc << 32), M * N, M * N, N, taps, blk])
+        blk += -(-(M * N) // 256)
+        keep += [part, out]
+        checks.append((out, ref))
+    for (nb, D, acc) in ((256, 72, 0), (100, 513, 1)):          # workspace rows {dgamma[D], dbeta[D]}: two strided wide entries
+        ws = rnd(nb, 2 * D)
+        for half in (0, 1):
+            out0 = rnd(D)
+            out = out0.clone()
+            ref = ws[:, half * D:(half + 1) * D].double().sum(0).float() + (out0 if acc else 0)
+            entries.append([ws.data_ptr() + 4 * half * D, out.data_ptr(), nb | (acc << 32) | (1 << 33), 2 * D, D, 0, 0, blk])
+            blk += -(-D // 16)
+            keep += [ws, out]
+            checks.append((out, ref))
+    tab = torch.tensor(entries, dtype=torch.int64, device="cuda")
+    _lib.check(hip.countr_reduce_table(tab.data_ptr(), len(entries), blk, _stream()), "reduce_table")
+    torch.cuda.synchronize()
+    for i, (out, ref) in enumerate(checks):
+        assert (out - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0), i
