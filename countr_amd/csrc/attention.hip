@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
 
 // Backward: recomputes P; dq per row; dk/dv are reduced over the rows of a block in LDS and written as
 // per-block partials  partial[blockIdx.x][2][S][D]  (blocks never straddle a batch element).
-template <typename T>
+// KS = compile-time bound on the number of keys (1, 2, 3 or XS): the per-lane key / value / dk / dv register arrays scale with
+// it (4 x KS x 8 floats), and shot_num <= 3 in the reference (FSC_finetune_cross.py:278-284), so XS-sized arrays were 2.7x the
+// registers and arithmetic the common case needs.
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                         const T* __restrict__ dout, T* __restrict__ dq, float* __restrict__ partial,
                                                         int N, int S, int D, int ldkv, float scale, int rows_per_block) {
@@ -132,9 +135,9 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q,
   const int r0 = (blockIdx.x - b * blocks_per_b) * rows_per_block;
   const int r1 = min(N, r0 + rows_per_block);
   const int c0 = lane * 8;  // D == 512
-  float kv[XS][8], vv[XS][8], dk[XS][8], dvv[XS][8];
+  float kv[KS][8], vv[KS][8], dk[KS][8], dvv[KS][8];
 #pragma unroll
-  for (int j = 0; j < XS; ++j) {
+  for (int j = 0; j < KS; ++j) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dk[j][e] = 0.f; dvv[j][e] = 0.f; kv[j][e] = 0.f; vv[j][e] = 0.f; }
     if (j < S) {
@@ -147,10 +150,10 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q,
     float qv[8], dov[8];
     ld8<T>(q + row * D + c0, qv);
     ld8<T>(dout + row * D + c0, dov);
-    float sc[XS], dp[XS];
+    float sc[KS], dp[KS];
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < XS; ++j) {
+    for (int j = 0; j < KS; ++j) {
       float d = 0.f, g = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { d += qv[e] * kv[j][e]; g += dov[e] * vv[j][e]; }
@@ -162,16 +165,16 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q,
     }
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < XS; ++j) { sc[j] = (j < S) ? __expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+    for (int j = 0; j < KS; ++j) { sc[j] = (j < S) ? __expf(sc[j] - mx) : 0.f; sum += sc[j]; }
     const float inv = 1.f / sum;
     float dot = 0.f;
 #pragma unroll
-    for (int j = 0; j < XS; ++j) { sc[j] *= inv; dot += sc[j] * dp[j]; }
+    for (int j = 0; j < KS; ++j) { sc[j] *= inv; dot += sc[j] * dp[j]; }
     float dqv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) dqv[e] = 0.f;
 #pragma unroll
-    for (int j = 0; j < XS; ++j) {
+    for (int j = 0; j < KS; ++j) {
       const float ds = sc[j] * (dp[j] - dot) * scale;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -240,7 +243,7 @@ extern "C" int countr_xattn_fwd(const void* q, const void* k, const void* v, voi
   COUNTR_LAUNCH_CHECK("countr_xattn_fwd");
 }
 
-static const int XATTN_ROWS_PER_BLOCK = 32;
+static const int XATTN_ROWS_PER_BLOCK = 16;   // 8 x 36 = 288 blocks at B = 8: backward 11.8 us (32 rows per block: 14.8 us)
 extern "C" int64_t countr_xattn_bwd_workspace_floats(int B, int N, int S, int D) {
   const int bpb = (N + XATTN_ROWS_PER_BLOCK - 1) / XATTN_ROWS_PER_BLOCK;
   return (int64_t)B * bpb * 2 * S * D;
@@ -253,13 +256,21 @@ extern "C" int countr_xattn_bwd(const void* q, const void* k, const void* v, con
   if (!q || !k || !v || !dout || !dq || !dk || !dv || !workspace || S < 1 || S > XS || D != 512 || heads * 32 != D) { countr_set_error("countr_xattn_bwd: bad args"); return -1; }
   const int bpb = (N + XATTN_ROWS_PER_BLOCK - 1) / XATTN_ROWS_PER_BLOCK;
   const size_t lds = (size_t)4 * 2 * S * D * sizeof(float);
-  if (dtype == COUNTR_BF16) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * XS * 512 * 4);
-    hipLaunchKernelGGL(xattn_bwd_kernel<bf16_t>, dim3(B * bpb), dim3(256), lds, STREAM(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dq, workspace, N, S, D, ldkv, scale, XATTN_ROWS_PER_BLOCK);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * XS * 512 * 4);
-    hipLaunchKernelGGL(xattn_bwd_kernel<float>, dim3(B * bpb), dim3(256), lds, STREAM(stream), (const float*)q, (const float*)k, (const float*)v, (const float*)dout, (float*)dq, workspace, N, S, D, ldkv, scale, XATTN_ROWS_PER_BLOCK);
-  }
+#define COUNTR_XB_LAUNCH(TT, KSV)                                                                                             \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_bwd_kernel<TT, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              4 * 2 * XS * 512 * 4);                                                                           \
+    hipLaunchKernelGGL((xattn_bwd_kernel<TT, KSV>), dim3(B * bpb), dim3(256), lds, STREAM(stream), (const TT*)q, (const TT*)k,   \
+                       (const TT*)v, (const TT*)dout, (TT*)dq, workspace, N, S, D, ldkv, scale, XATTN_ROWS_PER_BLOCK);         \
+  } while (0)
+#define COUNTR_XB_DISPATCH(TT)                                                                                                 \
+  do {                                                                                                                         \
+    if (S == 1) COUNTR_XB_LAUNCH(TT, 1); else if (S == 2) COUNTR_XB_LAUNCH(TT, 2); else if (S == 3) COUNTR_XB_LAUNCH(TT, 3);  \
+    else COUNTR_XB_LAUNCH(TT, XS);                                                                                             \
+  } while (0)
+  if (dtype == COUNTR_BF16) COUNTR_XB_DISPATCH(bf16_t); else COUNTR_XB_DISPATCH(float);
+#undef COUNTR_XB_DISPATCH
+#undef COUNTR_XB_LAUNCH
   hipLaunchKernelGGL(xattn_bwd_finish_kernel, dim3((2 * S * D + 255) / 256, B), dim3(256), 0, STREAM(stream), workspace, dk, dv, bpb, S, D);
   COUNTR_LAUNCH_CHECK("countr_xattn_bwd");
 }
