@@ -207,8 +207,14 @@ __global__ void xattn_bwd_finish_kernel(const float* __restrict__ partial, float
   const int tot = 2 * S * D;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= tot) return;
-  float s = 0.f;
-  for (int p = 0; p < blocks_per_b; ++p) s += partial[((int64_t)b * blocks_per_b + p) * tot + i];
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: the walk over the block partials is load-latency bound
+  int p = 0;
+  for (; p + 4 <= blocks_per_b; p += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += partial[((int64_t)b * blocks_per_b + p + u) * tot + i];
+  }
+  for (; p < blocks_per_b; ++p) s4[0] += partial[((int64_t)b * blocks_per_b + p) * tot + i];
+  const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   const int which = i / (S * D), r = i - which * S * D;
   (which == 0 ? dk : dv)[(int64_t)b * S * D + r] = s;
 }

@@ -395,12 +395,22 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
                                                               float* __restrict__ gm /* [B][G][2] */, int HW, int G, int ns) {
   const int b = blockIdx.x, c = threadIdx.x;  // 256 channels
-  float a = 0.f, q = 0.f;
-  for (int s = 0; s < ns; ++s) {
-    const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
-    a += o[c];
-    q += o[GN_C + c];
+  float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: the loop is load-latency bound
+  int s = 0;
+  for (; s + 4 <= ns; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* o = partial + ((int64_t)b * ns + s + u) * 3 * GN_C;
+      a4[u] += o[c];
+      q4[u] += o[GN_C + c];
+    }
   }
+  for (; s < ns; ++s) {
+    const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
+    a4[0] += o[c];
+    q4[0] += o[GN_C + c];
+  }
+  float a = (a4[0] + a4[1]) + (a4[2] + a4[3]), q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
   const float ga = gamma[c];
   a *= ga; q *= ga;
   const int cpg = GN_C / G;  // 32 channels per group: reduce inside each 32-lane half wave
