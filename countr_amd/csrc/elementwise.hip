@@ -7,6 +7,7 @@
 //   masked mse loss : FSC_finetune_cross.py:290-303
 //   adamw           : torch.optim.AdamW(betas=(0.9,0.95))           (FSC_finetune_cross.py:235)
 #include "common.cuh"
+#include <stdlib.h>
 #include "../../include/countr_hip.h"
 
 extern "C" int countr_colsum_partials(const float* partial, float* out, int nparts, int C, int accumulate, void* stream);
@@ -408,7 +409,9 @@ extern "C" int countr_im2patch(const float* img, void* out, int B, int H, int W,
 extern "C" int countr_conv3x3_c3_fwd(const float* in, const float* w, const float* bias, void* out, int S, int H, int W,
                                      int dtype, void* stream) {
   if (!in || !w || !bias || !out) { countr_set_error("countr_conv3x3_c3_fwd: null"); return -1; }
-  const int nb = nblocks((int64_t)S * H * W, 32, 2048);
+  // every block first stages the 64x27 weights into LDS: few, long-lived blocks (COUNTR_C3_BLOCKS overrides the cap for tuning)
+  static const int cap = [] { const char* e = getenv("COUNTR_C3_BLOCKS"); return e ? atoi(e) : 256; }();   // measured at 24 boxes: 2048 blocks 31.2 us, 512 23.6, 256 22.2, 128 38.2
+  const int nb = nblocks((int64_t)S * H * W, 32, cap);
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (bf16_t*)out, S, H, W);
   else hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (float*)out, S, H, W);
   COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_fwd");
