@@ -1,3 +1,5 @@
+"""Times countr_conv3x3_c3_fwd (first exemplar conv, 3 -> 64 channels, 24 boxes of 64x64) from a captured graph of 20 launches,
+so the Python launch rate does not bound the measurement; COUNTR_C3_BLOCKS sweeps the grid cap."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from countr_amd import _lib
