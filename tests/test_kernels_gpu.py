@@ -226,10 +226,11 @@ def test_im2patch_and_c3conv(hip, tdt, code, tol):
     assert relerr(dw, wr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("H,W", [(24, 20), (5, 7), (2, 2), (4, 2), (1, 6)])   # even sizes: 2x2-block kernels; odd: per-pixel kernels
 @pytest.mark.parametrize("Cc", [256, 1])
 @pytest.mark.parametrize("tdt,code,tol", DT)
-def test_upsample2x_fwd_bwd(hip, Cc, tdt, code, tol):
-    B, H, W = 2, 24, 20
+def test_upsample2x_fwd_bwd(hip, Cc, tdt, code, tol, H, W):
+    B = 2
     x = rnd((B, H, W, Cc), 24).to(tdt)
     xd = x.cuda()
     y = torch.empty((B, 2 * H, 2 * W, Cc), device="cuda", dtype=tdt)
