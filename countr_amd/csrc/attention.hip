@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) d += qv[e] * kv[e];
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
+        d = quad_sum(d);
         sc[j] = d * scale;
         mx = fmaxf(mx, sc[j]);
       }
@@ -157,8 +156,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q,
       float d = 0.f, g = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { d += qv[e] * kv[j][e]; g += dov[e] * vv[j][e]; }
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
-      g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+      d = quad_sum(d);
+      g = quad_sum(g);
       sc[j] = (j < S) ? d * scale : -INFINITY;
       dp[j] = g;
       mx = fmaxf(mx, sc[j]);

@@ -71,16 +71,48 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (
 }
 
 // Wave-level (64 lanes) butterfly reductions: every lane ends with the result.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Cross-lane reductions on the VALU: DPP (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror) inside the 16-lane rows, then
+// gfx950 v_permlane16_swap / v_permlane32_swap between rows.  hipcc lowers __shfl_xor to ds_bpermute: an LDS round trip and an
+// lgkmcnt wait per step (6 dependent ones for a wave sum).  All 64 lanes must be active (callers keep these wave-uniform).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);   // row_half_mirror
+  x += dpp_mov<0x140>(x);   // row_mirror
+  return x;
 }
+__device__ __forceinline__ float row16_max(float x) {
+  x = fmaxf(x, dpp_mov<0xB1>(x));
+  x = fmaxf(x, dpp_mov<0x4E>(x));
+  x = fmaxf(x, dpp_mov<0x141>(x));
+  x = fmaxf(x, dpp_mov<0x140>(x));
+  return x;
+}
+#define COUNTR_SWAP_OP(NAME, SWAP, OP)                                                                                      \
+  __device__ __forceinline__ float NAME(float x) {                                                                          \
+    float t;                                                                                                                \
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\t" SWAP " %0, %1\n\ts_nop 1\n\t" OP " %0, %0, %1" : "+v"(x), "=&v"(t));    \
+    return x;                                                                                                               \
+  }
+COUNTR_SWAP_OP(xor16_sum, "v_permlane16_swap_b32", "v_add_f32")
+COUNTR_SWAP_OP(xor32_sum, "v_permlane32_swap_b32", "v_add_f32")
+COUNTR_SWAP_OP(xor16_max, "v_permlane16_swap_b32", "v_max_f32")
+COUNTR_SWAP_OP(xor32_max, "v_permlane32_swap_b32", "v_max_f32")
+#undef COUNTR_SWAP_OP
+__device__ __forceinline__ float quad_sum(float x) { x += dpp_mov<0xB1>(x); x += dpp_mov<0x4E>(x); return x; }   // lanes 4k .. 4k+3
+// sum over the lanes that share (lane % NCV), NCV = 8, 16 or 32 (row_ror:8 pairs lane i with i ^ 8 inside its row)
+template <int NCV> __device__ __forceinline__ float stride_sum(float x) {
+  static_assert(NCV == 8 || NCV == 16 || NCV == 32, "stride_sum");
+  if (NCV <= 8) x += dpp_mov<0x128>(x);
+  if (NCV <= 16) x = xor16_sum(x);
+  return xor32_sum(x);
+}
+__device__ __forceinline__ float half_wave_sum(float v) { return xor16_sum(row16_sum(v)); }   // over lanes 0-31 / 32-63
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // Block-level sum for blocks of NW waves; `sm` must hold >= NW floats.  All threads get the result.
 template <int NW> __device__ __forceinline__ float block_sum(float v, float* sm) {

@@ -175,7 +175,7 @@ constexpr int GN_C = 256;
 
 // reduce `v` over the lanes/waves that share (threadIdx.x & 31): result valid in every thread.
 __device__ __forceinline__ float reduce_same_chanvec(float v, float* sm /* [8][32] */) {
-  v += __shfl_xor(v, 32, 64);
+  v = xor32_sum(v);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
   if (lane < 32) sm[wave * 32 + lane] = v;
@@ -190,7 +190,7 @@ __device__ __forceinline__ float reduce_same_chanvec(float v, float* sm /* [8][3
 template <int NV>
 __device__ __forceinline__ void reduce_vec_same_chanvec(float (&v)[NV], float* sm /* [4][32][NV] */) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+  for (int i = 0; i < NV; ++i) v[i] = xor32_sum(v[i]);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
   if (lane < 32) {
@@ -318,8 +318,7 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
         if (y) st8<T>(y + ((int64_t)b * HW + p) * GN_C + cv * 8, v[u]);
       }
       if (w1) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        dot = half_wave_sum(dot);
         if (ok && cv == 0) out1[(int64_t)b * HW + p] = dot + bias1;
       }
     }
@@ -414,7 +413,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
   const float ga = gamma[c];
   a *= ga; q *= ga;
   const int cpg = GN_C / G;  // 32 channels per group: reduce inside each 32-lane half wave
-  for (int off = cpg >> 1; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
+  if (cpg == 32) { a = half_wave_sum(a); q = half_wave_sum(q); }   // G = 8
+  else for (int off = cpg >> 1; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
   if ((c % cpg) == 0) {
     const float n = (float)HW * cpg;
     gm[((int64_t)b * G + c / cpg) * 2] = a / n;
@@ -479,10 +479,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restr
 template <int NCV>
 __device__ __forceinline__ void reduce8_same_cv(float (&v)[8], float* sm /* [4][NCV][8] */) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-#pragma unroll
-    for (int o = NCV; o < 64; o <<= 1) v[i] += __shfl_xor(v[i], o, 64);
-  }
+  for (int i = 0; i < 8; ++i) v[i] = stride_sum<NCV>(v[i]);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
   if (lane < NCV) {
