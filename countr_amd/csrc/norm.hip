@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm(G groups) on NHWC [B, HW, C], C = 256, 8 channels per thread (32 threads per pixel,
-// 8 pixels per pass).  Statistics are accumulated per (image, pixel-split) block and combined with
-// Chan's parallel formula by every consumer block (tiny), which keeps the result deterministic.
+// 8 pixels per pass).  Statistics are accumulated per (image, pixel-split) block as {mean, M2} and combined once by
+// gn_stats_finalize_kernel (exact two-pass combination, fixed order: deterministic).
 // ------------------------------------------------------------------------------------------
 constexpr int GN_C = 256;
 
@@ -248,28 +248,37 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// combine split statistics of image b into sm_mean[G], sm_rstd[G] (called by all threads of a block)
-__device__ __forceinline__ void gn_combine(const float* __restrict__ part, int b, int ns, int HW, int G, float eps,
-                                           float* sm_mean, float* sm_rstd) {
-  if (threadIdx.x < G) {
-    const int per = (HW + ns - 1) / ns;
-    const float cpg = (float)(GN_C / G);
-    float ntot = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < ns; ++s) {
-      const int p0 = s * per, p1 = min(HW, p0 + per);
-      const float n = (float)max(p1 - p0, 0) * cpg;
-      if (n <= 0.f) continue;
-      const float* o = part + (((int64_t)b * ns + s) * G + threadIdx.x) * 2;
-      const float d = o[0] - mean;
-      const float nn = ntot + n;
-      mean += d * (n / nn);
-      m2 += o[1] + d * d * (ntot * n / nn);
-      ntot = nn;
+// Per-(image, group) mean / rstd from the split partials {mean_s, M2_s}: one wave per group, lanes over the splits, the exact
+// two-pass combination  mean = sum n_s mean_s / N,  M2 = sum (M2_s + n_s (mean_s - mean)^2)  (all loads in flight at once).
+__global__ void gn_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats /* [B][G][2] */, int HW, int G,
+                                         int ns, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (HW + ns - 1) / ns;
+  const float cpg = (float)(GN_C / G);
+  float nsum = 0.f, msum = 0.f;
+  for (int s = lane; s < ns; s += 64) {
+    const float n = (float)max(min(HW, (s + 1) * per) - s * per, 0) * cpg;
+    if (n > 0.f) {   // an empty split's partial is never written
+      nsum += n;
+      msum += n * part[(((int64_t)b * ns + s) * G + g) * 2];
     }
-    sm_mean[threadIdx.x] = mean;
-    sm_rstd[threadIdx.x] = rsqrtf(m2 / ntot + eps);
   }
-  __syncthreads();
+  const float ntot = wave_sum(nsum);
+  const float mean = wave_sum(msum) / ntot;
+  float m2 = 0.f;
+  for (int s = lane; s < ns; s += 64) {
+    const float n = (float)max(min(HW, (s + 1) * per) - s * per, 0) * cpg;
+    if (n > 0.f) {
+      const float* o = part + (((int64_t)b * ns + s) * G + g) * 2;
+      const float d = o[0] - mean;
+      m2 += o[1] + n * d * d;
+    }
+  }
+  m2 = wave_sum(m2);
+  if (lane == 0) {
+    stats[((int64_t)b * G + g) * 2] = mean;
+    stats[((int64_t)b * G + g) * 2 + 1] = rsqrtf(m2 / ntot + eps);
+  }
 }
 
 // y = relu(gn(x)); with w1 != nullptr instead writes out1[b, p] = sum_c y[p, c] * w1[c] + b1 (the fused
@@ -281,16 +290,12 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ b1, float* __restrict__ out1,
                                                           float* __restrict__ stats_out /* [B][G][2] */, int HW, int G,
                                                           int ns, float eps) {
-  __shared__ float sm_mean[32], sm_rstd[32];
+  // statistics come finished from gn_stats_finalize_kernel: walking the ns split partials (Chan combine) in EVERY block of this
+  // kernel was a chain of ns dependent L2 round trips, 16 us at ns = 64 -- half the kernel's time on the 192 x 192 map
   const int b = blockIdx.y;
-  gn_combine(part, b, ns, HW, G, eps, sm_mean, sm_rstd);
-  if (blockIdx.x == 0 && threadIdx.x < G && stats_out) {
-    stats_out[((int64_t)b * G + threadIdx.x) * 2] = sm_mean[threadIdx.x];
-    stats_out[((int64_t)b * G + threadIdx.x) * 2 + 1] = sm_rstd[threadIdx.x];
-  }
   const int cv = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int g = (cv * 8) / (GN_C / G);
-  const float mu = sm_mean[g], rs = sm_rstd[g];
+  const float mu = stats_out[((int64_t)b * G + g) * 2], rs = stats_out[((int64_t)b * G + g) * 2 + 1];
   float ga[8], be[8], w[8];
   ld8<float>(gamma + cv * 8, ga);
   ld8<float>(beta + cv * 8, be);
@@ -899,14 +904,16 @@ extern "C" int countr_groupnorm_nsplit(int HW) { return gn_splits(HW); }
 extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
                                          const float* b1, float* out1, float* stats, float* workspace, int B, int HW, int C,
                                          int G, float eps, int dtype, void* stream) {
-  if (!x || !gamma || !beta || !stats || !workspace || C != GN_C || G > 32 || (GN_C / G) % 8 || (!y && !w1)) { countr_set_error("countr_groupnorm_relu_fwd: bad args (C must be 256)"); return -1; }
+  if (!x || !gamma || !beta || !stats || !workspace || C != GN_C || G > 16 || (GN_C / G) % 8 || (!y && !w1)) { countr_set_error("countr_groupnorm_relu_fwd: bad args (C must be 256, G <= 16)"); return -1; }
   const int ns = gn_splits(HW);
   const int nblk = min((HW + 7) / 8, 512);
   if (dtype == COUNTR_BF16) {
     hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, HW, G);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(B), dim3(64 * G), 0, STREAM(stream), workspace, stats, HW, G, ns, eps);
     hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, gamma, beta, (bf16_t*)y, w1, b1, out1, stats, HW, G, ns, eps);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, HW, G);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(B), dim3(64 * G), 0, STREAM(stream), workspace, stats, HW, G, ns, eps);
     hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, gamma, beta, (float*)y, w1, b1, out1, stats, HW, G, ns, eps);
   }
   COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_fwd");
