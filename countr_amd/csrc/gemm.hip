@@ -1067,10 +1067,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 }
 
 // Batched deferred reductions (one launch for many (partial slabs -> gradient) sums): table row e = {partial, out,
-// nslabs | accumulate << 32 | wide << 33, slab stride, count, N, taps, first block}; block b serves the entry with blk0[e] <= b < blk0[e+1].
+// nslabs | accumulate << 32 | wide << 33, slab stride, count, N, taps, first block}, followed by the int32 map block -> entry.
 __global__ void reduce_table_kernel(const long long* __restrict__ tab, int n) {
-  int e = 0;
-  while (e + 1 < n && tab[(e + 1) * 8 + 7] <= (long long)blockIdx.x) ++e;   // uniform scan, n is a few dozen
+  // block -> entry map (int32 [total_blocks]) behind the n rows: one load instead of a scan over the first-block column, which
+  // was a chain of up to n dependent scalar loads in every block (~10 us of the launch at n = 40)
+  const int e = reinterpret_cast<const int*>(tab + (long long)n * 8)[blockIdx.x];
   const long long* t = tab + (long long)e * 8;
   const float* __restrict__ partial = reinterpret_cast<const float*>(t[0]);
   float* __restrict__ out = reinterpret_cast<float*>(t[1]);

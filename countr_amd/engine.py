@@ -346,7 +346,12 @@ class Engine:
             wide = int(nslabs > 16 and taps == 0)          # LayerNorm block partials: 16 columns x 16 slab groups per block
             rows.append([pp, op, nslabs | (acc << 32) | (wide << 33), stride, count, N, taps, blk])
             blk += -(-count // (16 if wide else 256))
-        tab = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        tab = torch.tensor(rows, dtype=torch.int64).reshape(-1)
+        owner = torch.repeat_interleave(torch.arange(len(rows), dtype=torch.int32),
+                                        torch.tensor([(rows[i + 1][7] if i + 1 < len(rows) else blk) - rows[i][7] for i in range(len(rows))]))
+        if owner.numel() & 1:
+            owner = torch.cat([owner, owner.new_zeros(1)])
+        tab = torch.cat([tab, owner.view(torch.int64)]).to(self.device)   # rows, then the int32 block -> entry map
         self._tables.append(tab)   # read by the launch at every replay
         self._op(ops, self.L.countr_reduce_table, tab.data_ptr(), len(rows), blk)
 

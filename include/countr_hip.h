@@ -93,7 +93,8 @@ int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, in
  * table: device int64 [n][8] rows {partial (const float*), out (float*), nslabs | accumulate << 32 | wide << 33, slab stride
  * (floats), count, N, perm_taps, first block}: out[perm(i)] (+)= sum_z partial[z*stride + i], i < count; entry e owns the
  * 256-thread blocks [first_block(e), first_block(e+1)), total_blocks in all: ceil(count / 256) blocks per entry, or
- * ceil(count / 16) for a "wide" entry (many slabs: 16 columns x 16 slab groups per block, no permutation).
+ * ceil(count / 16) for a "wide" entry (many slabs: 16 columns x 16 slab groups per block, no permutation).  The rows are
+ * followed (at table + 8 n) by an int32 array [total_blocks] giving the entry of every block.
  * perm as in countr_splitk_reduce (taps > 0). */
 int countr_reduce_table(const long long* table, int n, int total_blocks, void* stream);
 

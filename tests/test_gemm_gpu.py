@@ -370,7 +370,11 @@ def test_reduce_table_matches_individual_reductions(hip):
             blk += -(-D // 16)
             keep += [ws, out]
             checks.append((out, ref))
-    tab = torch.tensor(entries, dtype=torch.int64, device="cuda")
+    firsts = [e[7] for e in entries] + [blk]
+    owner = torch.cat([torch.full((firsts[i + 1] - firsts[i],), i, dtype=torch.int32) for i in range(len(entries))])
+    if owner.numel() & 1:
+        owner = torch.cat([owner, owner.new_zeros(1)])
+    tab = torch.cat([torch.tensor(entries, dtype=torch.int64).reshape(-1), owner.view(torch.int64)]).cuda()
     _lib.check(hip.countr_reduce_table(tab.data_ptr(), len(entries), blk, _stream()), "reduce_table")
     torch.cuda.synchronize()
     for i, (out, ref) in enumerate(checks):
