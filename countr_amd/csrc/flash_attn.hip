@@ -576,23 +576,32 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
     __syncthreads();
   }
 
-  // ---- epilogue: lane (li, g) owns resident row r0 + rt*16 + li and channels dt*16 + 4g .. +3
+  // ---- epilogue: lane (li, g) owns resident row r0 + rt*16 + li and channels dt*16 + 4g .. +3; as in the forward the wave's
+  // [32][DH] block goes through its slice of the (now idle) tile ring and out as whole rows in 16-byte chunks
+  char* ost = smem + wave * 32 * PITCH;
+  auto emit = [&](const f32x4_t (&a)[DT][2], float sc, int64_t coloff) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int r = r0 + rt * 16 + li;
-    if (r >= N) continue;
-    bf16_t* drow = dqkv + ((int64_t)b * N + r) * rs + h * DH;  // q slot
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      const float v0[4] = {acc[0][dt][rt][0] * scale, acc[0][dt][rt][1] * scale, acc[0][dt][rt][2] * scale, acc[0][dt][rt][3] * scale};
-      if (MODE == 0) {
-        st4<bf16_t>(drow + dt * 16 + g * 4, v0);
-      } else {
-        st4<bf16_t>(drow + H * DH + dt * 16 + g * 4, v0);  // dK
-        const float v1[4] = {acc[NACC - 1][dt][rt][0], acc[NACC - 1][dt][rt][1], acc[NACC - 1][dt][rt][2], acc[NACC - 1][dt][rt][3]};
-        st4<bf16_t>(drow + 2 * H * DH + dt * 16 + g * 4, v1);  // dV
-      }
+      for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<uint2*>(ost + (rt * 16 + li) * PITCH + (dt * 16 + g * 4) * 2) =
+            make_uint2(pack2bf(a[dt][rt][0] * sc, a[dt][rt][1] * sc), pack2bf(a[dt][rt][2] * sc, a[dt][rt][3] * sc));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < (32 * CPR) / 64; ++j) {
+      const int idx = lane + 64 * j, r = idx / CPR, cc = idx % CPR;
+      const uint4 v = *reinterpret_cast<const uint4*>(ost + r * PITCH + cc * 16);
+      if (r0 + r < N) *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + r0 + r) * rs + h * DH + coloff + cc * 8) = v;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (MODE == 0) {
+    emit(acc[0], scale, 0);                      // dQ
+  } else {
+    emit(acc[0], scale, (int64_t)H * DH);        // dK
+    emit(acc[NACC - 1], 1.f, (int64_t)2 * H * DH);   // dV
   }
 }
 
