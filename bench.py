@@ -66,7 +66,7 @@ def attention_roofline(model, batch, iters=20):
     try:  # HBM/fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md)
         t = json.load(open(os.path.join(ROOT, "profiles", "r1_attention_traffic.json")))
         if batch == 8:
-            traffic = t["after_xcd_mapping"]["bytes_per_launch"]
+            traffic = t.get("end_of_round", t["after_xcd_mapping"])["bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass
     return {"bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
