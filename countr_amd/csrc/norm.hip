@@ -81,8 +81,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
     const float mu = mean[row], rs = rstd[row];
     const TI* dyr = dy + (int64_t)row * D;
     const float* xr = x + (int64_t)row * D;
-    float xh[MAXV][4], gy[MAXV][4];
+    float xh[MAXV][4], gy[MAXV][4], od[MAXV][4];
     float s1 = 0.f, s2 = 0.f;
+    float* dxr = dx + (int64_t)row * D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = i * 256 + lane * 4;
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
         ld4<TI>(dyr + c, d);
         ld4<float>(xr + c, xv);
         ld4<float>(gamma + c, g);
+        // the residual gradient to accumulate into is requested with the row's other loads, not after the two wave reductions
+        if (accumulate) ld4<float>(dxr + c, od[i]); else { od[i][0] = od[i][1] = od[i][2] = od[i][3] = 0.f; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][e] = (xv[e] - mu) * rs;
@@ -104,15 +107,13 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
     }
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
-    float* dxr = dx + (int64_t)row * D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = i * 256 + lane * 4;
       if (c < D) {
         float o[4];
-        if (accumulate) ld4<float>(dxr + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += rs * (gy[i][e] - s1 - xh[i][e] * s2);
+        for (int e = 0; e < 4; ++e) o[e] = od[i][e] + rs * (gy[i][e] - s1 - xh[i][e] * s2);
         st4<float>(dxr + c, o);
         if (dx_bf16) st4<bf16_t>(dx_bf16 + (int64_t)row * D + c, o);   // GEMM-operand copy of the updated residual gradient
       }
