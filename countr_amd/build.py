@@ -25,6 +25,10 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+# per-file flags on top of the common ones (reasons in the file headers)
+EXTRA_FLAGS = {"flash_attn_fwd.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -35,7 +39,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-c", src, "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -305,10 +305,16 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __res
 
 // qkv: bf16 [B, N, 3, H, dh] packed (row stride 3*H*dh); out: bf16 [B, N, H*dh]; lse: optional fp32 [B, H, N]
 // (natural-log sum-exp of the scaled scores, kept for a fused backward).  dh must be 32 or 64.
+int countr_attn_fwd_pipelined(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, hipStream_t s);   // flash_attn_fwd.hip
+
 extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream) {
   if (!qkv || !out || B <= 0 || N <= 0 || H <= 0) { countr_set_error("countr_attn_fwd: bad args"); return -1; }
+  if (dh != 32 && dh != 64) { countr_set_error("countr_attn_fwd: head_dim must be 32 or 64"); return -1; }
   const float c = scale * 1.4426950408889634f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // COUNTR_ATTN_IMPL=1 selects the first-generation (non-pipelined) kernel below: kept for A/B timing (tools/bench_attn.py)
+  static const int impl = [] { const char* e = getenv("COUNTR_ATTN_IMPL"); return e ? atoi(e) : 2; }();
+  if (impl != 1) return countr_attn_fwd_pipelined(qkv, out, lse, B, N, H, dh, scale, s);
   // keys per staged K/V tile: 128 halves the barriers / exposed waits per key (COUNTR_ATTN_BKV overrides)
   static const int force_bkv = [] { const char* e = getenv("COUNTR_ATTN_BKV"); return e ? atoi(e) : 0; }();
   const int bkv = force_bkv ? force_bkv : 64;

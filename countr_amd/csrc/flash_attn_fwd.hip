@@ -1,0 +1,530 @@
+// Fused self-attention forward for gfx950, software-pipelined (bf16 in/out, fp32 softmax + accumulation).
+// Reference: Attention.forward, models_crossvit.py:82-94 (== timm Attention): softmax(q k^T * dh^-0.5) v on a packed
+// qkv [B, N, 3, H, dh]; output [B, N, H*dh].  N = 576 (288 kept tokens in MAE pretraining), dh = 64 (encoder) or 32 (decoder).
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); a wave owns 32 rows; two workgroups per CU, i.e. two waves per
+// SIMD.  What differs from the first-generation kernel (flash_attn.hip, kept for the backward) is the instruction stream of a
+// wave.  There a K/V tile was processed as QK^T (MFMA only) -> softmax (200 VALU, no MFMA) -> PV (MFMA only).  Here:
+//   * S^T = K Q^T and O^T += V^T P^T use v_mfma_f32_32x32x16_bf16: a lane owns ONE query row (l & 31) and 16 of the 32 keys of a
+//     block, so the row max needs one v_permlane32_swap per tile and m / l are scalars per lane.
+//   * the loop is skewed by one tile: step t issues the 2*KS MFMAs of S(t+1) = K(t+1) Q^T and the PV MFMAs of tile t, and between
+//     consecutive MFMAs the exp2 / row-sum / bf16-pack work of S(t) (then the row max of S(t+1)) in fixed slots
+//     (__builtin_amdgcn_sched_barrier pins the interleave; fragment reads are issued two slots ahead of their MFMA).
+//   * P never leaves the lane: PV consumes the keys in the order the S^T accumulator holds them (k-slot j of half h <-> key
+//     16 s + 4 h + (j & 3) + 8 (j >> 2)), V^T fragments are read in that order with ds_read_b64_tr_b16.
+//   * waves whose 32 query rows lie beyond N (N = 576 = 4.5 x 128) only help staging and skip all MFMA / VALU work.
+//   * deferred rescale (reference max kept while the running max grows by <= 8 in log2 units), decided after ALL PV MFMAs of the
+//     pending tile were issued and before the next tile is exponentiated.
+// K runs one tile ahead of V ("stage j" = {K(j+1), V(j)}).  Two staging paths:
+//   * dh = 64 (DMA): stages stream by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs, no ds_write) into a 4-slot ring of
+//     unpadded 128-byte rows, two stages ahead of their use; the bank-conflict swizzle sits on the per-lane SOURCE address and again
+//     on the fragment reads (K: chunk ^= (row >> 1) & 7 -> ds_read_b128 of 32 distinct rows conflict-free; V: chunk ^= 4 for rows
+//     with bit 1 set -> the four consecutive rows of a transposing read cover the 64 banks once).  Fragment reads are inline asm
+//     with hand-counted lgkmcnt (a compiler-visible ds_read gets s_waitcnt vmcnt(0) in front of it while a DMA is in flight); a
+//     stage is published by a counted s_waitcnt vmcnt + one raw s_barrier per step.
+//   * dh = 32: register-staged double buffer (global_load at the top of a step, ds_write at its end, one barrier per step), K
+//     rows pitched dh*2+16 bytes, V rows 64 bytes.
+// Issue model behind the slot layout (tools/ubench_issue.hip, profiles/r2_issue_microbench.txt): with two waves per SIMD a
+// 32x32x16 MFMA occupies the matrix pipe for 32 cycles but hides only ~12 cycles of VALU work; v_fma 2.8, v_exp_f32 8.3,
+// v_cvt_pk_bf16_f32 4.7 cycles per wave instruction.  A tile costs a wave 16 MFMAs and ~570 VALU cycles (half of them the 32
+// v_exp_f32), so the loop is VALU-bound by construction at dh = 64.
+#include "common.cuh"
+#include <stdlib.h>
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef const __attribute__((address_space(1))) void* glb_vptr_t;
+typedef __attribute__((address_space(3))) const char* lds_cptr_t;
+
+__device__ uint4 g_fa_zero_page[1] = {};   // source of the DMA lanes whose key row does not exist (ragged last tile)
+
+template <typename F, int... I>
+__device__ __forceinline__ void fa_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void fa_static_for(F&& f) { fa_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int DH, bool DMA> struct FaCfg {
+  static constexpr int KP = DMA ? DH * 2 : DH * 2 + 16;                 // K row pitch (bytes); padded: odd multiple of 16
+  static constexpr int VP = DMA ? DH * 2 : (DH == 64 ? 192 : 64);       // V row pitch (bytes); padded: +-64 mod 256
+  static constexpr int KT = 64 * KP, VT = 64 * VP, STAGE = KT + VT;
+  static constexpr int NSLOT = DMA ? 4 : 2;
+  static constexpr int OP = DH * 2 + 16;                                // pitch of the output staging rows
+  static constexpr int OST = DMA ? 0 : NSLOT * STAGE;                   // DMA: the output staging aliases the (drained) ring
+  static constexpr int LDS = DMA ? NSLOT * STAGE : NSLOT * STAGE + 4 * 32 * OP;
+  static_assert(!DMA || (DH == 64 && 4 * 32 * OP <= NSLOT * STAGE), "DMA path is laid out for 128-byte rows");
+};
+
+// units of exp work (2 scores each) finished by the end of MFMA slot j; slots = 2*KS QK^T MFMAs then 4*DB PV MFMAs
+template <int DH> struct FaSched;
+template <> struct FaSched<64> {
+  static constexpr int NS = 16, MAX0 = 12;   // row max of S(t+1) spread over slots MAX0 .. NS-1
+  static constexpr int PRE = 2;              // units done under the latency of the first fragment reads, ahead of slot 0
+  static constexpr int unit_end[16] = {3, 4, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 16, 16, 16, 16};
+};
+template <> struct FaSched<32> {
+  static constexpr int NS = 8, MAX0 = 6;
+  static constexpr int PRE = 2;
+  static constexpr int unit_end[8] = {4, 7, 10, 12, 14, 16, 16, 16};
+};
+
+// Built with -fno-slp-vectorize -fno-honor-nans (countr_amd/build.py): plain -O3 SLP-packs adjacent fp32 adds into v_pk_add_f32
+// (slower beside MFMAs, and it collected the row-sum adds of a whole tile into one dependent chain) and wraps every fmaxf of an
+// MFMA result in a canonicalising v_max.  The arithmetic stays compiler-visible: hipcc pads the trans-use and MFMA-result
+// hazards only for instructions it can see.
+__device__ __forceinline__ float max3(float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); }
+
+__device__ __forceinline__ uint32_t fa_lds_addr(const char* p) { return (uint32_t)(uintptr_t)(lds_cptr_t)p; }
+template <int OFF> __device__ __forceinline__ bf16x8_t fa_read_b128(uint32_t a) {
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ bf16x8_t fa_read_tr(uint32_t a) {   // two transposing reads 8 rows apart
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 8 * 128));
+  const s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+// at most PENDING LDS reads outstanding; the fragment is threaded through so that its MFMA cannot move above the wait
+template <int PENDING> __device__ __forceinline__ void fa_lds_wait(bf16x8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(PENDING)); }
+template <int PENDING> __device__ __forceinline__ void fa_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory"); }
+
+// ABL (timing experiments only, selected by COUNTR_FA_ABL; 1-6 give wrong results): 1 = K/V staged in the prologue only (no loads,
+// LDS stores or barriers in the steps), 2 = 1 + no v_exp, 3 = 1 + no MFMA, 4 = staging and barriers only, 5 = empty kernel,
+// 6 = one tile only (prologue + epilogue), 7 = correct output + s_memtime stamps of wave 0 written to lse (tools/stamp_attn.py)
+template <int DH, bool RAGGED, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                             float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
+  constexpr bool DMA = DH == 64;
+  using C = FaCfg<DH, DMA>;
+  using SC = FaSched<DH>;
+  constexpr int KS = DH / 16;        // QK^T k-steps (16 channels each)
+  constexpr int DB = DH / 32;        // 32-channel blocks of O^T
+  constexpr int CPR = DH / 8;        // 16-byte chunks per K/V row
+  constexpr int RPP = 256 / CPR;     // rows staged per pass of the 256 threads (register path)
+  constexpr int PASSES = 64 / RPP;
+  constexpr int NQK = 2 * KS;        // MFMA slots of QK^T
+  constexpr bool STAGING = !(ABL >= 1 && ABL <= 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qblocks = (N + 127) >> 7;
+  // XCD-aware mapping (speed only): all query blocks of one (batch, head) get workgroup ids congruent mod 8 so that its K/V
+  // is fetched into ONE XCD's L2.
+  int bh, qb;
+  const int nbh = gridDim.x / qblocks;
+  if ((nbh & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    bh = xcd * (nbh >> 3) + j / qblocks;
+    qb = j - (j / qblocks) * qblocks;
+  } else {
+    bh = blockIdx.x / qblocks;
+    qb = blockIdx.x - bh * qblocks;
+  }
+  const int b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH;   // row stride (elements) of the packed qkv
+  const bf16_t* qp = qkv + (int64_t)b * N * rs + h * DH;
+  const bf16_t* kp = qp + H * DH;
+  const bf16_t* vp = kp + H * DH;
+  const int q0 = qb * 128 + wave * 32;
+  const bool active = (ABL == 4) ? false : q0 < N;   // wave-uniform
+  const int T = (ABL == 6) ? 1 : (N + 63) >> 6;
+  if (ABL == 5 && N > 0) return;
+  uint64_t tk0 = 0, tkc = 0, tks = 0, tkb = 0, tkp = 0;
+  if (ABL == 7) tk0 = __builtin_readcyclecounter();
+
+  // ---- Q^T fragments (MFMA B operand): lane (ql, hh) holds channels 16 ks + 8 hh .. +7 of query q0 + ql
+  bf16x8_t qf[KS];
+  {
+    const int q = q0 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4_t v = {0, 0, 0, 0};
+      if (q < N) v = *reinterpret_cast<const u32x4_t*>(qp + (int64_t)q * rs + ks * 16 + hh * 8);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  // ================================================================ staging
+  // register path: thread (srow, scc) moves 16-byte chunk scc of rows srow + RPP * pass
+  const int srow = tid / CPR, scc = tid % CPR;
+  u32x4_t kreg[PASSES], vreg[PASSES];
+  auto gload = [&](const bf16_t* base, int tile, u32x4_t (&reg)[PASSES]) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int key = tile * 64 + srow + ps * RPP;
+      if (!RAGGED || key < N) reg[ps] = *reinterpret_cast<const u32x4_t*>(base + (int64_t)key * rs + scc * 8);
+      else reg[ps] = u32x4_t{0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](char* dst, int pitch, const u32x4_t (&reg)[PASSES]) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) *reinterpret_cast<u32x4_t*>(dst + (srow + ps * RPP) * pitch + scc * 16) = reg[ps];
+  };
+  auto Kslot = [&](int slot) { return smem + slot * C::STAGE; };
+  auto Vslot = [&](int slot) { return smem + slot * C::STAGE + C::KT; };
+  // DMA path: wave w streams the 1-KiB pieces 2w, 2w+1 (8 rows each) of the K tile and of the V tile of a stage.  Lane L of piece
+  // p lands in row R = 8p + (L >> 3), 16-byte slot L & 7, and fetches the chunk that slot holds under the swizzle.
+  int koff[2], voff[2], srowd[2];
+  if (DMA) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int R = 8 * (2 * wave + p) + (lane >> 3), cs = lane & 7;
+      srowd[p] = R;
+      koff[p] = R * (int)rs + ((cs ^ ((R >> 1) & 7)) << 3);
+      voff[p] = R * (int)rs + ((cs ^ (((R >> 1) & 1) << 2)) << 3);
+    }
+  }
+  auto dma_tile = [&](const bf16_t* base, int tile, const int (&off)[2], char* dst) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const bf16_t* g = base + (int64_t)tile * 64 * rs + off[p];
+      if (RAGGED && tile * 64 + srowd[p] >= N) g = reinterpret_cast<const bf16_t*>(g_fa_zero_page);
+      __builtin_amdgcn_global_load_lds((glb_vptr_t)g, (lds_vptr_t)(dst + (2 * wave + p) * 1024), 16, 0, 0);
+    }
+  };
+  // stage j = {K(j+1), V(j)} -> ring slot j & 3
+  auto dma_stage = [&](int j) {
+    if (j + 1 < T) dma_tile(kp, j + 1, koff, Kslot(j & 3));
+    dma_tile(vp, j, voff, Vslot(j & 3));
+  };
+  auto stage_count = [&](int j) { return j < T ? (j + 1 < T ? 4 : 2) : 0; };   // DMA instructions of stage j per wave
+  auto vm_wait_pending = [&](int pending) {   // all but the newest `pending` DMA instructions of this wave have landed
+    if (pending >= 4) fa_vm_wait<4>();
+    else if (pending >= 2) fa_vm_wait<2>();
+    else fa_vm_wait<0>();
+  };
+
+  // ================================================================ fragment reads
+  // register path (compiler-visible)
+  auto kfrag = [&](const char* K, int blk, int ks) {   // K rows 32 blk + ql, channels 16 ks + 8 hh .. +7
+    return *reinterpret_cast<const bf16x8_t*>(K + (blk * 32 + ql) * C::KP + ks * 32 + hh * 16);
+  };
+  const int vlane = (4 * hh + ((lane & 15) >> 2)) * C::VP + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+  auto vfrag = [&](const char* V, int blk, int s, int d) {   // V^T: channels 32 d + (lane & 31), keys 32 blk + 16 s + kappa(hh, j)
+    const char* a = V + (blk * 32 + s * 16) * C::VP + d * 64 + vlane;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 8 * C::VP));
+    s16x8_t vv;
+    vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3]; vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, vv);
+  };
+  // DMA path: per-lane byte offsets inside a slot (the swizzle folded in); tile row / block displacements go in the offset field
+  uint32_t kbase[KS], vbase[DB];
+  if (DMA) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kbase[ks] = ql * 128 + (((2 * ks + hh) ^ ((ql >> 1) & 7)) << 4);
+    const int i = lane & 15, fl = (i >> 3) & 1;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) vbase[d] = C::KT + (4 * hh + (i >> 2)) * 128 + ((d ^ fl) << 6) + ((lane >> 4) & 1) * 32 + (i & 3) * 8;
+  }
+
+  f32x16_t o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float mref = 0.f, l0 = 0.f, l1 = 0.f;
+
+  auto mask_tail = [&](f32x16_t (&S)[2], int tile) {   // keys >= N of the ragged last tile do not exist
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (tile * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) S[blk][r] = -INFINITY;
+  };
+  // deferred rescale; every PV MFMA of the pending tile has been issued and l already contains its row sums
+  auto rescale_for = [&](float mx) {
+    const float mloc = mx * c;
+    if (!__all(mloc - mref <= 8.0f)) {
+      const float mnew = fmaxf(mref, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(mref - mnew);
+      mref = mnew;
+      l0 *= alpha;
+      l1 *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+  };
+
+  // exp unit u (0..15) of tile scores S: registers 2u', 2u'+1 of block u >> 3 -> P word, row sums
+  uint32_t P[2][8];
+  auto exp_unit = [&](const f32x16_t (&S)[2], int u) {
+    const int blk = u >> 3, w = u & 7;
+    float p0 = __builtin_fmaf(S[blk][2 * w], c, -mref), p1 = __builtin_fmaf(S[blk][2 * w + 1], c, -mref);
+    if (ABL != 2) { p0 = __builtin_amdgcn_exp2f(p0); p1 = __builtin_amdgcn_exp2f(p1); }
+    l0 += p0;
+    l1 += p1;
+    P[blk][w] = pack2bf(p0, p1);
+  };
+  auto pfrag = [&](int blk, int s) {
+    const u32x4_t v = {P[blk][4 * s], P[blk][4 * s + 1], P[blk][4 * s + 2], P[blk][4 * s + 3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  // ================================================================ prologue: S(0) = K(0) Q^T, its row max
+  // DMA: K(0) -> K area of slot 3 (stage "-1"), stages 0 and 1 -> slots 0, 1 (all in flight together; stage 1 stays in flight).
+  // registers: K(0) -> K area of slot 1, {K(1), V(0)} -> slot 0 (all loads issued before the first wait).
+  const char* K0;
+  if (DMA) {
+    dma_tile(kp, 0, koff, Kslot(3));
+    dma_stage(0);
+    if (1 < T) dma_stage(1);
+    vm_wait_pending(stage_count(1));
+    __builtin_amdgcn_s_barrier();
+    K0 = Kslot(3);
+  } else {
+    u32x4_t k1reg[PASSES];
+    gload(kp, 0, kreg);
+    gload(vp, 0, vreg);
+    if (T > 1) gload(kp, 1, k1reg);
+    lstore(Kslot(1), C::KP, kreg);
+    lstore(Vslot(0), C::VP, vreg);
+    if (T > 1) lstore(Kslot(0), C::KP, k1reg);
+    __syncthreads();
+    K0 = Kslot(1);
+  }
+  f32x16_t SA[2], SB[2];
+  if (active) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) SA[blk][i] = 0.f;
+    if (DMA) {
+      const uint32_t kb = fa_lds_addr(K0);
+      bf16x8_t f[2 * KS];
+      fa_static_for<2 * KS>([&](auto J) { constexpr int j = J; f[j] = fa_read_b128<(j & 1) * 4096>(kb + kbase[j >> 1]); });
+      fa_static_for<2 * KS>([&](auto J) {
+        constexpr int j = J;
+        fa_lds_wait<2 * KS - 1 - j>(f[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        SA[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], qf[j >> 1], SA[j & 1], 0, 0, 0);
+      });
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) SA[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(K0, blk, ks), qf[ks], SA[blk], 0, 0, 0);
+    }
+    if (RAGGED && T == 1) mask_tail(SA, 0);
+    float mx = fmaxf(SA[0][0], SA[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = max3(mx, SA[0][r], SA[1][r]);
+    mref = xor32_max(mx) * c;
+  }
+  if (!DMA) __syncthreads();   // register path: the K area of slot 1 is rewritten at the end of step 0
+
+  // ================================================================ one pipelined step (tile t, t + 1 < T)
+  // Sc = S(t) -> P, Sn = S(t+1) = K(t+1) Q^T, O += V(t)^T P^T, rescale decision for tile t + 1.  Reads stage t.
+  auto step = [&](const int t, f32x16_t (&Sc)[2], f32x16_t (&Sn)[2]) {
+    const int slot = DMA ? (t & 3) : (t & 1);
+    if (STAGING) {
+      if (DMA) {
+        if (t + 2 < T) dma_stage(t + 2);   // slot (t+2)&3 was last read in step t-2: two barriers ago
+      } else {
+        if (t + 2 < T) gload(kp, t + 2, kreg);
+        gload(vp, t + 1, vreg);
+      }
+    }
+    uint64_t ta = 0, tb = 0, tc = 0;
+    if (ABL == 7) ta = __builtin_readcyclecounter();
+    if (active) {
+      const char* K = Kslot(slot);
+      const char* V = Vslot(slot);
+      const uint32_t sb = fa_lds_addr(Kslot(slot));
+      uint32_t ka[KS], va[DB];
+      if (DMA) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka[ks] = sb + kbase[ks];
+#pragma unroll
+        for (int d = 0; d < DB; ++d) va[d] = sb + vbase[d];
+      }
+      bf16x8_t fr[SC::NS];   // operand A of slot j (lives two slots)
+      auto issue = [&](auto J) {   // fragment read(s) of MFMA slot j
+        constexpr int j = J;
+        if constexpr (j < NQK) {
+          if constexpr (DMA) fr[j] = fa_read_b128<(j & 1) * 4096>(ka[j >> 1]);
+          else fr[j] = kfrag(K, j & 1, j >> 1);
+        } else {
+          constexpr int e = j - NQK, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;   // PV slot: key block, k-step, channel block
+          if constexpr (DMA) fr[j] = fa_read_tr<(blk * 32 + s * 16) * 128>(va[d]);
+          else fr[j] = vfrag(V, blk, s, d);
+        }
+      };
+      issue(std::integral_constant<int, 0>{});
+      issue(std::integral_constant<int, 1>{});
+      float mx = 0.f;
+#pragma unroll
+      for (int u = 0; u < SC::PRE; ++u) exp_unit(Sc, u);
+      __builtin_amdgcn_sched_barrier(0);
+      fa_static_for<SC::NS>([&](auto J) {
+        constexpr int j = J;
+        if constexpr (j + 2 < SC::NS) issue(std::integral_constant<int, j + 2>{});
+        if constexpr (DMA) {   // LDS instructions issued after the reads of slot j: those of slots j+1, j+2
+          constexpr int c1 = (j + 1 < SC::NS) ? (j + 1 < NQK ? 1 : 2) : 0, c2 = (j + 2 < SC::NS) ? (j + 2 < NQK ? 1 : 2) : 0;
+          fa_lds_wait<c1 + c2>(fr[j]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (j < NQK) {
+          constexpr int blk = j & 1, ks = j >> 1;
+          if constexpr (ABL == 3) {
+            Sn[blk][ks] = __builtin_bit_cast(float, (int)fr[j][0] | ((int)qf[ks][0] << 16));
+          } else if constexpr (ks == 0) {
+            f32x16_t z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.f;
+            Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], z, 0, 0, 0);
+          } else {
+            Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], Sn[blk], 0, 0, 0);
+          }
+        } else {
+          constexpr int e = j - NQK, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
+          if constexpr (ABL == 3) o[d][e] += __builtin_bit_cast(float, (int)fr[j][0] | ((int)pfrag(blk, s)[0] << 16));
+          else o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], pfrag(blk, s), o[d], 0, 0, 0);
+        }
+        constexpr int u0 = (j == 0) ? SC::PRE : SC::unit_end[j == 0 ? 0 : j - 1], u1 = SC::unit_end[j];
+#pragma unroll
+        for (int u = u0; u < u1; ++u) exp_unit(Sc, u);
+        if constexpr (j >= SC::MAX0) {   // row max of S(t+1), a share per slot
+          constexpr int PER = 16 / (SC::NS - SC::MAX0), r0 = (j - SC::MAX0) * PER;
+          if (RAGGED && j == SC::MAX0 && t + 2 == T) mask_tail(Sn, t + 1);
+#pragma unroll
+          for (int r = r0; r < r0 + PER; ++r) mx = (r == 0) ? fmaxf(Sn[0][0], Sn[1][0]) : max3(mx, Sn[0][r], Sn[1][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      rescale_for(xor32_max(mx));
+    }
+    if (ABL == 7) tb = __builtin_readcyclecounter();
+    if (STAGING) {
+      if (DMA) {
+        vm_wait_pending(stage_count(t + 2));   // stage t+1 has landed (this wave's part); stage t+2 stays in flight
+        if (ABL == 7) tc = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+      } else {
+        if (t + 2 < T) lstore(Kslot(slot ^ 1), C::KP, kreg);
+        lstore(Vslot(slot ^ 1), C::VP, vreg);
+        if (ABL == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tc = __builtin_readcyclecounter(); }
+        __syncthreads();
+      }
+    }
+    if (ABL == 7) { const uint64_t td = __builtin_readcyclecounter(); tkc += tb - ta; tks += tc - tb; tkb += td - tc; }
+  };
+  // ---- last tile: no next scores
+  auto tail = [&](const int t, f32x16_t (&Sc)[2]) {
+    if (active) {
+      const int slot = DMA ? (t & 3) : (t & 1);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) exp_unit(Sc, u);
+      if (DMA) {
+        const uint32_t sb = fa_lds_addr(Kslot(slot));
+        bf16x8_t f[4 * DB];
+        fa_static_for<4 * DB>([&](auto E) {
+          constexpr int e = E, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
+          f[e] = fa_read_tr<(blk * 32 + s * 16) * 128>(sb + vbase[d]);
+        });
+        fa_static_for<4 * DB>([&](auto E) {
+          constexpr int e = E, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
+          fa_lds_wait<2 * (4 * DB - 1 - e)>(f[e]);
+          __builtin_amdgcn_sched_barrier(0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], pfrag(blk, s), o[d], 0, 0, 0);
+        });
+      } else {
+        const char* V = Vslot(slot);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(V, blk, s, d), pfrag(blk, s), o[d], 0, 0, 0);
+      }
+    }
+  };
+
+  if (ABL == 7) tkp = __builtin_readcyclecounter();
+  int t = 0;
+  for (; t + 2 < T; t += 2) {
+    step(t, SA, SB);
+    step(t + 1, SB, SA);
+  }
+  if (t + 1 < T) {
+    step(t, SA, SB);
+    tail(t + 1, SB);
+  } else {
+    tail(t, SA);
+  }
+
+  uint64_t tke = 0;
+  if (ABL == 7) tke = __builtin_readcyclecounter();
+  // ---- epilogue: normalise, stage the wave's [32][DH] bf16 block through its private LDS rows, store whole rows (16-byte chunks)
+  if (DMA) __builtin_amdgcn_s_barrier();   // the staging rows alias the ring: every wave is done with the last V tile (no DMA pending)
+  if (active) {
+    char* ost = smem + C::OST + wave * 32 * C::OP;
+    const float lt = xor32_sum(l0 + l1);
+    const float inv = 1.f / lt;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const uint2 pk = make_uint2(pack2bf(o[d][4 * rg] * inv, o[d][4 * rg + 1] * inv), pack2bf(o[d][4 * rg + 2] * inv, o[d][4 * rg + 3] * inv));
+        *reinterpret_cast<uint2*>(ost + ql * C::OP + (d * 32 + 8 * rg + 4 * hh) * 2) = pk;
+      }
+    const int q = q0 + ql;
+    if (ABL != 7 && lse && hh == 0 && q < N) lse[((int64_t)b * H + h) * N + q] = (mref + log2f(lt)) * 0.6931471805599453f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < (32 * CPR) / 64; ++j) {
+      const int idx = lane + 64 * j, r = idx / CPR, cc = idx % CPR;
+      const uint4 v = *reinterpret_cast<const uint4*>(ost + r * C::OP + cc * 16);
+      if (q0 + r < N) *reinterpret_cast<uint4*>(out + ((int64_t)b * N + q0 + r) * (H * DH) + h * DH + cc * 8) = v;
+    }
+  }
+  if (ABL == 7 && lse && wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint64_t tend = __builtin_readcyclecounter();
+    if (lane == 0) {
+      float* d = lse + blockIdx.x * 8;
+      d[0] = (float)(tend - tk0); d[1] = (float)(tkp - tk0); d[2] = (float)tkc; d[3] = (float)tks; d[4] = (float)tkb;
+      d[5] = (float)(tend - tke); d[6] = (float)(tk0 & 0xffffff); d[7] = (float)(tke - tkp);
+    }
+  }
+}
+
+template <int DH>
+int launch_fa_fwd_pipe(const void* qkv, void* out, float* lse, int B, int N, int H, float c, hipStream_t s) {
+  using C = FaCfg<DH, DH == 64>;
+  dim3 grid(B * H * ((N + 127) / 128)), block(256);
+  static const int abl = [] { const char* e = getenv("COUNTR_FA_ABL"); return e ? atoi(e) : 0; }();
+  if (DH == 64 && abl && N % 64 == 0) {
+    constexpr int lds64 = FaCfg<64, true>::LDS;
+#define COUNTR_FA_ABL_CASE(A) case A: hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, A>), grid, block, lds64, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c); break;
+    switch (abl) { COUNTR_FA_ABL_CASE(1) COUNTR_FA_ABL_CASE(2) COUNTR_FA_ABL_CASE(3) COUNTR_FA_ABL_CASE(4) COUNTR_FA_ABL_CASE(5) COUNTR_FA_ABL_CASE(6) COUNTR_FA_ABL_CASE(7) default: break; }
+#undef COUNTR_FA_ABL_CASE
+    COUNTR_LAUNCH_CHECK("countr_attn_fwd (ablation)");
+  }
+  if (N % 64) {
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, true>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+  } else {
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, false>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+  }
+  COUNTR_LAUNCH_CHECK("countr_attn_fwd");
+}
+
+}  // namespace
+
+// Called by countr_attn_fwd (flash_attn.hip).  dh must be 32 or 64.
+int countr_attn_fwd_pipelined(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, hipStream_t s) {
+  const float c = scale * 1.4426950408889634f;
+  if (dh == 64) return launch_fa_fwd_pipe<64>(qkv, out, lse, B, N, H, c, s);
+  return launch_fa_fwd_pipe<32>(qkv, out, lse, B, N, H, c, s);
+}
