@@ -10,6 +10,7 @@ pipeline of util/FSC147.py is out of scope); `--synthetic_steps K` trains on syn
 iterations per epoch) and is the automatic fallback when the dataset is absent."""
 import argparse
 import json
+import random
 import time
 
 import numpy as np
@@ -87,61 +88,112 @@ def main(args):
                         accum_iter=args.accum_iter)
     if ckpt is not None and args.do_resume and "epoch" in ckpt:      # util/misc.py:400-421: optimizer / epoch only with --do_resume
         args.start_epoch = ckpt["epoch"] + 1
-        opt = ckpt.get("optimizer")
-        if isinstance(opt, dict) and opt.get("exp_avg") is not None and opt["exp_avg"].numel() == step.eng.G.numel():
-            step.eng.M = opt["exp_avg"].to(device)               # our flat AdamW state (a reference optimizer dict is per-tensor
-            step.eng.V = opt["exp_avg_sq"].to(device)            # and in a different order: not convertible without its param groups)
-            step.eng.step_count = int(opt["step"])
+        if step.load_optimizer_state(ckpt.get("optimizer")):
             print("With optim & sched!")
     from countr_amd.data import fsc147
-    loader = None
+    loader = val_loader = None
     if args.synthetic_steps <= 0 and fsc147.available(args):
         ds = fsc147.TrainData(args, split="train", do_aug=args.do_aug)
         sampler = torch.utils.data.DistributedSampler(ds, num_replicas=misc.get_world_size(), rank=misc.get_rank(), shuffle=True)
         loader = torch.utils.data.DataLoader(ds, sampler=sampler, batch_size=args.batch_size, num_workers=args.num_workers,
                                              pin_memory=args.pin_mem, drop_last=True)   # drop_last: the fused step has a static batch
         n_iter = len(loader)
+        dsv = fsc147.TrainData(args, split="val", do_aug=False)                         # :146-155, :185-191
+        vsampler = torch.utils.data.DistributedSampler(dsv, num_replicas=misc.get_world_size(), rank=misc.get_rank(), shuffle=True)
+        val_loader = torch.utils.data.DataLoader(dsv, sampler=vsampler, batch_size=args.batch_size, num_workers=args.num_workers,
+                                                 pin_memory=args.pin_mem, drop_last=False)
+        n_val = len(val_loader)
     else:
         if args.synthetic_steps <= 0:
             print("FSC147 not found under %s: training on synthetic batches" % args.data_path)
         n_iter = args.synthetic_steps if args.synthetic_steps > 0 else 50
+        n_val = max(1, n_iter // 4)
     loss_mask_gen = torch.Generator(device=device).manual_seed(seed)
+    val_rng = random.Random(seed + 7919)      # the reference draws the validation shot_num per rank from `random` (:338)
+    min_MAE = 99999.0                         # :253
+    B = args.batch_size
     t_start = time.time()
     for epoch in range(args.start_epoch, args.epochs):
-        mae = rmse = 0.0
+        # running MAE / RMSE of the epoch (:256-257, :303-304): accumulated on the device, read once per epoch
+        train_acc = torch.zeros(2, dtype=torch.float64, device=device)
         if loader is not None:
             loader.sampler.set_epoch(epoch)                                             # :260-261
         it_data = iter(loader) if loader is not None else None
         for it in range(n_iter):
             if it % args.accum_iter == 0:                                               # :270-271 (per accumulation window)
                 lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
-            S = shared_shot_num(epoch * n_iter + it, seed=args.seed)                   # :278-284 (shared across ranks)
             if it_data is not None:
-                imgs, gt, _n, boxes, _pos, _m, _ids = next(it_data)
+                imgs, gt, _n, boxes, _pos, m_flag, _ids = next(it_data)
                 # loss mask: Bernoulli(0.8) per pixel, one mask per batch (FSC_finetune_cross.py:290-292)
                 mask = (torch.rand(384, 384, device=device, generator=loss_mask_gen) < 0.8).float()
                 # host tensors go straight to load(): it stages them over PCIe on a copy stream while the previous step computes
+                mosaic = int(torch.as_tensor(m_flag).sum().item()) != 0
             else:
-                imgs, boxes, gt, mask = make_batch(args.batch_size, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
+                imgs, boxes, gt, mask = make_batch(B, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
+                mosaic = False
+            if misc.get_world_size() > 1:            # shot_num is shared by all ranks, so is the ban: any rank with a Type-2 mosaic
+                flag = torch.tensor([int(mosaic)], device=device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                mosaic = bool(flag.item())
+            # :276-284: "If there is at least one image in the batch using Type 2 Mosaic, 0-shot is banned."
+            S = shared_shot_num(epoch * n_iter + it, seed=args.seed, allow_zero=not mosaic)
             step.load(imgs, boxes, gt, mask, S)
             sums = step.step(S, lr=lr)
+            err = (sums[1:1 + B] - sums[1 + B:1 + 2 * B]).abs().double()                # :296-304, no host sync
+            train_acc[0] += err.mean()
+            train_acc[1] += (err ** 2).mean()
             if (it + 1) % args.log_every == 0 or it + 1 == n_iter:
-                s = sums.float().cpu().numpy()                                          # the only host sync
-                B = args.batch_size
-                err = np.abs(s[1:1 + B] - s[1 + B:1 + 2 * B])
-                mae += err.mean(); rmse += (err ** 2).mean()
+                s = sums.float().cpu().numpy()                                          # host sync (logging only)
                 loss = misc.all_reduce_mean(float(s[0]))                                # :319
                 if not np.isfinite(loss):
                     raise SystemExit("Loss is %s, stopping training" % loss)            # :308-310
                 if misc.is_main_process():
+                    gn = step.grad_norm()
                     print(json.dumps({"epoch": epoch, "it": it + 1, "loss": loss, "lr": lr, "shot_num": S,
-                                      "batch_MAE": float(err.mean())}))
-        opt_state = {"step": step.eng.step_count, "exp_avg": step.eng.M.cpu() if step.eng.M is not None else None,
-                     "exp_avg_sq": step.eng.V.cpu() if step.eng.V is not None else None}
-        misc.save_model(args, epoch, model, opt_state, suffix="finetuning_last")
-        if args.output_dir and (epoch % 50 == 0 or epoch + 1 == args.epochs) and epoch != 0:
+                                      "batch_MAE": float(np.abs(s[1:1 + B] - s[1 + B:1 + 2 * B]).mean()),
+                                      "grad_norm": float(gn.item()) if gn is not None else None}))
+        # ---- evaluation on the validation split (:329-350): no_grad forward, shot_num drawn per batch, MAE / RMSE / NAE of the counts
+        val = evaluate(model, val_loader, n_val, B, device, val_rng, seed, epoch)
+        train_mae, train_mse = (train_acc / n_iter).tolist()
+        opt_state = step.optimizer_state()
+        if args.output_dir and (epoch % 50 == 0 or epoch + 1 == args.epochs) and epoch != 0:      # :408-412
             misc.save_model(args, epoch, model, opt_state, suffix="finetuning_%d" % epoch)
+        misc.save_model(args, epoch, model, opt_state, suffix="finetuning_last")                  # :413-415
+        if args.output_dir and val["MAE"] < min_MAE:                                              # :416-420
+            min_MAE = val["MAE"]
+            misc.save_model(args, epoch, model, opt_state, suffix="finetuning_minMAE")
+        print("[Train Epoch #%d] - MAE: %5.2f, RMSE: %5.2f" % (epoch, train_mae, train_mse ** 0.5), flush=True)             # :422
+        print("[Val Epoch #%d] - MAE: %5.2f, RMSE: %5.2f, NAE: %5.2f" % (epoch, val["MAE"], val["RMSE"], val["NAE"]), flush=True)  # :423
     print("Training time %.1fs" % (time.time() - t_start))
+
+
+def evaluate(model, val_loader, n_val, B, device, rng, seed, epoch):
+    """Validation pass of FSC_finetune_cross.py:329-350 (per rank, like the reference: its val metrics are not all-reduced)."""
+    was_training = model.training
+    model.eval()
+    acc = torch.zeros(3, dtype=torch.float64, device=device)
+    it_val = iter(val_loader) if val_loader is not None else None
+    with torch.no_grad():
+        for j in range(n_val):
+            if it_val is not None:
+                imgs, gt, _n, boxes, _pos, _m, _ids = next(it_val)
+                imgs, gt, boxes = imgs.to(device, non_blocking=True), gt.to(device, non_blocking=True), boxes.to(device, non_blocking=True)
+            else:
+                imgs, boxes, gt, _mask = make_batch(B, shots=3, seed=seed * 100003 + 7_000_000 + epoch * n_val + j, device=device)
+            S = rng.randint(0, 3)                                                       # :338
+            out = model(imgs, boxes, S)
+            pred = out.reshape(len(imgs), -1).sum(1) / 60
+            gtc = gt.reshape(len(imgs), -1).sum(1) / 60
+            err = (pred - gtc).abs().float()
+            nae = err / gtc
+            nae[nae == float("inf")] = 0                                                # :348-349
+            acc[0] += err.double().mean()
+            acc[1] += (err ** 2).double().mean()
+            acc[2] += nae.double().mean()
+    if was_training:
+        model.train()
+    a = (acc / n_val).tolist()
+    return {"MAE": a[0], "RMSE": a[1] ** 0.5, "NAE": a[2]}
 
 
 if __name__ == "__main__":

@@ -81,13 +81,10 @@ def main(args):
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = PretrainStep(model, batch=args.batch_size, mask_ratio=args.mask_ratio, lr=args.lr, weight_decay=args.weight_decay,
                         betas=(0.9, 0.95), accum_iter=args.accum_iter)
-    if ckpt is not None and isinstance(ckpt.get("optimizer"), dict) and "exp_avg" in ckpt["optimizer"] and "epoch" in ckpt:
-        opt = ckpt["optimizer"]                  # our flat AdamW state (reference optimizer dicts are not convertible)
-        step.eng.M = opt["exp_avg"].to(device)
-        step.eng.V = opt["exp_avg_sq"].to(device)
-        step.eng.step_count = int(opt["step"])
-        args.start_epoch = ckpt["epoch"] + 1
-        print("With optim & sched!")
+    if ckpt is not None and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:352-361
+        if step.load_optimizer_state(ckpt["optimizer"]):                  # (element count checked; a torch per-tensor dict is reported)
+            args.start_epoch = ckpt["epoch"] + 1
+            print("With optim & sched!")
     from countr_amd.data import fsc147
     loader = None
     if args.synthetic_steps <= 0 and fsc147.available(args):
@@ -124,7 +121,7 @@ def main(args):
                 losses.append(lv)
                 if misc.is_main_process():
                     print(json.dumps({"epoch": epoch, "it": it + 1, "loss": lv, "lr": lr}))
-        opt_state = {"step": step.eng.step_count, "exp_avg": step.eng.M.cpu(), "exp_avg_sq": step.eng.V.cpu()}
+        opt_state = step.optimizer_state()
         if args.output_dir and (epoch % 100 == 0 or epoch + 1 == args.epochs):         # :327-329
             misc.save_model(args, epoch, model, opt_state, suffix="pretraining_%d" % epoch)
         if args.output_dir and misc.is_main_process():

@@ -410,20 +410,32 @@ __global__ __launch_bounds__(64) void masked_mse_finish_kernel(const float* __re
 }
 
 // ---------------- fused AdamW over flat fp32 buffers, with an optional low-precision shadow of the params
+// torch.optim.AdamW keeps a step counter PER PARAMETER (bias corrections 1 - beta^t with t = number of steps that parameter took).
+// The conditional parameter sets of the finetune step (exemplar CNN: no gradient when shot_num == 0; shot_token: only then) start
+// later than the rest, so every range names one of three counter groups; with the device-side scalars (graph replay) the layout is
+// hyper[8] = {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}.  zero[r] != 0: the range is stepped with a zero
+// gradient (torch 1.13 optimizer.zero_grad() keeps zero tensors, so a parameter that had a gradient once is stepped ever after).
 struct AdamRanges {
   int n;
   int64_t start[8], end[8];
   float wd[8];
+  int grp[8], zero[8];
 };
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             bf16_t* __restrict__ shadow, AdamRanges R, float lr, float b1, float b2, float eps, float bc1,
-                             float bc2, float grad_scale, const float* __restrict__ hyper) {
-  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; grad_scale = hyper[3]; }  // graph-replay safe
+                             bf16_t* __restrict__ shadow, AdamRanges R, float lr, float b1, float b2, float eps, float bc1s,
+                             float bc2s, float grad_scale, const float* __restrict__ hyper, float* __restrict__ gnorm_ws) {
+  __shared__ float red[4];
+  if (hyper) { lr = hyper[0]; grad_scale = hyper[3]; }  // graph-replay safe
+  float sq = 0.f;
   for (int r = 0; r < R.n; ++r) {
     const float wd = R.wd[r];
+    const int gr = R.grp[r];
+    const float bc1 = hyper ? hyper[gr == 0 ? 1 : 2 + 2 * gr] : bc1s, bc2 = hyper ? hyper[gr == 0 ? 2 : 3 + 2 * gr] : bc2s;
+    const bool zg = R.zero[r] != 0;
     for (int64_t i = R.start[r] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.end[r];
          i += (int64_t)gridDim.x * blockDim.x) {
-      const float gi = g[i] * grad_scale;
+      const float gi = zg ? 0.f : g[i] * grad_scale;
+      sq += gi * gi;
       float pi = p[i] * (1.f - lr * wd);
       const float mi = b1 * m[i] + (1.f - b1) * gi;
       const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -433,6 +445,16 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
       if (shadow) shadow[i] = f2bf(pi);
     }
   }
+  if (gnorm_ws) {   // deterministic two-stage sum of squares of the (scaled) gradients: util/misc.py:289-301 get_grad_norm_
+    sq = block_sum<4>(sq, red);
+    if (threadIdx.x == 0) gnorm_ws[1 + blockIdx.x] = sq;
+  }
+}
+__global__ void gnorm_finish_kernel(float* __restrict__ ws, int nb) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s += ws[1 + i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) ws[0] = sqrtf(s);
 }
 
 }  // namespace
@@ -555,16 +577,25 @@ extern "C" int countr_masked_mse(const float* pred, const float* gt, const float
   COUNTR_LAUNCH_CHECK("countr_masked_mse");
 }
 
+extern "C" int countr_adamw_gnorm_floats(void) { return 1 + 2048; }
 extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
-                                 const int64_t* starts, const int64_t* ends, const float* wds, float lr, float beta1,
-                                 float beta2, float eps, int step, float grad_scale, const float* hyper_dev, void* stream) {
+                                 const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
+                                 const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                 const float* hyper_dev, float* gnorm_ws, void* stream) {
   if (!p || !g || !m || !v || nranges < 1 || nranges > 8 || (step < 1 && !hyper_dev)) { countr_set_error("countr_adamw_step: bad args (1..8 ranges, step >= 1)"); return -1; }
   AdamRanges R;
   R.n = nranges;
   int64_t total = 0;
-  for (int i = 0; i < nranges; ++i) { R.start[i] = starts[i]; R.end[i] = ends[i]; R.wd[i] = wds[i]; total += ends[i] - starts[i]; }
+  for (int i = 0; i < nranges; ++i) {
+    R.start[i] = starts[i]; R.end[i] = ends[i]; R.wd[i] = wds[i]; total += ends[i] - starts[i];
+    R.grp[i] = groups ? groups[i] : 0;
+    R.zero[i] = zero_grad ? zero_grad[i] : 0;
+    if (R.grp[i] < 0 || R.grp[i] > 2) { countr_set_error("countr_adamw_step: counter group must be 0, 1 or 2"); return -1; }
+  }
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(total, 256, 2048)), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev);
+  const int nb = nblocks(total, 256, 2048);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev, gnorm_ws);
+  if (gnorm_ws) hipLaunchKernelGGL(gnorm_finish_kernel, dim3(1), dim3(64), 0, STREAM(stream), gnorm_ws, nb);
   COUNTR_LAUNCH_CHECK("countr_adamw_step");
 }
 

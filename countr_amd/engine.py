@@ -95,6 +95,33 @@ class ParamLayout:
             out.append((s, e, 0.0 if nodecay else weight_decay))
         return out
 
+    def adam_plan(self, weight_decay, skip=(), zero=(), group_of_bucket=None):
+        """(start, end, wd, counter group, zero-gradient flag) of every range the optimizer steps: buckets in `skip` never had a
+        gradient (torch: grad is None -> skipped), buckets in `zero` had one earlier but none in this window (torch 1.13
+        zero_grad() leaves a zero tensor -> stepped with g = 0)."""
+        gob = ADAM_GROUP_OF_BUCKET if group_of_bucket is None else group_of_bucket
+        return [(s, e, 0.0 if nodecay else weight_decay, gob.get(bucket, 0), int(bucket in zero))
+                for (bucket, nodecay), s, e in self.segments if bucket not in skip]
+
+
+def check_supported(cfg, img_size):
+    """The gfx950 kernels cover the CounTR shapes: fused attention for head_dim 32 / 64 and a patch grid that tiles the image.
+    mae_vit_huge_patch14 (models_mae_cross.py:235-239: patch 14 does not divide 384, head_dim 1280 / 16 = 80) can be constructed
+    and (de)serialised -- its state_dict schema is the reference's -- but cannot be executed."""
+    patch, D, _depth, H, Dd, _dd, Hd = cfg
+    bad = []
+    if img_size % patch:
+        bad.append("patch size %d does not divide the %d-pixel input" % (patch, img_size))
+    for what, dim, heads in (("encoder", D, H), ("decoder", Dd, Hd)):
+        if dim % heads or dim // heads not in (32, 64):
+            bad.append("%s head_dim %s (embed_dim %d / %d heads) is not 32 or 64" % (what, dim / heads, dim, heads))
+    if bad:
+        raise _lib.CountrError("this model configuration is not supported by the gfx950 kernels: " + "; ".join(bad))
+
+
+# bias-correction counter group of an AdamW range by gradient bucket: the conditional parameter sets start stepping later
+ADAM_GROUP_OF_BUCKET = {0: 0, 1: 0, 2: 1, 3: 2}
+
 
 class _Fake:
     """Stand-in tensor used by the sizing pass of a plan build (no memory is touched)."""
@@ -123,8 +150,10 @@ class Plan:
 
 
 class Engine:
-    def __init__(self, cfg, named_shapes, device, precision="bf16", img_size=384, attention="auto"):
-        """cfg = (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads)."""
+    def __init__(self, cfg, named_shapes, device, precision="bf16", img_size=384, attention="auto", ln_eps=1e-6):
+        """cfg = (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads); ln_eps: eps of the model's norm_layer (the
+        reference factories pass partial(nn.LayerNorm, eps=1e-6), models_mae_cross.py:210-239)."""
+        self.ln_eps = float(ln_eps)
         self.L = _lib.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -132,6 +161,7 @@ class Engine:
         _lib.check(self.L.countr_init(self.device.index or 0), "countr_init")
         self.cfg = cfg
         self.patch, self.D, self.depth, self.H, self.Dd, self.ddepth, self.Hd = cfg
+        check_supported(cfg, img_size)
         self.img = img_size
         self.grid = img_size // self.patch
         self.N = self.grid * self.grid
@@ -156,8 +186,11 @@ class Engine:
             self.Wf[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
             self.Wd[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
         self.plans = {}
-        self.hyper = torch.zeros(4, device=self.device, dtype=torch.float32)
+        self.hyper = torch.zeros(8, device=self.device, dtype=torch.float32)   # {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
         self.step_count = 0
+        self.group_steps = [0, 0, 0]    # optimizer steps taken by counter group 0 (always), 1 (exemplar CNN), 2 (shot_token)
+        self.opt_seen = set()           # conditional gradient buckets (2, 3) that have had a gradient at least once
+        self.gnorm = None               # device fp32 [countr_adamw_gnorm_floats()]: [0] = gradient L2 norm of the last step
         self._ws = {}
         self._need = {}
         self._sizing = False
@@ -433,7 +466,7 @@ class Engine:
 
     def _layernorm(self, ops, x, name, y, rows, D, mean=None, rstd=None):
         self._op(ops, self.L.countr_layernorm_fwd, x.data_ptr(), self._pp(name + ".weight"), self._pp(name + ".bias"), y.data_ptr(),
-                 mean.data_ptr() if mean is not None else None, rstd.data_ptr() if rstd is not None else None, rows, D, 1e-6,
+                 mean.data_ptr() if mean is not None else None, rstd.data_ptr() if rstd is not None else None, rows, D, self.ln_eps,
                  int(y.dtype == torch.bfloat16))
 
     def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate, dx_t=None):
@@ -841,6 +874,8 @@ class Engine:
         p = self.plan(B, int(shot_num), train)
         self._load_inputs(p, imgs, boxes, int(shot_num))
         self.run(p.fwd_par)
+        if train:
+            p.fwd_gen = getattr(p, "fwd_gen", 0) + 1   # the activations a backward of this plan will read belong to THIS forward
         return p.buf["out"]
 
     def backward(self, B, shot_num, dout):
@@ -854,22 +889,35 @@ class Engine:
     def adam_ranges(self, S, weight_decay, skip=None):
         return self.layout.adam_ranges(S, weight_decay, skip)
 
-    def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None, skip=None):
-        """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[4] {lr, 1-b1^t, 1-b2^t, grad_scale}
-        read by the kernel at run time, so a captured launch can be replayed with new values."""
+    def adam_plan(self, weight_decay, skip=(), zero=()):
+        return self.layout.adam_plan(weight_decay, skip, zero)
+
+    def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None, skip=None,
+                     zero=(), gnorm=False):
+        """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[8] {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1],
+        bc1[2], bc2[2]} read by the kernel at run time, so a captured launch can be replayed with new values.  skip=None: the
+        shot_num rule of adam_ranges (parameters without a gradient for S are skipped)."""
         if self.M is None:
             self.M = torch.zeros_like(self.G)
             self.V = torch.zeros_like(self.G)
-        rng = self.adam_ranges(S, weight_decay, skip)
+        if skip is None:
+            rng = [(s, e, wd, 0, 0) for s, e, wd in self.adam_ranges(S, weight_decay, None)]
+        else:
+            rng = self.adam_plan(weight_decay, tuple(skip), tuple(zero))
         n = len(rng)
         starts = (C.c_int64 * n)(*[r[0] for r in rng])
         ends = (C.c_int64 * n)(*[r[1] for r in rng])
         wds = (C.c_float * n)(*[r[2] for r in rng])
+        groups = (C.c_int * n)(*[r[3] for r in rng])
+        zeros = (C.c_int * n)(*[r[4] for r in rng])
+        if gnorm and self.gnorm is None:
+            self.gnorm = torch.zeros(self.L.countr_adamw_gnorm_floats(), device=self.device, dtype=torch.float32)
         lay = self.layout
         shadow = (self.Wt.data_ptr() + 2 * lay.train_start) if self.precision == "bf16" else None
         _lib.check(self.L.countr_adamw_step(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                            shadow, n, starts, ends, wds, lr, betas[0], betas[1], eps, step, grad_scale,
-                                            hyper_dev.data_ptr() if hyper_dev is not None else None, self._stream()), "adamw")
+                                            shadow, n, starts, ends, wds, groups, zeros, lr, betas[0], betas[1], eps, step, grad_scale,
+                                            hyper_dev.data_ptr() if hyper_dev is not None else None,
+                                            self.gnorm.data_ptr() if gnorm else None, self._stream()), "adamw")
         self._refresh_conv_shadows()
 
     def adamw_step(self, S, lr, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):

@@ -57,6 +57,9 @@ class MaeEngine(Engine):
     def adam_ranges(self, S, weight_decay, skip=None):
         return [(s, e, 0.0 if nodecay else weight_decay) for (_b, nodecay), s, e in self.layout.segments]
 
+    def adam_plan(self, weight_decay, skip=(), zero=()):   # every parameter has a gradient in every step: one counter group
+        return [(s, e, wd, 0, 0) for s, e, wd in self.adam_ranges(0, weight_decay)]
+
     # ------------------------------------------------------------------ timm Block (x += attn(norm1 x); x += mlp(norm2 x))
     def _block_fwd(self, ops, p, b, xin, B, N, Dm, heads, train):
         T, f32 = self.tdt, torch.float32

@@ -27,12 +27,19 @@ class _DecoderFn(torch.autograd.Function):
         eng = model._engine()
         out = eng.forward(imgs, boxes, shot_num, train=True)
         ctx.model, ctx.B, ctx.S, ctx.nparams = model, imgs.shape[0], int(shot_num), len(params)
+        ctx.gen = eng.plan(ctx.B, ctx.S, True).fwd_gen
         return out.clone()
 
     @staticmethod
     def backward(ctx, dout):
         model = ctx.model
         eng = model._engine()
+        # the engine keeps ONE set of activation buffers per (batch, shot_num): a second train-mode forward of the same shape
+        # overwrites what this backward needs (the reference module has no such limit) -- refuse instead of returning wrong gradients
+        if eng.plan(ctx.B, ctx.S, True).fwd_gen != ctx.gen:
+            raise RuntimeError("SupervisedMAE (HIP engine): backward() of a forward whose activations were overwritten by a later "
+                               "train-mode forward with the same (batch, shot_num); run backward before the next forward "
+                               "(gradient accumulation across forwards is supported by countr_amd.trainer.FinetuneStep)")
         eng.backward(ctx.B, ctx.S, dout.contiguous().float())
         grads = []
         unused = ("decoder_proj",) if ctx.S == 0 else ("shot_token",)
@@ -112,7 +119,7 @@ class SupervisedMAE(HipModule):
 
     # ------------------------------------------------------------------ engine plumbing (see _module.HipModule)
     def _make_engine(self, shapes, device):
-        return Engine(self.cfg, shapes, device, precision=self.precision, img_size=self.img_size)
+        return Engine(self.cfg, shapes, device, precision=self.precision, img_size=self.img_size, ln_eps=self.norm.eps)
 
     def _is_trainable(self, name):
         return is_trainable(name)

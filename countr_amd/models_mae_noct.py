@@ -87,7 +87,7 @@ class MaskedAutoencoderViTNoCT(HipModule):
             nn.init.constant_(m.weight, 1.0)
 
     def _make_engine(self, shapes, device):
-        return MaeEngine(self.cfg, shapes, device, precision=self.precision, img_size=self.img_size)
+        return MaeEngine(self.cfg, shapes, device, precision=self.precision, img_size=self.img_size, ln_eps=self.norm.eps)
 
     def _is_trainable(self, name):
         return mae_trainable(name)

@@ -41,7 +41,7 @@ class _GraphStep:
         self.bucket_rest = (self.bucket0[1], lay.n_train)
         self.sync = self._make_sync(process_group)
         self.world = self.sync.world
-        self._ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self._ring = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._ring_ev = [None] * 16
         self.grad_scale = 1.0 / self.accum
 
@@ -84,15 +84,21 @@ class _GraphStep:
     def _phases(self, key):     # [(name, launcher, graph key)]: forward + loss + first backward part, then the remaining backward parts
         raise NotImplementedError
 
-    def _skip(self, key):
+    def _comm_skip(self, touched):
+        """Gradient buckets that are not all-reduced in this step (nobody has a gradient for them)."""
         return ()
+
+    def _adam_sets(self, touched):
+        """(skip, zero): buckets the optimizer skips (never had a gradient) / steps with a zero gradient."""
+        return (), ()
 
     def _lists(self, plan, acc):
         """The plan's backward launch lists that overwrite (first micro-step) or accumulate into (later ones) eng.G."""
         return plan.acc if acc else plan
 
-    def _phase_c(self, skip):
-        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip)
+    def _phase_c(self, key):
+        skip, zero = key
+        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip, zero=zero, gnorm=True)
 
     def _run_phase(self, name, fn, S):
         """S: hashable argument of the phase; (name, S) identifies its captured graph."""
@@ -114,23 +120,60 @@ class _GraphStep:
             return
         g.replay()
 
-    def _upload_hyper(self):
-        """Step-dependent AdamW scalars go through a small device buffer so that graph replay sees new values."""
+    def _upload_hyper(self, skip=()):
+        """Step-dependent AdamW scalars go through a small device buffer so that graph replay sees new values.  Bias corrections
+        are per counter group (torch.optim.AdamW counts steps per parameter): group 0 steps always, group 1 (exemplar CNN, bucket
+        2) and group 2 (shot_token, bucket 3) only once they have had a gradient."""
         eng = self.eng
         eng.step_count += 1
+        eng.group_steps[0] += 1
+        for bucket, grp in ((2, 1), (3, 2)):
+            if bucket not in skip:
+                eng.group_steps[grp] += 1
         slot = eng.step_count % len(self._ring)
         ev = self._ring_ev[slot]
         if ev is not None:
             ev.synchronize()  # the copy that last used this pinned slot has completed
         h = self._ring[slot]
         h[0] = self.lr
-        h[1] = 1.0 - self.betas[0] ** eng.step_count
-        h[2] = 1.0 - self.betas[1] ** eng.step_count
         h[3] = self.grad_scale / self.world
+        for grp, (i1, i2) in enumerate(((1, 2), (4, 5), (6, 7))):
+            t = max(eng.group_steps[grp], 1)
+            h[i1] = 1.0 - self.betas[0] ** t
+            h[i2] = 1.0 - self.betas[1] ** t
         eng.hyper.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._ring_ev[slot] = ev
+
+    # ------------------------------------------------------------------ optimizer state (checkpoint 'optimizer' entry)
+    def optimizer_state(self):
+        """Flat AdamW state of the engine: first / second moments over the trainable region, the global step and the per-group step
+        counters.  (A reference checkpoint stores torch's per-tensor state dict instead; see load_optimizer_state.)"""
+        eng = self.eng
+        return {"format": "countr_amd.flat_adamw.v2", "step": eng.step_count, "group_steps": list(eng.group_steps),
+                "seen_buckets": sorted(eng.opt_seen), "exp_avg": eng.M.cpu() if eng.M is not None else None,
+                "exp_avg_sq": eng.V.cpu() if eng.V is not None else None}
+
+    def load_optimizer_state(self, opt):
+        """Restores optimizer_state(); returns False (and prints why) when `opt` is not ours -- e.g. the torch.optim.AdamW
+        state_dict of a reference checkpoint, whose per-tensor entries are keyed by parameter-group order and cannot be mapped
+        onto the flat buffers without the reference's parameter list."""
+        eng = self.eng
+        if not isinstance(opt, dict) or opt.get("exp_avg") is None:
+            print("checkpoint 'optimizer' entry is not a countr_amd flat AdamW state (torch per-tensor state?): optimizer state NOT restored")
+            return False
+        if opt["exp_avg"].numel() != eng.G.numel() or opt["exp_avg_sq"].numel() != eng.G.numel():
+            print("checkpoint optimizer state has %d elements, this model trains %d: optimizer state NOT restored"
+                  % (opt["exp_avg"].numel(), eng.G.numel()))
+            return False
+        eng.M = opt["exp_avg"].to(eng.device, torch.float32)
+        eng.V = opt["exp_avg_sq"].to(eng.device, torch.float32)
+        eng.step_count = int(opt["step"])
+        gs = opt.get("group_steps")
+        eng.group_steps = [int(x) for x in gs] if gs is not None else [eng.step_count] * 3   # v1 files: one global counter
+        eng.opt_seen = set(int(b) for b in opt.get("seen_buckets", (2, 3) if eng.step_count else ()))
+        return True
 
     def _step(self, key):
         """backward phases in bucket order: after phase i the gradients of bucket i are final and its all-reduce starts on the
@@ -147,10 +190,11 @@ class _GraphStep:
                 if last and i + 1 < len(phases):
                     self.sync.start(i)
             if last:
-                skip = tuple(self._skip(key))
-                self.sync.finish(skip=skip)
-                self._upload_hyper()
-                self._run_phase("c", self._phase_c, skip)
+                touched = frozenset(self._touched)
+                self.sync.finish(skip=tuple(self._comm_skip(touched)))
+                skip, zero = self._adam_sets(touched)
+                self._upload_hyper(skip)
+                self._run_phase("c", self._phase_c, (tuple(skip), tuple(zero)))
         torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
         if last:
             self.model.mark_weights_synced()
@@ -188,10 +232,21 @@ class FinetuneStep(_GraphStep):
         lay = self.eng.layout   # buckets in backward-completion order: head | decoder blocks + embed | exemplar CNN | shot_token
         return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
 
-    def _skip(self, S):
-        """Parameters without a gradient in this window (exemplar CNN when every micro-step had shot_num 0, shot_token when none
-        had) are neither reduced nor stepped, as torch AdamW skips grad None."""
-        return tuple(b for b in (2, 3) if b not in self._touched)
+    def _comm_skip(self, touched):
+        """Conditional buckets without a gradient in this window (exemplar CNN when every micro-step had shot_num 0, shot_token
+        when none had) are not all-reduced: their gradient is None / zero on every rank (shot_num is shared)."""
+        return tuple(b for b in (2, 3) if b not in touched)
+
+    def _adam_sets(self, touched):
+        """Optimizer semantics of the reference environment (torch 1.13.1, FSC_finetune_cross.py:313-316): a parameter whose
+        .grad is None is skipped; optimizer.zero_grad() leaves ZERO tensors behind, so once a conditional parameter set has had a
+        gradient it is stepped in every later iteration -- with g = 0 (moment decay + bias-corrected update) when the drawn
+        shot_num does not use it -- and its step counter runs from its first gradient."""
+        seen = self.eng.opt_seen
+        seen |= set(touched)
+        skip = tuple(b for b in (2, 3) if b not in seen)
+        zero = tuple(b for b in (2, 3) if b in seen and b not in touched)
+        return skip, zero
 
     def _phase_b(self, key):
         S, acc = key
@@ -233,6 +288,11 @@ class FinetuneStep(_GraphStep):
             self.lr = lr
         self.applied = self._step(S)
         return self.sums[S]
+
+    def grad_norm(self):
+        """Device scalar: L2 norm of the (averaged) gradients the last optimizer step consumed -- get_grad_norm_ of
+        util/misc.py:289-301 as returned by NativeScalerWithGradNormCount.__call__ (:266-280).  No host sync."""
+        return self.eng.gnorm[0] if self.eng.gnorm is not None else None
 
 
 class PretrainStep(_GraphStep):

@@ -58,9 +58,20 @@ def save_model(args, epoch, model_without_ddp, optimizer_state, suffix=""):
     return path
 
 
+def _checkpoint_path(args):
+    """The reference hands args.resume straight to torch.load (util/misc.py:338-376): a missing file raises.  Here an EMPTY
+    --resume means "start from the model's own initialisation"; a non-empty path that does not exist is an error -- with the
+    encoder frozen, silently finetuning a randomly initialised encoder would still write plausible-looking checkpoints."""
+    if not args.resume:
+        return None
+    if not os.path.exists(args.resume):
+        raise FileNotFoundError("--resume %r does not exist (pass --resume '' to start from the model's initialisation)" % args.resume)
+    return args.resume
+
+
 def load_model_FSC(args, model_without_ddp):
     """util/misc.py:363-376: strict=False, pos_embed dropped on shape mismatch."""
-    if not args.resume or not os.path.exists(args.resume):
+    if _checkpoint_path(args) is None:
         return None
     ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
     sd = ckpt["model"] if "model" in ckpt else ckpt
@@ -75,7 +86,7 @@ def load_model_FSC(args, model_without_ddp):
 def load_model(args, model_without_ddp):
     """util/misc.py:338-361 (pretraining resume, starts from MAE ImageNet weights FSC_pretrain.py:80): strict=False, both
     pos-embeds dropped on shape mismatch; returns the checkpoint (the caller restores the flat AdamW state / epoch)."""
-    if not args.resume or not os.path.exists(args.resume):
+    if _checkpoint_path(args) is None:
         return None
     ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
     sd = ckpt["model"]

@@ -194,12 +194,20 @@ int countr_conv_shadows(int n, const float* const* src, void* const* wf, void* c
 int countr_masked_mse_workspace_floats(int B);
 int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
                       float* workspace, int B, int HW, float grad_scale, void* stream);
-/* fused AdamW over flat fp32 buffers; up to 8 [start,end) ranges each with its weight decay.
- * hyper_dev (optional, device fp32[4] = {lr, 1-beta1^t, 1-beta2^t, grad_scale}) overrides the scalars so a
- * captured graph can be replayed with new values.  shadow_bf16 (optional) receives bf16(p). */
+/* fused AdamW over flat fp32 buffers (torch.optim.AdamW at FSC_finetune_cross.py:235); up to 8 [start,end) ranges each with
+ * its weight decay, its bias-correction counter group (groups[i] in {0,1,2}, NULL = all 0: torch keeps a step counter per
+ * parameter, util/misc.py:266-280 steps only parameters that have a gradient) and a zero-gradient flag (zero_grad[i] != 0: the
+ * range is stepped with g = 0, which is what torch 1.13's zero_grad() -- zero tensors, not None -- makes of a parameter that is
+ * unused in this iteration but had a gradient before).  hyper_dev (optional, device fp32[8] = {lr, bc1[0], bc2[0], grad_scale,
+ * bc1[1], bc2[1], bc1[2], bc2[2]}, bc = 1 - beta^t of the group) overrides the scalars so a captured graph can be replayed with
+ * new values; without it every group uses `step`.  shadow_bf16 (optional) receives bf16(p).  gnorm_ws (optional,
+ * countr_adamw_gnorm_floats() floats): gnorm_ws[0] = L2 norm of the (scaled) gradients of the stepped ranges
+ * (get_grad_norm_, util/misc.py:289-301). */
+int countr_adamw_gnorm_floats(void);
 int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
-                      const int64_t* starts, const int64_t* ends, const float* wds, float lr, float beta1,
-                      float beta2, float eps, int step, float grad_scale, const float* hyper_dev, void* stream);
+                      const int64_t* starts, const int64_t* ends, const float* wds, const int* groups, const int* zero_grad,
+                      float lr, float beta1, float beta2, float eps, int step, float grad_scale, const float* hyper_dev,
+                      float* gnorm_ws, void* stream);
 
 /* ---- MAE pretraining (reference models_mae_noct.py) ----
  * row gather: dst[r,:] = (idx[r] >= 0 ? src[idx[r],:] : default_row[:]) + add[r % add_mod,:]; idx may be NULL (identity),

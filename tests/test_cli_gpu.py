@@ -49,6 +49,19 @@ def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
     assert len(lines) == 2 and all(np.isfinite(l["loss"]) for l in lines)          # 4 images / batch 2, drop_last
     ckpt = os.path.join(out, "checkpoint__finetuning_last.pth")
     assert os.path.exists(ckpt)
+    # validation pass (FSC_finetune_cross.py:329-350, :416-423): MAE / RMSE / NAE line and the model-selection checkpoint
+    assert os.path.exists(os.path.join(out, "checkpoint__finetuning_minMAE.pth"))
+    val = [l for l in log.splitlines() if l.startswith("[Val Epoch #0]")]
+    assert len(val) == 1 and "MAE:" in val[0] and "RMSE:" in val[0] and "NAE:" in val[0]
+    assert any(l.startswith("[Train Epoch #0] - MAE:") for l in log.splitlines())
+    assert all(l["grad_norm"] is not None and np.isfinite(l["grad_norm"]) and l["grad_norm"] > 0 for l in lines)
+    import torch
+    opt = torch.load(ckpt, map_location="cpu", weights_only=False)["optimizer"]
+    assert opt["step"] == 2 and len(opt["group_steps"]) == 3 and opt["exp_avg"].numel() == opt["exp_avg_sq"].numel()
+    # a mistyped --resume must not silently finetune a randomly initialised (frozen) encoder
+    r = subprocess.run([sys.executable, "FSC_finetune_cross.py", "--data_path", fake_fsc, "--batch_size", "2", "--epochs", "1",
+                        "--output_dir", out, "--resume", "/nonexistent/checkpoint-300.pth"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "does not exist" in r.stderr
     # --do_resume restores epoch and the flat AdamW state and continues with epoch 1
     log = run(["FSC_finetune_cross.py", "--data_path", "/nonexistent", "--synthetic_steps", "2", "--batch_size", "2", "--epochs", "2",
                "--warmup_epochs", "0", "--output_dir", out, "--resume", ckpt, "--do_resume", "--log_every", "1", "--accum_iter", "2"])

@@ -1,0 +1,58 @@
+"""GPU: the N > 1 step on ONE GPU.  Two ranks (gloo; RCCL refuses two ranks per device) run FinetuneStep / PretrainStep under
+hipGraph replay with the bucketed gradient all-reduce between the backward phases (collectives on the side stream, 1/world
+folded into AdamW).  Requirements: parameters bit-identical across ranks, and equal (fp32 mode) to ONE process stepping the
+2B-image global batch.  Reference: DDP wrap FSC_finetune_cross.py:178-183,230; util/misc.py:225-257."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(what, outdir):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), what, str(outdir)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [torch.load(os.path.join(outdir, "%s_rank%d.pt" % (what, k)), weights_only=False) for k in range(2)]
+
+
+@pytest.mark.parametrize("what", ["finetune", "pretrain"])
+def test_two_ranks_on_one_gpu_match_single_process(what, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_gpu_worker as Wk
+    r0, r1 = launch(what, tmp_path)
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k            # ranks stay bit-identical
+    single, losses = (Wk.run_finetune if what == "finetune" else Wk.run_pretrain)(0, 1, 4)
+    # the logged loss of a rank is the loss of ITS half; their mean is the global-batch loss
+    for a, b, c in zip(r0["losses"], r1["losses"], losses):
+        assert abs(0.5 * (a + b) - c) <= 2e-4 * abs(c), (a, b, c)
+    lr = 1e-3
+    n_steps = len(losses)
+    for k, p in single.named_parameters():
+        d = (p.detach().cpu().double() - r0["params"][k].double()).abs()
+        # same tolerance logic as test_trainer_gpu: AdamW steps are ~lr per element; summation order differs (2 x B=2 vs B=4)
+        assert d.pow(2).mean().sqrt().item() <= 0.03 * lr * n_steps, (k, d.pow(2).mean().sqrt().item())
+        if not k.startswith("decoder_proj"):
+            assert d.max().item() <= 0.3 * lr * n_steps, (k, d.max().item())
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` started like the N = 1 run (no torch.distributed.run) re-launches itself with one rank per
+    requested GPU and reports n_gpus = 2 (gloo on the single GPU of this box)."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["value"] > 0

@@ -309,29 +309,55 @@ def test_masked_mse_and_adamw(hip):
     assert relerr(dp, pr.grad) < 1e-5
     assert relerr(sums[1:1 + B], R.counts(pred.double())) < 1e-5
     assert relerr(sums[1 + B:], R.counts(gt.double())) < 1e-5
-    # AdamW: 3 steps, two ranges (wd / no wd), scalars and device-hyper forms
-    n = 100003
+    # AdamW vs the real torch.optim.AdamW (FSC_finetune_cross.py:235): two weight-decay groups; the second range joins at step 2
+    # (its gradient was None before -> skipped, own step counter) and gets a zero gradient at step 4 (torch 1.13 zero_grad()
+    # semantics: zero tensor, still stepped); scalars and device-hyper forms; gradient norm (util/misc.py:289-301)
+    n, n0 = 100003, 60000
     p0 = rnd((n,), 31); p = p0.cuda().clone()
     m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
     shadow = torch.empty(n, device="cuda", dtype=torch.bfloat16)
-    pr_, mr, vr = p0.double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
-    starts = (C.c_int64 * 2)(0, 60000); ends = (C.c_int64 * 2)(60000, n); wds = (C.c_float * 2)(0.05, 0.0)
-    for step in range(1, 4):
+    gn = torch.zeros(hip.countr_adamw_gnorm_floats(), device="cuda")
+    ta, tb = torch.nn.Parameter(p0[:n0].double().clone()), torch.nn.Parameter(p0[n0:].double().clone())
+    opt = torch.optim.AdamW([{"params": [ta], "weight_decay": 0.05}, {"params": [tb], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    starts = (C.c_int64 * 2)(0, n0); ends = (C.c_int64 * 2)(n0, n); wds = (C.c_float * 2)(0.05, 0.0)
+    groups = (C.c_int * 2)(0, 1)
+    tsteps = [0, 0]
+    for step in range(1, 6):
         gsteps = rnd((n,), 40 + step)
         gdev = gsteps.cuda()
         lr = 1e-3 * step
-        if step < 3:
-            _lib.check(hip.countr_adamw_step(P(p), P(gdev), P(m), P(v), P(shadow), 2, starts, ends, wds, lr, 0.9, 0.95, 1e-8,
-                                             step, 1.0, None, st()))
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        b_has = step >= 2 and step != 4          # range b: no gradient at step 1 (None), zero gradient at step 4
+        ta.grad = gsteps[:n0].double().clone()
+        if b_has:
+            tb.grad = gsteps[n0:].double().clone()
+        elif step == 4:
+            tb.grad = torch.zeros_like(tb)       # what optimizer.zero_grad(set_to_none=False) leaves behind
         else:
-            hyper = torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 1.0], device="cuda")
-            _lib.check(hip.countr_adamw_step(P(p), P(gdev), P(m), P(v), P(shadow), 2, starts, ends, wds, 0.0, 0.9, 0.95, 1e-8,
-                                             0, 0.0, P(hyper), st()))
-        a, ma, va = R.adamw_step(pr_[:60000], gsteps.double()[:60000], mr[:60000], vr[:60000], step, lr, wd=0.05)
-        b, mb, vb = R.adamw_step(pr_[60000:], gsteps.double()[60000:], mr[60000:], vr[60000:], step, lr, wd=0.0)
-        pr_, mr, vr = torch.cat([a, b]), torch.cat([ma, mb]), torch.cat([va, vb])
-        assert relerr(p, pr_) < 1e-5
+            tb.grad = None
+        opt.step()
+        nr = 2 if step >= 2 else 1
+        zeros = (C.c_int * 2)(0, 1 if step == 4 else 0)
+        tsteps[0] += 1
+        tsteps[1] += 1 if step >= 2 else 0
+        bc = lambda t: (1 - 0.9 ** max(t, 1), 1 - 0.95 ** max(t, 1))
+        hyper = torch.tensor([lr, *bc(tsteps[0]), 1.0, *bc(tsteps[1]), 1.0, 1.0], device="cuda")
+        _lib.check(hip.countr_adamw_step(P(p), P(gdev), P(m), P(v), P(shadow), nr, starts, ends, wds, groups, zeros, 0.0, 0.9, 0.95, 1e-8,
+                                         0, 0.0, P(hyper), P(gn), st()))
+        pr_ = torch.cat([ta.detach(), tb.detach()])
+        assert relerr(p, pr_) < 1e-5, step
+        want = gsteps[:n0].double().pow(2).sum() + (gsteps[n0:].double().pow(2).sum() if b_has else 0.0)
+        assert abs(gn[0].item() - want.sqrt().item()) < 1e-5 * want.sqrt().item(), step
     assert relerr(shadow, pr_) < 5e-3
+    # scalar form (no device hyper): every range uses `step`
+    p2 = p0.cuda().clone(); m2 = torch.zeros(n, device="cuda"); v2 = torch.zeros(n, device="cuda")
+    g1 = rnd((n,), 77)
+    _lib.check(hip.countr_adamw_step(P(p2), P(g1.cuda()), P(m2), P(v2), None, 2, starts, ends, wds, None, None, 1e-3, 0.9, 0.95, 1e-8,
+                                     1, 1.0, None, None, st()))
+    a, _, _ = R.adamw_step(p0.double()[:n0], g1.double()[:n0], torch.zeros(n0, dtype=torch.float64), torch.zeros(n0, dtype=torch.float64), 1, 1e-3, wd=0.05)
+    b, _, _ = R.adamw_step(p0.double()[n0:], g1.double()[n0:], torch.zeros(n - n0, dtype=torch.float64), torch.zeros(n - n0, dtype=torch.float64), 1, 1e-3, wd=0.0)
+    assert relerr(p2, torch.cat([a, b])) < 1e-5
 
 
 @pytest.mark.parametrize("B,N,H,dh", [(2, 576, 12, 64), (2, 576, 16, 32), (1, 200, 3, 64), (1, 64, 2, 32)])

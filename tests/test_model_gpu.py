@@ -181,3 +181,37 @@ def test_other_factories_fp32_match_oracle(name, tol):
     got = out.cpu().numpy().reshape(ref.shape)
     assert rel(got, ref) <= tol
     assert abs(got.sum() / 60 - ref.sum() / 60) < 0.5
+
+
+def test_unsupported_configuration_fails_loudly():
+    """mae_vit_huge_patch14 (models_mae_cross.py:235-239: patch 14, head_dim 80) keeps the reference's constructor and
+    state_dict schema but cannot run on the gfx950 kernels: the first forward raises a clear error instead of computing
+    something else.  (Same check on a small stand-in with the same patch size / head_dim, to keep the test light.)"""
+    from functools import partial
+    import torch.nn as nn
+    from countr_amd import _lib
+    from countr_amd.models_mae_cross import SupervisedMAE
+    m = SupervisedMAE(patch_size=14, embed_dim=160, depth=1, num_heads=2, decoder_embed_dim=512, decoder_depth=1,
+                      decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6)).to("cuda")
+    with pytest.raises(_lib.CountrError, match="not supported by the gfx950 kernels.*patch size 14.*head_dim 80"):
+        m(torch.rand(1, 3, 384, 384, device="cuda"), torch.rand(1, 3, 3, 64, 64, device="cuda"), 3)
+
+
+def test_backward_after_overwriting_forward_is_refused():
+    """The engine keeps one set of activation buffers per (batch, shot_num): backward() of a forward that a later train-mode
+    forward of the same shape has overwritten must raise, not return gradients of the wrong activations."""
+    from functools import partial
+    import torch.nn as nn
+    from countr_amd.models_mae_cross import SupervisedMAE
+    p, D, depth, H, Dd, ddepth, Hd = W.CONFIGS["tiny_test"]
+    m = SupervisedMAE(patch_size=p, embed_dim=D, depth=depth, num_heads=H, decoder_embed_dim=Dd, decoder_depth=ddepth,
+                      decoder_num_heads=Hd, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), precision="fp32").to("cuda").train()
+    imgs, boxes, gt, mask = (torch.from_numpy(a).cuda() for a in W.make_inputs(batch=1, shots=3, seed=3))
+    out1 = m(imgs, boxes, 3)
+    out2 = m(imgs * 0.5, boxes, 3)
+    out2.sum().backward()                      # the latest forward: fine
+    with pytest.raises(RuntimeError, match="overwritten by a later train-mode forward"):
+        out1.sum().backward()
+    out3 = m(imgs, boxes, 3)                   # a forward of another shot_num in between does not disturb it
+    m(imgs, boxes, 0)
+    out3.sum().backward()

@@ -24,46 +24,116 @@ def make(precision):
     return m.to("cuda"), sd
 
 
+class TorchAdamW:
+    """The reference's optimizer on CPU in fp64: torch.optim.AdamW(betas=(0.9, 0.95)) over timm's two add_weight_decay groups
+    (FSC_finetune_cross.py:234-235) with the zero_grad() of its pinned torch 1.13.1 (set_to_none=False: a parameter that had a
+    gradient once keeps a ZERO gradient and is stepped in every later iteration; one that never had any is skipped)."""
+
+    def __init__(self, sd, lr, eps, wd=0.05):
+        from countr_amd.engine import is_trainable, no_weight_decay
+        self.p = {k: torch.nn.Parameter(torch.from_numpy(v).double()) for k, v in sd.items() if is_trainable(k)}
+        decay = [v for k, v in self.p.items() if not no_weight_decay(k, v.shape)]
+        no_decay = [v for k, v in self.p.items() if no_weight_decay(k, v.shape)]
+        self.opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": wd}], lr=lr,
+                                     betas=(0.9, 0.95), eps=eps)
+
+    def state_dict_f32(self, sd):
+        cur = {k: v.copy() for k, v in sd.items()}
+        for k, v in self.p.items():
+            cur[k] = v.detach().float().numpy()
+        return cur
+
+    def accumulate(self, grads, scale=1.0):
+        for k, g in grads.items():
+            if g is None:
+                continue
+            g = g.double() * scale
+            self.p[k].grad = g if self.p[k].grad is None else self.p[k].grad + g
+
+    def grad_norm(self):
+        return torch.sqrt(sum((v.grad.double() ** 2).sum() for v in self.p.values() if v.grad is not None))
+
+    def step(self):
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=False)
+
+
+def check_params(m, ref, lr, it, tag):
+    for k, p in m.named_parameters():
+        if k not in ref.p:
+            continue
+        # AdamW normalises the step to ~lr per element, so compare in units of lr: rms error everywhere, max error
+        # outside the exemplar CNN (one fp32 ReLU-boundary flip, |xhat| ~ 1e-7, moves single elements there by
+        # a fraction of lr: tools/diag_exemplar.py).  A wrong or missing step (or a wrong bias correction: the first
+        # update of a late-starting parameter is 1 lr per element) would be >= 0.3 lr off.
+        d = (p.detach().cpu().double() - ref.p[k].detach()).abs()
+        assert d.pow(2).mean().sqrt().item() <= 0.03 * lr * (it + 1), (tag, it, k, d.pow(2).mean().sqrt().item())
+        if not k.startswith("decoder_proj"):
+            assert d.max().item() <= 0.25 * lr * (it + 1), (tag, it, k, d.max().item())
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_finetune_steps_match_oracle(use_graph):
+def test_finetune_steps_match_torch_adamw(use_graph):
+    """FinetuneStep (loss, gradients, optimizer) against the oracle's loss / gradients fed to the REAL torch.optim.AdamW over the
+    shot schedule [3, 0, 3, 0, 1]: shot_token takes its first step at iteration 2 (own bias correction: that update is a full
+    lr per element), the exemplar CNN is stepped with a zero gradient when shot_num == 0, shot_token likewise afterwards."""
     from countr_amd.trainer import FinetuneStep
-    from countr_amd.engine import no_weight_decay
     m, sd = make("fp32")
+    lr = 1e-3
     # eps=1e-4 keeps AdamW's g/(|g|+eps) well conditioned for the (near-)zero gradients; with 1e-8 their sign is noise
-    step = FinetuneStep(m, batch=2, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph)
-    ref = {k: torch.from_numpy(v).double() for k, v in sd.items()}
-    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
-    t = 0
-    # shot schedule exercises both parameter subsets twice (second use of each replays the captured graphs)
-    for it, S in enumerate([3, 0, 3, 0]):
+    step = FinetuneStep(m, batch=2, lr=lr, weight_decay=0.05, eps=1e-4, use_graph=use_graph)
+    ref = TorchAdamW(sd, lr, 1e-4)
+    tok0 = torch.from_numpy(sd["shot_token"]).double()
+    for it, S in enumerate([3, 0, 3, 0, 1]):
         imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=10 + it)
         step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
         sums = step.step(S).clone()
+        gn = step.grad_norm().item()
         torch.cuda.synchronize()
-        cur = {k: v.float().numpy() for k, v in ref.items()}
-        out, rloss, rg = R.loss_and_grads(cur, imgs, boxes, gt, mask, S, NAME)
+        out, rloss, rg = R.loss_and_grads(ref.state_dict_f32(sd), imgs, boxes, gt, mask, S, NAME)
         assert abs(sums[0].item() - rloss.item()) <= 2e-3 * abs(rloss.item()), (it, S)
         assert np.abs(sums[1:3].cpu().numpy() - R.counts(out).numpy()).max() < 0.5
-        t += 1
-        for k, g in rg.items():
-            if g is None:
-                continue  # AdamW skips parameters without a gradient (exemplar CNN at S=0, shot_token at S>0)
-            wd = 0.0 if no_weight_decay(k, ref[k].shape) else 0.05
-            ref[k], m1, m2 = R.adamw_step(ref[k], g.double(), mom[k][0], mom[k][1], t, 1e-3, eps=1e-4, wd=wd)
-            mom[k] = (m1, m2)
-        for k, p in m.named_parameters():
-            got = p.detach().cpu().double()
-            # AdamW normalises the step to ~lr per element, so compare in units of lr: rms error everywhere, max error
-            # outside the exemplar CNN (one fp32 ReLU-boundary flip, |xhat| ~ 1e-7, moves single elements there by
-            # a fraction of lr: tools/diag_exemplar.py).  A wrong or missing step would be >= 1 lr off.
-            d = (got - ref[k]).abs()
-            assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (it + 1), (it, S, k)
-            if not k.startswith("decoder_proj"):
-                assert d.max().item() <= 0.25 * 1e-3 * (it + 1), (it, S, k, d.max().item())
+        ref.accumulate(rg)
+        assert abs(gn - ref.grad_norm().item()) <= 2e-3 * ref.grad_norm().item(), (it, gn, ref.grad_norm().item())
+        ref.step()
+        check_params(m, ref, lr, it, "steps")
+        tok = dict(m.named_parameters())["shot_token"].detach().cpu().double()
+        if it == 0:
+            assert torch.equal(tok, tok0)                       # no gradient yet: skipped
+        if it == 1:                                             # first step of shot_token: |update| = lr * g/(|g| + eps) ~ lr
+            assert 0.5 * lr < (tok - tok0).abs().median().item() <= 1.01 * lr
+    assert step.eng.group_steps == [5, 5, 4] and step.eng.opt_seen == {2, 3}
     # frozen encoder untouched
     for k, p in m.named_parameters():
         if not k.startswith(("decoder", "decode_head", "shot_token")):
             assert torch.equal(p.detach().cpu(), torch.from_numpy(sd[k])), k
+
+
+def test_optimizer_state_roundtrip():
+    """optimizer_state() -> load_optimizer_state() on a fresh step continues bit-identically (moments, global and per-group
+    step counters, the set of conditional buckets that already had a gradient); foreign dicts are refused."""
+    from countr_amd.trainer import FinetuneStep
+    res = []
+    for resume in (False, True):
+        m, sd = make("fp32")
+        step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=False)
+        for it, S in enumerate([0, 0, 3, 0]):
+            if resume and it == 2:
+                state = step.optimizer_state()
+                weights = {k: v.detach().clone() for k, v in m.state_dict().items()}
+                m, _ = make("fp32")
+                m.load_state_dict(weights)
+                step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=False)
+                assert not step.load_optimizer_state({"state": {}, "param_groups": []})
+                assert step.load_optimizer_state(state)
+                assert step.eng.group_steps == [2, 0, 2] and step.eng.opt_seen == {3}
+            imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=70 + it)
+            step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+            step.step(S)
+        torch.cuda.synchronize()
+        res.append({k: p.detach().cpu().clone() for k, p in m.named_parameters()})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
 
 
 def test_bf16_step_runs_and_reduces_loss():
@@ -118,20 +188,19 @@ def test_host_batches_are_staged_and_match_device_batches():
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_gradient_accumulation_matches_oracle(use_graph):
+def test_gradient_accumulation_matches_torch_adamw(use_graph):
     """--accum_iter 2 (FSC_finetune_cross.py:300-305: loss / accum_iter, optimizer step every accum_iter-th iteration): the
     accumulated gradient is the mean over the window's micro-batches; shot_num changes inside a window, so a conditional
-    parameter set (exemplar CNN / shot_token) steps iff some micro-step of the window gave it a gradient."""
+    parameter set (exemplar CNN / shot_token) gets a gradient iff some micro-step of the window gave it one -- and, once it had
+    one, is stepped with zeros otherwise (window 2 below: the exemplar CNN)."""
     from countr_amd.trainer import FinetuneStep
-    from countr_amd.engine import no_weight_decay
     m, sd = make("fp32")
-    step = FinetuneStep(m, batch=2, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph, accum_iter=2)
-    ref = {k: torch.from_numpy(v).double() for k, v in sd.items()}
-    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    lr = 1e-3
+    step = FinetuneStep(m, batch=2, lr=lr, weight_decay=0.05, eps=1e-4, use_graph=use_graph, accum_iter=2)
+    ref = TorchAdamW(sd, lr, 1e-4)
     seed = 50
     for w, shots in enumerate([(3, 0), (0, 0), (2, 3)]):
-        cur = {k: v.float().numpy() for k, v in ref.items()}
-        acc = {}
+        cur = ref.state_dict_f32(sd)
         for j, S in enumerate(shots):
             imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=seed)
             seed += 1
@@ -140,17 +209,8 @@ def test_gradient_accumulation_matches_oracle(use_graph):
             assert step.applied == (j == 1)
             _, rloss, rg = R.loss_and_grads(cur, imgs, boxes, gt, mask, S, NAME)
             assert abs(sums[0].item() - rloss.item()) <= 2e-3 * abs(rloss.item()), (w, j)   # the logged loss is not divided
-            for k, g in rg.items():
-                if g is not None:
-                    acc[k] = acc.get(k, 0) + g.double() / 2
+            ref.accumulate(rg, 0.5)
         torch.cuda.synchronize()
-        for k, g in acc.items():
-            wd = 0.0 if no_weight_decay(k, ref[k].shape) else 0.05
-            # the fused AdamW keeps ONE step counter (bias correction) for the whole flat buffer
-            ref[k], m1, m2 = R.adamw_step(ref[k], g, mom[k][0], mom[k][1], w + 1, 1e-3, eps=1e-4, wd=wd)
-            mom[k] = (m1, m2)
-        for k, p in m.named_parameters():
-            d = (p.detach().cpu().double() - ref[k]).abs()
-            assert d.pow(2).mean().sqrt().item() <= 0.03 * 1e-3 * (w + 1), (w, k)
-            if not k.startswith("decoder_proj"):
-                assert d.max().item() <= 0.25 * 1e-3 * (w + 1), (w, k, d.max().item())
+        ref.step()
+        check_params(m, ref, lr, w, "accum")
+    assert step.eng.group_steps == [3, 3, 3]
