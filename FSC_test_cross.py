@@ -47,6 +47,7 @@ def get_args_parser():
     # additions
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="the reference tests in fp32")
     p.add_argument("--synthetic", default=0, type=int, help="evaluate N synthetic images instead of FSC147")
+    p.add_argument("--group_images", default=8, type=int, help="images whose sliding windows share forward batches (up to 32 windows each)")
     return p
 
 
@@ -99,16 +100,18 @@ def main(args):
     from countr_amd.parallel import shard_batch
     lo, hi = shard_batch(len(items), misc.get_rank(), misc.get_world_size())   # replicas only: images sharded, no collective
     mae = rmse = nae = 0.0
-    t_inf = 0.0
-    for name, img, boxes, pos, gt_cnt in items[lo:hi]:
-        samples = img.unsqueeze(0).to(device)
-        bx = boxes.unsqueeze(0).to(device)
-        num_boxes = bx.shape[1] if bx.nelement() > 0 else 0
-        t0 = time.time()
-        pred, _ = inference.count_image(model, samples, bx, num_boxes, pos=pos, normalization=bool(args.normalization),
-                                        max_s_cnt=args.max_s_cnt)
-        torch.cuda.synchronize()
-        t_inf += time.time() - t0
+    # windows are batched ACROSS images (every 384-px window is an independent forward): groups of --group_images images go
+    # through inference.count_images together
+    mine = items[lo:hi]
+    t0 = time.time()
+    preds = []
+    for g0 in range(0, len(mine), args.group_images):
+        grp = mine[g0:g0 + args.group_images]
+        its = [(img.unsqueeze(0).to(device), boxes.unsqueeze(0).to(device), pos) for _name, img, boxes, pos, _gt in grp]
+        preds += [p for p, _dm in inference.count_images(model, its, normalization=bool(args.normalization), max_s_cnt=args.max_s_cnt)]
+    torch.cuda.synchronize()
+    t_inf = time.time() - t0
+    for (name, _img, _boxes, _pos, gt_cnt), pred in zip(mine, preds):
         err = abs(pred - gt_cnt)
         mae += err; rmse += err ** 2; nae += err / gt_cnt if gt_cnt > 0 else 0
         print("%s: pred_cnt: %5.3f, gt_cnt: %5.3f, error: %5.3f" % (name, pred, gt_cnt, err))

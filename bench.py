@@ -155,6 +155,54 @@ def bench_pretrain(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def bench_infer(args, world, rank, dev):
+    """BASELINE.json configs[4]: zero-shot sliding-window inference (demo_zero.py:41-74) on 1920x1080 frames -- resized to
+    384 x 672 they give 4 windows each, so 8 frames = one forward batch of 32 windows (shot_num = 0, shot_token path), then the
+    per-column blend.  Replicas only: every rank counts its own frames, no collective.  Selected with --workload infer."""
+    import models_mae_cross
+    from countr_amd import inference
+    from countr_amd.synthetic import wide_frames
+    torch.manual_seed(0)
+    model = models_mae_cross.__dict__["mae_vit_base_patch16"](norm_pix_loss=False, precision=args.precision)
+    model.to(dev).eval()
+    frames = wide_frames(8, 672, dev, seed=rank)
+    empty = [torch.zeros(1, 0, device=dev)] * len(frames)
+
+    def one():
+        dms = inference.density_maps(model, frames, empty, 0, max_batch=32)
+        return torch.stack([d.sum() for d in dms]) / 60
+    for _ in range(max(args.warmup, 2)):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cnt = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        ips = world * len(frames) * args.steps / dt
+        print(json.dumps({
+            "metric": "frames/sec (1920x1080 -> 384x672, zero-shot sliding window, 4 windows per frame)", "value": ips, "unit": "frames/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "zero-shot inference ViT-B/16 (mae_vit_base_patch16), 8 frames x 4 windows = batch 32 per GPU, "
+                                   "forward + sliding-window blend + counts", "global_batch": world * 32, "parallelism": "replicas%d" % world},
+            "windows_per_sec": 4 * ips, "mean_count": float(cnt.mean().item()), "fwd_tflops": 180.89e9 * 4 * ips / 1e12}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,8 +212,9 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="finetune", choices=["finetune", "pretrain"],
-                    help="finetune = BASELINE.json metric (default); pretrain = MAE pretraining step (SURVEY 8f rank 3, config 4)")
+    ap.add_argument("--workload", default="finetune", choices=["finetune", "pretrain", "infer"],
+                    help="finetune = BASELINE.json metric (default); pretrain = MAE pretraining step (SURVEY 8f rank 3, config 4); "
+                         "infer = zero-shot sliding-window inference, batch 32 windows (config 5)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
     args = ap.parse_args()
 
@@ -195,6 +244,8 @@ def main():
 
     if args.workload == "pretrain":
         return bench_pretrain(args, world, rank, dev)
+    if args.workload == "infer":
+        return bench_infer(args, world, rank, dev)
     import models_mae_cross
     from countr_amd.trainer import FinetuneStep
     from countr_amd.synthetic import make_batch

@@ -37,43 +37,118 @@ def blend_windows(outputs, starts, width, height=384):
     return dm
 
 
+def _bucket(n, max_batch):
+    """Forward batch sizes come from {1, 2, 4, ..., max_batch}: the engine keeps one static plan (buffers + launch lists) per
+    batch size, so arbitrary window counts would build arbitrarily many plans.  A chunk is padded up to its bucket."""
+    b = 1
+    while b < n and b < max_batch:
+        b *= 2
+    return min(b, max_batch)
+
+
+@torch.no_grad()
+def density_maps(model, images, boxes, shot_num, max_batch=32):
+    """Stitched densities of SEVERAL images in as few forwards as possible: images = [[1, 3, 384, w_i], ...], boxes = per image
+    [1, >= shot_num, 3, 64, 64] (anything when shot_num == 0) -> [[384, w_i], ...].  Every 384-px window of every image is an
+    independent forward of the reference (FSC_test_cross(few-shot).py:326-349, demo_zero.py:49-72), so the windows of all images
+    are concatenated and run in chunks of up to max_batch (zero-shot 1920x1080 frames: 8 images x 4 windows = one batch of 32)."""
+    shot_num = int(shot_num)
+    dev = images[0].device
+    plan = [(i, s) for i, im in enumerate(images) for s in window_starts(im.shape[-1])]
+    outs = []
+    for c0 in range(0, len(plan), max_batch):
+        chunk = plan[c0:c0 + max_batch]
+        nb = _bucket(len(chunk), max_batch)
+        wins = torch.zeros(nb, 3, images[0].shape[-2], 384, device=dev, dtype=torch.float32)
+        for j, (i, s) in enumerate(chunk):
+            wins[j] = images[i][0, :, :, s:s + 384]
+        if shot_num > 0:
+            bx = torch.zeros(nb, shot_num, 3, 64, 64, device=dev, dtype=torch.float32)
+            for j, (i, _s) in enumerate(chunk):
+                bx[j] = boxes[i][0, :shot_num]
+        else:
+            bx = torch.zeros(nb, 0, device=dev)
+        outs.append(model(wins, bx, shot_num)[:len(chunk)].clone())
+    outs = torch.cat(outs, 0) if outs else None
+    res, k = [], 0
+    for i, im in enumerate(images):
+        h, w = im.shape[-2], im.shape[-1]
+        starts = window_starts(w)
+        if not starts:
+            res.append(torch.zeros(h, w, device=dev))       # narrower than a window: the reference's loop never runs
+            continue
+        res.append(blend_windows(outs[k:k + len(starts)], starts, w, h))
+        k += len(starts)
+    return res
+
+
 @torch.no_grad()
 def density_map(model, samples, boxes, shot_num, max_batch=32):
     """samples [1, 3, 384, w] -> stitched density [384, w]; all windows run as batched forwards."""
-    _, _, h, w = samples.shape
-    starts = window_starts(w)
-    if not starts:
-        return torch.zeros(h, w, device=samples.device)
-    wins = torch.cat([samples[:, :, :, s:s + 384] for s in starts], 0)
-    bx = boxes.expand(len(starts), *boxes.shape[1:]) if boxes.nelement() > 0 else boxes.new_zeros((len(starts), 0))
-    outs = []
-    for i in range(0, len(starts), max_batch):
-        outs.append(model(wins[i:i + max_batch].contiguous(), bx[i:i + max_batch].contiguous(), shot_num))
-    return blend_windows(torch.cat(outs, 0), starts, w, h)
+    return density_maps(model, [samples], [boxes], shot_num, max_batch)[0]
 
 
-@torch.no_grad()
-def count_image(model, samples, boxes, shot_num, pos=None, normalization=True, max_s_cnt=1):
-    """Full per-image test path: returns (pred_cnt, density_map).  pos: exemplar rectangles [(y1, x1, y2, x2), ...]."""
-    _, _, h, w = samples.shape
+def _small_exemplars(pos):
     s_cnt = 0
     for rect in (pos or [])[:3]:
         if rect[2] - rect[0] < 10 and rect[3] - rect[1] < 10:
             s_cnt += 1
-    if pos is not None and s_cnt >= max_s_cnt:
-        # 3x3 split: each crop is upscaled back to (h, w) and counted on its own (FSC_test_cross(few-shot).py:273-320)
-        pred, dm = 0.0, None
-        for (top, left) in ((0, 0), (h // 3, 0), (0, w // 3), (h // 3, w // 3), (h * 2 // 3, 0), (h * 2 // 3, w // 3),
-                            (0, w * 2 // 3), (h // 3, w * 2 // 3), (h * 2 // 3, w * 2 // 3)):
-            crop = samples[:, :, top:top + h // 3, left:left + w // 3]
-            crop = F.interpolate(crop, size=(h, w), mode="bilinear", align_corners=False)
-            dm = density_map(model, crop, boxes, shot_num)
-            pred += (dm.sum() / 60).item()
-    else:
-        dm = density_map(model, samples, boxes, shot_num)
-        pred = (dm.sum() / 60).item()
+    return s_cnt
+
+
+def _normalise(pred, dm, pos, normalization):
+    """Test-time normalisation (FSC_test_cross(few-shot).py:353-359): divide by the mean count inside the exemplar boxes if > 1.8."""
     if normalization and pos:
         e_cnt = sum((dm[r[0]:r[2] + 1, r[1]:r[3] + 1].sum() / 60).item() for r in pos) / 3
         if e_cnt > 1.8:
             pred /= e_cnt
-    return pred, dm
+    return pred
+
+
+@torch.no_grad()
+def count_image(model, samples, boxes, shot_num, pos=None, normalization=True, max_s_cnt=1, max_batch=32):
+    """Full per-image test path: returns (pred_cnt, density_map).  pos: exemplar rectangles [(y1, x1, y2, x2), ...]."""
+    _, _, h, w = samples.shape
+    if pos is not None and _small_exemplars(pos) >= max_s_cnt:
+        # 3x3 split: each crop is upscaled back to (h, w) and counted on its own (FSC_test_cross(few-shot).py:273-320); the nine
+        # upscaled crops are nine independent images for the stitcher, so all their windows share forwards
+        crops = []
+        for (top, left) in ((0, 0), (h // 3, 0), (0, w // 3), (h // 3, w // 3), (h * 2 // 3, 0), (h * 2 // 3, w // 3),
+                            (0, w * 2 // 3), (h // 3, w * 2 // 3), (h * 2 // 3, w * 2 // 3)):
+            crop = samples[:, :, top:top + h // 3, left:left + w // 3]
+            crops.append(F.interpolate(crop, size=(h, w), mode="bilinear", align_corners=False))
+        dms = density_maps(model, crops, [boxes] * 9, shot_num, max_batch)
+        pred = sum((d.sum() / 60).item() for d in dms)
+        dm = dms[-1]                                   # the reference normalises with the LAST crop's map (its variable is reused)
+    else:
+        dm = density_map(model, samples, boxes, shot_num, max_batch)
+        pred = (dm.sum() / 60).item()
+    return _normalise(pred, dm, pos, normalization), dm
+
+
+@torch.no_grad()
+def count_images(model, items, normalization=True, max_s_cnt=1, max_batch=32):
+    """Test path over MANY images with windows batched across images: items = [(samples [1,3,384,w], boxes [1,S,3,64,64] or
+    empty, pos or None), ...] -> [(pred_cnt, density_map), ...] in input order.  Images are grouped by shot count (one forward
+    has one shot_num, models_mae_cross.py:201); images that take the 3x3 split path already fill batches on their own."""
+    res = [None] * len(items)
+    groups = {}
+    for idx, (samples, boxes, pos) in enumerate(items):
+        S = boxes.shape[1] if boxes.nelement() > 0 else 0
+        if pos is not None and _small_exemplars(pos) >= max_s_cnt:
+            res[idx] = count_image(model, samples, boxes, S, pos, normalization, max_s_cnt, max_batch)
+        else:
+            groups.setdefault(S, []).append(idx)
+    for S, idxs in groups.items():
+        g0 = 0
+        while g0 < len(idxs):                           # as many images as fill one forward batch
+            g1, nwin = g0, 0
+            while g1 < len(idxs) and (g1 == g0 or nwin + len(window_starts(items[idxs[g1]][0].shape[-1])) <= max_batch):
+                nwin += len(window_starts(items[idxs[g1]][0].shape[-1]))
+                g1 += 1
+            sel = idxs[g0:g1]
+            dms = density_maps(model, [items[i][0] for i in sel], [items[i][1] for i in sel], S, max_batch)
+            for i, dm in zip(sel, dms):
+                res[i] = (_normalise((dm.sum() / 60).item(), dm, items[i][2], normalization), dm)
+            g0 = g1
+    return res

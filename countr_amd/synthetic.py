@@ -19,3 +19,10 @@ def make_batch(batch, shots=3, seed=0, img_size=384, device="cpu"):
     mask = rs.binomial(1, 0.8, size=(img_size, img_size)).astype(np.float32)
     t = lambda a: torch.from_numpy(a).to(device)
     return t(imgs), t(boxes), t(gt), t(mask)
+
+
+def wide_frames(n, width=672, device="cpu", seed=0, height=384):
+    """n test-time frames [1, 3, 384, width] ~ U[0,1): a 1920x1080 image resized as the reference's test loader does
+    (height 384, width 16 * int(1920 / 1080 * 384 / 16) = 672: FSC_test_cross(few-shot).py:150-153, demo_zero.py:28-31)."""
+    rs = np.random.RandomState(7000 + seed)
+    return [torch.from_numpy(rs.uniform(0, 1, size=(1, 3, height, width)).astype(np.float32)).to(device) for _ in range(n)]

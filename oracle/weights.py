@@ -155,6 +155,19 @@ def make_inputs(batch, shots=3, seed=0, img_size=384):
     return imgs, boxes, gt, mask
 
 
+def make_wide_inputs(seed, width, shots=3, height=384):
+    """Test-time inputs (FSC_test_cross(few-shot).py:134-190 shapes): one image [1, 3, 384, width] (height 384, width a multiple
+    of 16), `shots` exemplar crops [1, shots, 3, 64, 64] and their rectangles (y1, x1, y2, x2) inside the image."""
+    rs = np.random.RandomState(5000 + seed)
+    img = rs.uniform(0, 1, size=(1, 3, height, width)).astype(np.float32)
+    boxes = rs.uniform(0, 1, size=(1, shots, 3, 64, 64)).astype(np.float32)
+    pos = []
+    for _ in range(shots):
+        y1, x1 = int(rs.randint(0, height - 80)), int(rs.randint(0, width - 80))
+        pos.append((y1, x1, y1 + int(rs.randint(20, 70)), x1 + int(rs.randint(20, 70))))
+    return img, boxes, pos
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # MAE pretraining model (reference models_mae_noct.py:11-235): schema + deterministic weights
 # ---------------------------------------------------------------------------------------------------------------

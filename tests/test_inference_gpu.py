@@ -50,3 +50,94 @@ def test_stitched_density_matches_reference_golden():
     assert np.isfinite(pred)
     z = inference.density_map(m, torch.rand(1, 3, 384, 300).cuda(), bx, 3)
     assert z.shape == (384, 300) and float(z.abs().sum()) == 0.0
+
+
+@pytest.fixture(scope="module")
+def fp32_model():
+    import models_mae_cross
+    m = models_mae_cross.mae_vit_base_patch16(precision="fp32")
+    sd = W.make_state_dict("mae_vit_base_patch16", seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to("cuda").eval()
+
+
+@pytest.mark.gpu
+def test_zero_shot_stitch_matches_demo_zero_golden(fp32_model):
+    """demo_zero.py:41-74 run unchanged by tools/oracle/make_golden_infer.py on two 384 x 672 frames (1920x1080 resized: config 5)
+    with boxes = torch.Tensor([]) and shot_num = 0; here both frames go through ONE forward of 8 windows."""
+    from countr_amd import inference
+    g = np.load(os.path.join(G, "infer.npz"))
+    imgs = [torch.from_numpy(W.make_wide_inputs(100 + k, 672, 0)[0]).cuda() for k in range(2)]
+    empty = torch.zeros(1, 0, device="cuda")
+    dms = inference.density_maps(fp32_model, imgs, [empty, empty], 0)
+    for k, dm in enumerate(dms):
+        assert abs(dm.sum().item() / 60 - float(g["zero%d_count" % k])) < 0.5
+        for axis, key in ((0, "colsum"), (1, "rowsum")):
+            ref = g["zero%d_%s" % (k, key)]
+            assert np.abs(dm.sum(axis).cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), (k, key)
+
+
+@pytest.mark.gpu
+def test_count_image_paths_match_reference_golden(fp32_model):
+    """FSC_test_cross(few-shot).py:261-359 run unchanged by the generator: (a) plain windows + test-time normalisation, (b) two
+    exemplars below 10 px -> the 3x3 crop-and-upscale path (nine crops, counts summed, normalised with the last crop's map)."""
+    from countr_amd import inference
+    g = np.load(os.path.join(G, "infer.npz"))
+    img, bx, pos = W.make_wide_inputs(200, 512, 3)
+    pred, dm = inference.count_image(fp32_model, torch.from_numpy(img).cuda(), torch.from_numpy(bx).cuda(), 3, pos=pos)
+    assert int(g["plain_s_cnt"]) == 0 and [tuple(r) for r in g["plain_pos"]] == pos
+    assert abs(pred - float(g["plain_count"])) <= 2e-3 * float(g["plain_count"])
+    assert np.abs(dm.sum(0).cpu().numpy() - g["plain_colsum"]).max() <= 1e-3 * np.abs(g["plain_colsum"]).max()
+    img, bx, _ = W.make_wide_inputs(201, 400, 3)
+    pos = [tuple(int(v) for v in r) for r in g["split_pos"]]
+    assert int(g["split_s_cnt"]) == 2
+    pred, dm = inference.count_image(fp32_model, torch.from_numpy(img).cuda(), torch.from_numpy(bx).cuda(), 3, pos=pos)
+    assert abs(pred - float(g["split_count"])) <= 2e-3 * float(g["split_count"])
+    assert np.abs(dm.sum(0).cpu().numpy() - g["split_colsum"]).max() <= 1e-3 * np.abs(g["split_colsum"]).max()
+    # without normalisation the prediction is the plain sum of the nine crop counts
+    pred_raw, _ = inference.count_image(fp32_model, torch.from_numpy(img).cuda(), torch.from_numpy(bx).cuda(), 3, pos=pos, normalization=False)
+    assert abs(pred_raw - float(g["split_crop_counts"].sum())) <= 1e-3 * float(g["split_crop_counts"].sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_batch_of_32_windows(precision, fp32_model):
+    """BASELINE config 5: zero-shot, 8 frames of 1920x1080 (-> 384 x 672, 4 windows each) = ONE forward of 32 windows.  The batched
+    result equals the per-image path window for window, and mixed widths / shot counts keep their input order through
+    count_images."""
+    import models_mae_cross
+    from countr_amd import inference
+    if precision == "fp32":
+        m = fp32_model
+    else:
+        m = models_mae_cross.mae_vit_base_patch16(precision="bf16")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict("mae_vit_base_patch16", seed=0).items()})
+        m.to("cuda").eval()
+    imgs = [torch.from_numpy(W.make_wide_inputs(300 + k, 672, 0)[0]).cuda() for k in range(8)]
+    empty = torch.zeros(1, 0, device="cuda")
+    calls = []
+    orig = m.forward
+    m.forward = lambda a, b, c: (calls.append(a.shape[0]), orig(a, b, c))[1]
+    try:
+        dms = inference.density_maps(m, imgs, [empty] * 8, 0)
+        assert calls == [32]
+        single = [inference.density_map(m, im, empty, 0) for im in imgs]
+    finally:
+        m.forward = orig
+    for a, b in zip(dms, single):
+        if precision == "fp32":      # same kernels, other batch size (tile / split-K choices may differ): rounding-level agreement
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+        else:
+            assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+        assert torch.isfinite(a).all() and a.shape == (384, 672)
+    # count_images: mixed widths and shot counts, results in input order
+    items = []
+    for k, (w, S) in enumerate(((672, 0), (512, 3), (384, 0), (640, 3), (300, 3))):
+        img, bx, pos = W.make_wide_inputs(400 + k, w, max(S, 1))
+        items.append((torch.from_numpy(img).cuda(), torch.from_numpy(bx).cuda() if S else empty, pos if S else None))
+    res = inference.count_images(m, items)
+    for (samples, bx, pos), (pred, dm) in zip(items, res):
+        S = bx.shape[1] if bx.nelement() > 0 else 0
+        p1, d1 = inference.count_image(m, samples, bx, S, pos=pos)
+        assert dm.shape == d1.shape and abs(pred - p1) <= 1e-3 * max(abs(p1), 1.0)
+    assert float(res[4][1].abs().sum()) == 0.0      # 300 px wide: no window, all-zero map

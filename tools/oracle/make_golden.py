@@ -183,37 +183,28 @@ def main():
         meta["grad_tensors_" + tag] = sorted(k for k, p in model.named_parameters() if p.grad is not None)
     np.savez_compressed(os.path.join(OUT, "grads_b2.npz"), **gr)
 
-    # ---------------- sliding-window stitch (FSC_test_cross(few-shot).py:322-351) on synthetic wide images
+    # ---------------- sliding-window stitch (FSC_test_cross(few-shot).py:322-351) on synthetic wide images.  The loop is inline in
+    # the reference's main(), so it cannot be imported; it is not restated here either: the lines are read from /root/reference at
+    # run time and executed unchanged.  The window starts are recovered from the storage offset of each slice the loop feeds the model.
+    import textwrap
+    with open(os.path.join(REF, "FSC_test_cross(few-shot).py")) as f:
+        stitch_src = textwrap.dedent("".join(f.readlines()[321:351]))
     st = {}
     rs = np.random.RandomState(77)
     for width in (672, 512, 384):
         wide = rs.uniform(0, 1, size=(1, 3, 384, width)).astype(np.float32)
         bx = torch.from_numpy(boxes[:1])
         samples = torch.from_numpy(wide)
-        density_map = torch.zeros([384, width])
-        start, prev, starts = 0, -1, []
-        with torch.no_grad():
-            while start + 383 < width:
-                starts.append(start)
-                output, = model(samples[:, :, :, start:start + 384], bx, 3)
-                output = output.squeeze(0)
-                b1 = nn.ZeroPad2d(padding=(start, width - prev - 1, 0, 0))
-                d1 = b1(output[:, 0:prev - start + 1])
-                b2 = nn.ZeroPad2d(padding=(prev + 1, width - start - 384, 0, 0))
-                d2 = b2(output[:, prev - start + 1:384])
-                b3 = nn.ZeroPad2d(padding=(0, width - start, 0, 0))
-                density_map_l = b3(density_map[:, 0:start])
-                density_map_m = b1(density_map[:, start:prev + 1])
-                b4 = nn.ZeroPad2d(padding=(prev + 1, 0, 0, 0))
-                density_map_r = b4(density_map[:, prev + 1:width])
-                density_map = density_map_l + density_map_r + density_map_m / 2 + d1 / 2 + d2
-                prev = start + 383
-                start = start + 128
-                if start + 383 >= width:
-                    if start == width - 384 + 128:
-                        break
-                    else:
-                        start = width - 384
+        starts = []
+
+        class Rec(nn.Module):
+            def forward(self, x, b, n):
+                starts.append(x.storage_offset())
+                return model(x, b, n)
+        ns = {"torch": torch, "nn": nn, "model": Rec(), "device": torch.device("cpu"), "samples": samples, "boxes": bx, "num_boxes": 3,
+              "h": 384, "w": width}
+        exec(stitch_src, ns)
+        density_map = ns["density_map"]
         st["starts_%d" % width] = np.array(starts)
         st["count_%d" % width] = np.float64(density_map.sum().item() / 60)
         st["colsum_%d" % width] = density_map.sum(0).numpy()
