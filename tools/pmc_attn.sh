@@ -1,10 +1,12 @@
 #!/bin/bash
-# PMC passes for the attention forward (run on the GPU box).  Usage: bash tools/pmc_attn.sh <impl 1|2> <outfile>
-impl=$1; out=$2
+# PMC passes for the fused attention forward INSIDE the finetune step (run on the GPU box: bash tools/pmc_attn.sh <outdir>).
+# Separate passes per counter group (SQ: 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), --kernel-trace only.
+out=${1:-gpurun_out/pmc_attn}; mkdir -p $out
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rm -rf /tmp/pmcA /tmp/pmcB /tmp/pmcC
-COUNTR_ATTN_IMPL=$impl rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d /tmp/pmcA -o a -- python tools/bench_attn.py --one > /dev/null 2>&1
-COUNTR_ATTN_IMPL=$impl rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM -d /tmp/pmcB -o b -- python tools/bench_attn.py --one > /dev/null 2>&1
-COUNTR_ATTN_IMPL=$impl rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_INST_LEVEL_LDS SQ_LDS_UNALIGNED_STALL -d /tmp/pmcC -o c -- python tools/bench_attn.py --one > /dev/null 2>&1
-(for d in /tmp/pmcA /tmp/pmcB /tmp/pmcC; do f=$(find $d -name "*.db" | head -1); echo "## $d $f"; python tools/pmc_summary.py $f | grep -A12 -i "fa_fwd\|flash_attn_fwd"; done) > $out 2>&1
+run() { rm -rf /tmp/pmc_$1; rocprofv3 --kernel-trace --pmc $2 -d /tmp/pmc_$1 -o p -- python bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > /dev/null 2>&1; f=$(find /tmp/pmc_$1 -name "*.db" | head -1); echo "## pass $1: $2"; python tools/pmc_summary.py $f | grep -A12 "fa_fwd_pipe_kernelILi64"; }
+(run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+ run sq2 "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
+ run fetch "FETCH_SIZE"
+ run write "WRITE_SIZE") > $out/pmc.txt 2>&1
+cat $out/pmc.txt
