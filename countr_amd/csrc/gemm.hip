@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     // of a k-step are shared by its halves), so LDS round trips hide under the matrix pipe.
     constexpr int NH = TMW / 4, NS = 2 * NH;
     constexpr int XR = 4 * FragReads<MA>::N, WR = 4 * FragReads<MB>::N;   // LDS instructions per step for x / w fragments
-    auto mma_tile = [&](const char* sa_, const char* sb_) {
+    auto mma_tile = [&](const char* sa_, const char* sb_, auto mid) {   // mid(): called between the two halves of the tile's steps
       const uint32_t sa = lds_addr(sa_), sb = lds_addr(sb_);
       bf16x8_t xf[2][4], wf[2][4];
       auto request = [&](auto S) {
@@ -642,12 +642,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
       };
       request(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 0>{});
+      if constexpr (NS == 2) mid();
       step(std::integral_constant<int, 1>{});
       if constexpr (NS > 2) {
+        mid();
         step(std::integral_constant<int, 2>{});
         step(std::integral_constant<int, 3>{});
       }
     };
+    auto nomid = [] {};
     auto main_loop = [&](auto FAST) {
       constexpr bool fast = decltype(FAST)::value;
       auto issueA = [&](int k0, char* lds) {
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         issueB(ktile(t), smem + SA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma_tile(smem, smem + SA);
+        mma_tile(smem, smem + SA, nomid);
         __builtin_amdgcn_s_barrier();  // all fragment reads of this tile are consumed before it is overwritten
       }
     } else if constexpr (SPEC) {
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         int slot = 0;
         for (int t = 0; t < ntiles; ++t) {
           __builtin_amdgcn_s_barrier();
-          mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
+          mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA, nomid);
           slot = (slot + 1 == STAGES) ? 0 : slot + 1;
         }
       }
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           issueA(ktile(t + STAGES - 1), nxt);
           issueB(ktile(t + STAGES - 1), nxt + SA);
         }
-        mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
+        mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA, nomid);
         slot = (slot + 1 == STAGES) ? 0 : slot + 1;
         islot = (islot + 1 == STAGES) ? 0 : islot + 1;
       }
@@ -734,17 +737,49 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      // 8-wave workgroups (one per CU): waves w and w + 4 share a SIMD and run in lock step behind the per-tile barrier, so a
+      // DMA issue phase common to all waves leaves the matrix pipes of the whole CU idle.  The second wave group therefore issues
+      // its share of tile t+1 in the MIDDLE of tile t: while one wave of a SIMD spends its ~60 cycles per 1-KiB piece, the other
+      // one multiplies.
+#ifndef COUNTR_GEMM_STAGGER
+#define COUNTR_GEMM_STAGGER 1
+#endif
+      const bool late_group = COUNTR_GEMM_STAGGER && (NW == 8) && wv >= 4;
+#ifdef COUNTR_GEMM_STAMP   // s_memtime anatomy (tools/stamp_gemm.py): per-wave cycles in DMA issue / MFMA steps / load wait / barrier
+      uint64_t tki = 0, tkm = 0, tkw = 0, tkb = 0;
+      const uint64_t tk0 = __builtin_readcyclecounter();
+#define STAMP(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define STAMP(x)
+#endif
       for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntiles && (COUNTR_ABL != 3)) {
-          char* nxt = smem + (cur ^ 1) * (SA + SB);
-          issueA(ktile(t + 1), nxt);
-          issueB(ktile(t + 1), nxt + SA);
-        }
-        mma_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA);
+        char* nxt = smem + (cur ^ 1) * (SA + SB);
+        const bool more = t + 1 < ntiles && (COUNTR_ABL != 3);
+        auto issue_next = [&] {
+          if (more) {
+            issueA(ktile(t + 1), nxt);
+            issueB(ktile(t + 1), nxt + SA);
+          }
+        };
+        STAMP(ta);
+        if (!late_group) issue_next();        // (one copy of the MFMA code: the branches wrap the DMA issue only)
+        STAMP(tb);
+        mma_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA, [&] { if (late_group) issue_next(); });
+        STAMP(tc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(td);
         __builtin_amdgcn_s_barrier();
+#ifdef COUNTR_GEMM_STAMP
+        { STAMP(te); tki += tb - ta; tkm += tc - tb; tkw += td - tc; tkb += te - td; }
+#endif
       }
+#ifdef COUNTR_GEMM_STAMP
+      if (g.nbatch == 1 && g.sC1 && lane == 0) {   // (stamp builds only: the unused batch stride carries the debug buffer address)
+        float* d = reinterpret_cast<float*>(g.sC1) + ((int64_t)blockIdx.x * NW + wv) * 8;
+        d[0] = (float)(__builtin_readcyclecounter() - tk0); d[1] = (float)tki; d[2] = (float)tkm; d[3] = (float)tkw; d[4] = (float)tkb; d[5] = (float)ntiles;
+      }
+#endif
     }
     };
     if (fast_addr) main_loop(std::true_type{}); else main_loop(std::false_type{});
@@ -1013,6 +1048,9 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
       static const int big = [] { const char* e = getenv("COUNTR_GEMM_BIGTILE"); return e ? atoi(e) : 4096; }();
       if (!tile) tile = (t128 >= big && a.N >= 256) ? 124 : 22;
       if (tile == 124) return launch_variant<T, MA, MB, 3, 2, 4, 4, 4>(a, s);   // 128x256, 8 compute + 4 loader waves, 3-stage ring
+#ifdef COUNTR_GEMM_EXP   // experiments (tools/exp_gemm256.sh): 256x256 tile, 8 waves of 128x64, two LDS stages
+      if (tile == 88) return launch_variant<T, MA, MB, 2, 2, 4, 8, 0>(a, s);
+#endif
     }
     // tuning aids (the other variants this round measured -- 1/3/4 LDS stages, 64x128 / 256x128 / 256x256 tiles, a 4-stage and a
     // 2-workgroup specialised ring -- lost everywhere and were removed to keep the build short; DESIGN.md section 7 has the numbers)

@@ -1,0 +1,23 @@
+"""s_memtime anatomy of the 2-stage GEMM loop (library built with -DCOUNTR_GEMM_STAMP -DCOUNTR_GEMM_EXP): mean cycles per k-tile
+and wave spent in DMA issue / fragment reads + MFMAs / waiting for the next tile's loads / the barrier."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from countr_amd import _lib
+L = _lib.lib(); _lib.check(L.countr_init(0))
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def mk(*shape): return (torch.rand(shape, device="cuda") - 0.5).to(torch.bfloat16)
+M = 4608
+for name, N, K in (("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)):
+    A_, B_ = mk(M, K), mk(N, K); Cc = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    a = _lib.GemmArgs(); a.alpha = 1.0; a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    a.A, a.B, a.C = A_.data_ptr(), B_.data_ptr(), Cc.data_ptr(); a.lda = a.ldb = K; a.ldc = N; a.M, a.N, a.K = M, N, K; a.out_bf16 = 1
+    dbg = torch.zeros(4096 * 8 * 8, device="cuda")
+    a.sC1 = dbg.data_ptr()
+    for _ in range(5): _lib.check(L.countr_gemm(C.byref(a), 1, 0, 0, st()))
+    torch.cuda.synchronize()
+    d = dbg.view(-1, 8).cpu(); d = d[d[:, 0] > 0]
+    nt = d[:, 5].mean().item()
+    print("%s: %d waves, k-tiles %.0f; mean cycles per wave: loop total %.0f | per k-tile: dma issue %.0f  frags+mfma %.0f  load wait %.0f  barrier %.0f"
+          % (name, d.shape[0], nt, d[:, 0].mean(), d[:, 1].mean() / nt, d[:, 2].mean() / nt, d[:, 3].mean() / nt, d[:, 4].mean() / nt))
+    w = d.view(-1, 8, 8) if d.shape[0] % 8 == 0 else None
