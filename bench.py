@@ -76,7 +76,7 @@ def attention_roofline(model, batch, iters=20, instep_passes=6):
     samples.sort(); empty.sort()
     us = samples[len(samples) // 2]
     one = []
-    eng._attention_fwd(one, p, p.buf["qkv"], p.buf["att"], batch, eng.H, eng.D)
+    eng._attention_fwd(one, p, p.buf["qkv"], p.buf["att"], batch, eng.H, eng.D, prescaled=eng.prescale_q)
     for _ in range(3):
         eng.run(one)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

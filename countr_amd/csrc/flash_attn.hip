@@ -314,7 +314,7 @@ extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // COUNTR_ATTN_IMPL=1 selects the first-generation (non-pipelined) kernel below: kept for A/B timing (tools/bench_attn.py)
   static const int impl = [] { const char* e = getenv("COUNTR_ATTN_IMPL"); return e ? atoi(e) : 2; }();
-  if (impl != 1) return countr_attn_fwd_pipelined(qkv, out, lse, B, N, H, dh, scale, s);
+  if (impl != 1 || scale <= 0.f) return countr_attn_fwd_pipelined(qkv, out, lse, B, N, H, dh, scale, s);
   // keys per staged K/V tile: 128 halves the barriers / exposed waits per key (COUNTR_ATTN_BKV overrides)
   static const int force_bkv = [] { const char* e = getenv("COUNTR_ATTN_BKV"); return e ? atoi(e) : 0; }();
   const int bkv = force_bkv ? force_bkv : 64;

@@ -98,7 +98,10 @@ template <int PENDING> __device__ __forceinline__ void fa_vm_wait() { asm volati
 // ABL (timing experiments only, selected by COUNTR_FA_ABL; 1-6 give wrong results): 1 = K/V staged in the prologue only (no loads,
 // LDS stores or barriers in the steps), 2 = 1 + no v_exp, 3 = 1 + no MFMA, 4 = staging and barriers only, 5 = empty kernel,
 // 6 = one tile only (prologue + epilogue), 7 = correct output + s_memtime stamps of wave 0 written to lse (tools/stamp_attn.py)
-template <int DH, bool RAGGED, int ABL = 0>
+// PRE: q already carries scale * log2(e) (the frozen encoder's q projection is pre-scaled at weight-packing time, engine.py): the
+// scores come out of the MFMA in the exp2 domain, and because the QK^T accumulators start at -m_ref instead of 0 the softmax
+// needs no subtract / scale FMA at all (one VALU instruction per score less: 32 of ~135 per tile and wave).
+template <int DH, bool RAGGED, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                              float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
   constexpr bool DMA = DH == 64;
@@ -232,6 +235,9 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float mref = 0.f, l0 = 0.f, l1 = 0.f;
+  f32x16_t negm;     // PRE: -m_ref in every accumulator slot (all 16 scores of a lane belong to one query row)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
   auto mask_tail = [&](f32x16_t (&S)[2], int tile) {   // keys >= N of the ragged last tile do not exist
 #pragma unroll
@@ -240,19 +246,28 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
       for (int r = 0; r < 16; ++r)
         if (tile * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) S[blk][r] = -INFINITY;
   };
-  // deferred rescale; every PV MFMA of the pending tile has been issued and l already contains its row sums
-  auto rescale_for = [&](float mx) {
-    const float mloc = mx * c;
-    if (!__all(mloc - mref <= 8.0f)) {
-      const float mnew = fmaxf(mref, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(mref - mnew);
-      mref = mnew;
+  // deferred rescale; every PV MFMA of the pending tile has been issued and l already contains its row sums.
+  // mx: row max of the NEXT tile's scores Sn -- raw (scale c applies) or, PRE, already relative to m_ref in the exp2 domain.
+  auto rescale_for = [&](float mx, f32x16_t (&Sn)[2]) {
+    const float excess = PRE ? mx : mx * c - mref;     // how far the next tile's max lies above the reference max
+    if (!__all(excess <= 8.0f)) {
+      const float delta = fmaxf(excess, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      mref += delta;
       l0 *= alpha;
       l1 *= alpha;
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+      if (PRE) {   // the next tile's scores were accumulated against the old reference
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Sn[blk][i] -= delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = -mref;
+      }
     }
   };
 
@@ -260,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   uint32_t P[2][8];
   auto exp_unit = [&](const f32x16_t (&S)[2], int u) {
     const int blk = u >> 3, w = u & 7;
-    float p0 = __builtin_fmaf(S[blk][2 * w], c, -mref), p1 = __builtin_fmaf(S[blk][2 * w + 1], c, -mref);
+    float p0 = PRE ? S[blk][2 * w] : __builtin_fmaf(S[blk][2 * w], c, -mref);
+    float p1 = PRE ? S[blk][2 * w + 1] : __builtin_fmaf(S[blk][2 * w + 1], c, -mref);
     if (ABL != 2) { p0 = __builtin_amdgcn_exp2f(p0); p1 = __builtin_amdgcn_exp2f(p1); }
     l0 += p0;
     l1 += p1;
@@ -279,7 +295,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
     dma_tile(kp, 0, koff, Kslot(3));
     dma_stage(0);
     if (1 < T) dma_stage(1);
-    vm_wait_pending(stage_count(1));
+    // K(0) first: S(0) and its row max are computed while stages 0 and 1 are still landing
+    { const int pend = stage_count(0) + stage_count(1); if (pend >= 8) fa_vm_wait<8>(); else if (pend >= 6) fa_vm_wait<6>(); else if (pend >= 4) fa_vm_wait<4>(); else fa_vm_wait<2>(); }
     __builtin_amdgcn_s_barrier();
     K0 = Kslot(3);
   } else {
@@ -319,9 +336,22 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
     float mx = fmaxf(SA[0][0], SA[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = max3(mx, SA[0][r], SA[1][r]);
-    mref = xor32_max(mx) * c;
+    mref = xor32_max(mx) * (PRE ? 1.f : c);
+    if (PRE) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) SA[blk][i] -= mref;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = -mref;
+    }
   }
-  if (!DMA) __syncthreads();   // register path: the K area of slot 1 is rewritten at the end of step 0
+  if (DMA) {   // stage 0 = {K(1), V(0)} has landed for every wave (stage 1 stays in flight)
+    vm_wait_pending(stage_count(1));
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();   // register path: the K area of slot 1 is rewritten at the end of step 0
+  }
 
   // ================================================================ one pipelined step (tile t, t + 1 < T)
   // Sc = S(t) -> P, Sn = S(t+1) = K(t+1) Q^T, O += V(t)^T P^T, rescale decision for tile t + 1.  Reads stage t.
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
             f32x16_t z;
 #pragma unroll
             for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], z, 0, 0, 0);
+            Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], PRE ? negm : z, 0, 0, 0);
           } else {
             Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], Sn[blk], 0, 0, 0);
           }
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      rescale_for(xor32_max(mx));
+      rescale_for(xor32_max(mx), Sn);
     }
     if (ABL == 7) tb = __builtin_readcyclecounter();
     if (STAGING) {
@@ -423,8 +453,6 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   auto tail = [&](const int t, f32x16_t (&Sc)[2]) {
     if (active) {
       const int slot = DMA ? (t & 3) : (t & 1);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) exp_unit(Sc, u);
       if (DMA) {
         const uint32_t sb = fa_lds_addr(Kslot(slot));
         bf16x8_t f[4 * DB];
@@ -432,13 +460,24 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
           constexpr int e = E, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
           f[e] = fa_read_tr<(blk * 32 + s * 16) * 128>(sb + vbase[d]);
         });
-        fa_static_for<4 * DB>([&](auto E) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) exp_unit(Sc, u);
+        __builtin_amdgcn_sched_barrier(0);
+        fa_static_for<4 * DB>([&](auto E) {   // the PV MFMAs of key block 0 run under the exp work of key block 1
           constexpr int e = E, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
           fa_lds_wait<2 * (4 * DB - 1 - e)>(f[e]);
           __builtin_amdgcn_sched_barrier(0);
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], pfrag(blk, s), o[d], 0, 0, 0);
+          if constexpr (e < 2 * DB) {
+            constexpr int per = 8 / (2 * DB);
+#pragma unroll
+            for (int u = 8 + e * per; u < 8 + (e + 1) * per; ++u) exp_unit(Sc, u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         });
       } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) exp_unit(Sc, u);
         const char* V = Vslot(slot);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -511,6 +550,11 @@ int launch_fa_fwd_pipe(const void* qkv, void* out, float* lse, int B, int N, int
     switch (abl) { COUNTR_FA_ABL_CASE(1) COUNTR_FA_ABL_CASE(2) COUNTR_FA_ABL_CASE(3) COUNTR_FA_ABL_CASE(4) COUNTR_FA_ABL_CASE(5) COUNTR_FA_ABL_CASE(6) COUNTR_FA_ABL_CASE(7) default: break; }
 #undef COUNTR_FA_ABL_CASE
     COUNTR_LAUNCH_CHECK("countr_attn_fwd (ablation)");
+  }
+  if (c <= 0.f) {   // pre-scaled q (see PRE): built for the encoder shape class only
+    if (DH != 64 || N % 64) { countr_set_error("countr_attn_fwd: scale <= 0 (pre-scaled q) needs head_dim 64 and N % 64 == 0"); return -1; }
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, 0, true>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, 1.f);
+    COUNTR_LAUNCH_CHECK("countr_attn_fwd");
   }
   if (N % 64) {
     hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, true>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);

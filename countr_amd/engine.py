@@ -150,6 +150,8 @@ class Plan:
 
 
 class Engine:
+    FROZEN_ENCODER = True    # SupervisedMAE: the ViT encoder runs under no_grad (models_mae_cross.py:204-205) and is never updated
+
     def __init__(self, cfg, named_shapes, device, precision="bf16", img_size=384, attention="auto", ln_eps=1e-6):
         """cfg = (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads); ln_eps: eps of the model's norm_layer (the
         reference factories pass partial(nn.LayerNorm, eps=1e-6), models_mae_cross.py:210-239)."""
@@ -191,6 +193,10 @@ class Engine:
         self.group_steps = [0, 0, 0]    # optimizer steps taken by counter group 0 (always), 1 (exemplar CNN), 2 (shot_token)
         self.opt_seen = set()           # conditional gradient buckets (2, 3) that have had a gradient at least once
         self.gnorm = None               # device fp32 [countr_adamw_gnorm_floats()]: [0] = gradient L2 norm of the last step
+        # frozen-encoder q projection packed pre-scaled for the attention kernel (see _pack_prescaled_q); COUNTR_PRESCALE_Q=0 disables
+        self.prescale_q = (self.FROZEN_ENCODER and precision == "bf16" and attention != "unfused" and self.D // self.H == 64
+                           and self.N % 64 == 0 and os.environ.get("COUNTR_PRESCALE_Q", "1") != "0")
+        self.qkv_bias_pre = None
         self._ws = {}
         self._need = {}
         self._sizing = False
@@ -241,7 +247,24 @@ class Engine:
             lo = lay.train_start if trainable_only else 0
             _lib.check(L.countr_cast_permute(self.P.data_ptr() + 4 * lo, self.Wt.data_ptr() + 2 * lo, lay.total - lo, 0, 0, 0, 0,
                                              BF16, st), "cast")
+            if self.prescale_q and not trainable_only and stream is None:
+                self._pack_prescaled_q()
         self._refresh_conv_shadows()
+
+    def _pack_prescaled_q(self):
+        """Frozen encoder, bf16 mode: the q rows of every blocks.i.attn.qkv shadow (and a copy of its bias) carry the factor
+        dh^-0.5 * log2(e), rounded ONCE from the fp32 master -- q = x W_q^T + b_q is linear, so the attention kernel receives
+        scores in the exp2 domain (countr_attn_fwd with scale <= 0) and does no per-score scale / subtract.  Weight-packing
+        time only (load_state_dict / .to()), a few torch elementwise ops on the engine's stream."""
+        D, lay = self.D, self.layout
+        c = (D // self.H) ** -0.5 * 1.4426950408889634
+        if self.qkv_bias_pre is None:
+            self.qkv_bias_pre = torch.zeros((self.depth, 3 * D), device=self.device, dtype=torch.float32)
+        for i in range(self.depth):
+            ow, ob = lay.off["blocks.%d.attn.qkv.weight" % i], lay.off["blocks.%d.attn.qkv.bias" % i]
+            self.Wt[ow:ow + D * D].copy_((self.P[ow:ow + D * D] * c).to(torch.bfloat16))
+            self.qkv_bias_pre[i].copy_(self.P[ob:ob + 3 * D])
+            self.qkv_bias_pre[i, :D].mul_(c)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -393,11 +416,11 @@ class Engine:
             self._flush_list(key)
 
     # linear forward: out = act(x W^T + b) (+ resid)
-    def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True):
+    def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True, bias_ptr=None):
         out_bf16 = (out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
         self._gemm(ops, self.code, OP_ROW, OP_ROW, A=x.data_ptr(), B=self._wp(wname), C=out.data_ptr(),
                    C2=(pre.data_ptr() if pre is not None else None),
-                   bias=(self._pp(wname[:-6] + "bias") if bias else None),
+                   bias=(bias_ptr if bias_ptr is not None else (self._pp(wname[:-6] + "bias") if bias else None)),
                    resid=(resid if isinstance(resid, int) else (resid.data_ptr() if resid is not None else None)),
                    lda=K, ldb=K, ldc=N, ldres=N, M=M, N=N, K=K, res_mod=res_mod, act=act, out_bf16=int(out_bf16))
 
@@ -491,13 +514,14 @@ class Engine:
     def _fused_attention(self, dh):
         return self.code == BF16 and dh in (32, 64) and self.attention != "unfused"
 
-    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None, lse=None, N=None):
+    def _attention_fwd(self, ops, plan, qkv, out, B, heads, Dm, probs=None, lse=None, N=None, prescaled=False):
         N, dh = (self.N if N is None else N), Dm // heads
         scale = dh ** -0.5
         if self._fused_attention(dh) and probs is None:
             self._op(ops, self.L.countr_attn_fwd, qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None, B, N,
-                     heads, dh, scale)
+                     heads, dh, 0.0 if prescaled else scale)   # scale <= 0: q carries dh^-0.5 * log2(e) already
             return
+        assert not prescaled
         scores = self._shared("scores", B * heads * N * N)
         if probs is None:
             probs = self._shared("probs", B * heads * N * N, self.tdt)
@@ -619,8 +643,12 @@ class Engine:
         for i in range(self.depth):
             b = "blocks.%d" % i
             self._layernorm(ops, x, b + ".norm1", xn, rows, D)
-            self._linear(ops, xn, b + ".attn.qkv.weight", qkv, rows, 3 * D, D)
-            self._attention_fwd(ops, p, qkv, att, B, H, D)
+            pre_q = self.prescale_q
+            if pre_q and self.qkv_bias_pre is None:
+                self._pack_prescaled_q()
+            self._linear(ops, xn, b + ".attn.qkv.weight", qkv, rows, 3 * D, D,
+                         bias_ptr=self.qkv_bias_pre[i].data_ptr() if pre_q else None)
+            self._attention_fwd(ops, p, qkv, att, B, H, D, prescaled=pre_q)
             self._linear(ops, att, b + ".attn.proj.weight", x, rows, D, D, resid=x)
             self._layernorm(ops, x, b + ".norm2", xn, rows, D)
             self._linear(ops, xn, b + ".mlp.fc1.weight", hid, rows, 4 * D, D, act=ACT_GELU)

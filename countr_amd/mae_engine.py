@@ -48,6 +48,8 @@ class MaePlan(Plan):
 
 
 class MaeEngine(Engine):
+    FROZEN_ENCODER = False   # the whole model trains: no pre-scaled q packing (the backward reads the same qkv)
+
     def _make_layout(self, named_shapes):
         return ParamLayout(named_shapes, trainable=mae_trainable, bucket=mae_bucket_fn(self.depth))
 

@@ -140,7 +140,10 @@ int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* s
 
 /* -------- fused self-attention forward (Attention.forward, models_crossvit.py:82-94 == timm Attention):
  * out = softmax(q k^T * scale) v on a packed bf16 qkv [B, N, 3, H, dh] (dh = 32 or 64) -> bf16 [B, N, H*dh].
- * lse: optional fp32 [B, H, N] log-sum-exp of the scaled scores. */
+ * lse: optional fp32 [B, H, N] log-sum-exp of the scaled scores.
+ * scale <= 0 (dh = 64, N % 64 == 0 only): the caller has already multiplied q by dh^-0.5 * log2(e) -- e.g. by packing the
+ * frozen encoder's q projection rows and bias pre-scaled, as engine.py does -- so the scores leave the matrix core in the exp2
+ * domain and the kernel spends no VALU instruction on the scale / max subtraction. */
 int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream);
 
 /* Backward of countr_attn_fwd (autograd of models_crossvit.py:84-91), two fused passes, no P materialised, no atomics.

@@ -379,6 +379,32 @@ def test_flash_attention_fwd(hip, B, N, H, dh):
     assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-4
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 576, 12), (1, 64, 3), (1, 1088, 2)])
+def test_flash_attention_fwd_prescaled_q(hip, B, N, H):
+    """scale <= 0: q arrives multiplied by dh^-0.5 * log2(e) (rounded once to bf16, as the engine packs the frozen encoder's q
+    projection); the kernel works in the exp2 domain with accumulators started at -m_ref.  Reference in fp64 on the SAME bf16
+    inputs: softmax over 2^(q' k).  A spiked key forces the rescale branch (which must also shift the pending next-tile scores)."""
+    dh = 64
+    c = dh ** -0.5 * 1.4426950408889634
+    qkv = rnd((B, N, 3, H, dh), 52, 1.0)
+    qkv[0, N // 2, 1, 0] = 6.0
+    qkv[0, N - 3, 1, H - 1] = -5.0
+    qkv[:, :, 0] *= c
+    qkv = qkv.to(torch.bfloat16)
+    qd = qkv.cuda()
+    out = torch.full((B, N, H * dh), float("nan"), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty((B, H, N), device="cuda")
+    _lib.check(hip.countr_attn_fwd(P(qd), P(out), P(lse), B, N, H, dh, 0.0, st()))
+    q = qkv[:, :, 0].double().permute(0, 2, 1, 3); k = qkv[:, :, 1].double().permute(0, 2, 1, 3)
+    v = qkv[:, :, 2].double().permute(0, 2, 1, 3)
+    sc = (q @ k.transpose(-1, -2)) * 0.6931471805599453
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * dh)
+    assert relerr(out, ref) < 1.5e-2
+    assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-4
+    # unsupported shapes are refused, not silently computed with another scale
+    assert hip.countr_attn_fwd(P(qd), P(out), P(lse), B, N, H * 2, 32, 0.0, st()) != 0
+
+
 @pytest.mark.parametrize("B,N,H,dh", [(2, 576, 16, 32), (1, 576, 12, 64), (1, 200, 3, 32), (2, 64, 2, 64)])
 def test_flash_attention_bwd(hip, B, N, H, dh):
     """Fused attention backward (dq, dk, dv in one packed tensor) vs fp64 autograd of softmax(q k^T * scale) v."""
