@@ -71,6 +71,7 @@ def transform_train_noaug(image, rects, dots, rng=random):
     sh, sw = float(new_h) / H, float(new_w) / W
     img_t = to_tensor(image.resize((new_w, new_h), Image.BILINEAR))
     dens = dot_map(dots, new_h, new_w, sh, sw)
+    rng.random()     # the reference draws its mosaic coin before looking at do_aug (util/FSC147.py:127): same random stream
     start = rng.randint(0, new_w - MAX_HW)
     crop = img_t[:, 0:MAX_HW, start:start + MAX_HW]
     dens = ndimage.gaussian_filter(dens[0:MAX_HW, start:start + MAX_HW], sigma=(1, 1), order=0) * 60

@@ -168,6 +168,25 @@ def make_wide_inputs(seed, width, shots=3, height=384):
     return img, boxes, pos
 
 
+DATA_CASES = [(640, 384), (384, 600), (500, 400), (900, 384), (300, 250)]   # (W, H) of the synthetic dataset items
+
+
+def make_fsc_item(k, w, h):
+    """A synthetic FSC147 item (util/FSC147.py sample layout): RGB PIL image, three exemplar rectangles [y1, x1, y2, x2] in
+    original pixel coordinates and dot annotations [x, y] -- deterministic from k."""
+    from PIL import Image
+    rs = np.random.RandomState(9000 + k)
+    yy, xx = np.mgrid[0:h, 0:w]
+    arr = np.stack([(xx * 255 // w), (yy * 255 // h), ((xx * 3 + yy * 5) % 256)], -1).astype(np.int32)
+    arr = np.clip(arr + rs.randint(-20, 21, size=arr.shape), 0, 255).astype(np.uint8)
+    dots = np.stack([rs.uniform(2, w - 2, 25), rs.uniform(2, h - 2, 25)], 1)
+    rects = []
+    for _ in range(3):
+        x1, y1 = int(rs.uniform(0, w - 80)), int(rs.uniform(0, h - 80))
+        rects.append([y1, x1, y1 + int(rs.uniform(20, 70)), x1 + int(rs.uniform(20, 70))])
+    return Image.fromarray(arr), rects, dots
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # MAE pretraining model (reference models_mae_noct.py:11-235): schema + deterministic weights
 # ---------------------------------------------------------------------------------------------------------------

@@ -81,3 +81,25 @@ def test_pretrain_samples_and_collation(fake_fsc):
     dt = D.TrainData(fake_fsc, split="train", do_aug=False)
     imgs, dens, n, boxes, pos, m_flag, ids = next(iter(torch.utils.data.DataLoader(dt, batch_size=4)))
     assert imgs.shape == (4, 3, 384, 384) and dens.shape == (4, 384, 384) and boxes.shape == (4, 3, 3, 64, 64) and len(ids) == 4
+
+
+def test_transforms_match_reference_golden():
+    """The non-augmented train transform and the val transform against util/FSC147.py ITSELF: tools/oracle/make_golden_data.py
+    imports the reference module (torchvision / cv2 / imgaug replaced by thin stand-ins with their documented behaviour) and runs
+    ResizeTrainImage(do_aug=False) and ResizeValImage unchanged on the synthetic items of oracle/weights.make_fsc_item."""
+    from countr_amd.data import fsc147 as D
+    from oracle import weights as W
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "data.npz"))
+    for k, (w, h) in enumerate(W.DATA_CASES):
+        image, rects, dots = W.make_fsc_item(k, w, h)
+        assert tuple(g["train%d_flex" % k]) == D.flex_resize(h, w)
+        s = D.transform_train_noaug(image, rects, dots, rng=random.Random(100 + k))   # the generator seeds `random` the same way
+        v = D.transform_val(image, rects, dots)
+        for tag, got in (("train", s), ("val", v)):
+            img = got["image"]
+            assert img.shape == (3, 384, 384)
+            assert np.abs(img.numpy()[:, ::4, ::4] - g["%s%d_image" % (tag, k)]).max() <= 1e-6, (tag, k)
+            assert np.abs(img.double().sum(dim=(1, 2)).numpy() - g["%s%d_image_sum" % (tag, k)]).max() <= 1e-6 * 384 * 384
+            assert np.abs(got["gt_density"].numpy() - g["%s%d_density" % (tag, k)]).max() <= 1e-6, (tag, k)
+            assert np.abs(got["boxes"].numpy() - g["%s%d_boxes" % (tag, k)]).max() <= 1e-6, (tag, k)
+            assert np.array_equal(np.asarray(got["pos"]), g["%s%d_pos" % (tag, k)]), (tag, k)

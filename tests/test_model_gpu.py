@@ -143,18 +143,25 @@ def test_gradients_fp32_match_reference_golden(fp32_model, tag, shots):
         worst = max(worst, err / (np.abs(ref).max() + 1e-12))
 
 
-def test_bf16_gradients_close_to_oracle(bf16_model):
-    """bf16 training mode: gradients of the large tensors within a few % (norm) of the fp32 oracle."""
+@pytest.mark.parametrize("B,S,seed", [(2, 3, 1), (8, 3, 3), (2, 0, 2)])
+def test_bf16_gradients_close_to_oracle(bf16_model, B, S, seed):
+    """bf16 training mode vs the fp32 oracle, per trainable tensor (direction and magnitude), at B = 2 and at the BASELINE config-2
+    batch B = 8.  Bars sit just outside what tools/diag_bf16_grads.py measures (gpurun_out -> profiles/r2_bf16_gradient_quality.txt):
+    shot_num = 3: every decoder-side tensor cos >= 0.9998, norm within 0.5 %; the exemplar CNN (its gradient arrives through the tiny
+    cross-attention k/v signal) cos 0.960-0.963, norm within 1.4 %.  shot_num = 0 has the smallest map magnitude, its forward
+    cancellation error (counts 6 %, see the module docstring) scales dL/dout: cos >= 0.988, norms 0.81-0.95 of the oracle's."""
     m, sd = bf16_model
-    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=1)
+    imgs, boxes, gt, mask = W.make_inputs(batch=B, shots=3, seed=seed)
     m.train()
     m.zero_grad()
-    out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3)
+    out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), S)
     loss = R.masked_mse_loss(out, torch.from_numpy(gt).cuda(), torch.from_numpy(mask).cuda())
     loss.backward()
     m.eval()
-    _, rloss, rg = R.loss_and_grads(sd, imgs, boxes, gt, mask, 3, MODEL)
-    assert abs(loss.item() - rloss.item()) / rloss.item() < 5e-2
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    _, rloss, rg = R.loss_and_grads(sd, imgs, boxes, gt, mask, S, MODEL)
+    assert abs(loss.item() - rloss.item()) / rloss.item() < (1e-3 if S else 5e-3)
+    checked = 0
     for k, p in m.named_parameters():
         if p.grad is None or rg.get(k) is None:
             continue
@@ -162,10 +169,16 @@ def test_bf16_gradients_close_to_oracle(bf16_model):
         if ref.norm() < 1e-3:
             continue
         got = p.grad.detach().cpu().double()
-        cos = (got * ref).sum() / (got.norm() * ref.norm())
-        # exemplar-CNN gradients arrive through the (tiny) cross-attention k/v signal: measured 0.96-0.98
-        assert cos > (0.94 if k.startswith("decoder_proj") else 0.98), (k, cos.item())
-        assert abs(got.norm() - ref.norm()) / ref.norm() < 0.1, k
+        cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
+        ratio = (got.norm() / ref.norm()).item()
+        if S == 0:
+            assert cos > 0.98 and 0.75 < ratio < 1.02, (k, cos, ratio)
+        elif k.startswith("decoder_proj"):
+            assert cos > 0.95 and abs(ratio - 1) < 0.03, (k, cos, ratio)
+        else:
+            assert cos > 0.999 and abs(ratio - 1) < 0.01, (k, cos, ratio)
+        checked += 1
+    assert checked >= (50 if S == 0 else 55)
 
 
 @pytest.mark.parametrize("name,tol", [("mae_vit_large_patch16", 1e-3), ("mae_vit_base6_patch16", 1e-3)])
