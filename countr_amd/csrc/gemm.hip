@@ -542,6 +542,36 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
   auto mrow = [&](int tm) { return MPERM ? (wm0 + (tm >> 2) * 64 + (li >> 2) * 16 + (tm & 3) * 4 + (li & 3)) : (wm0 + tm * 16 + li); };
   const int ntiles = (kend > kstart) ? (kend - kstart + BK - 1) / BK : 0;
 
+  // Residual prefetch.  The fp32 residual tile of a (bias + residual -> fp32) GEMM is known before the first k-tile, but the
+  // epilogue used to fetch it at the very end: with one wave per SIMD and 8 KB in flight per wave that was two exposed memory
+  // round trips per workgroup (in-step proj 19.5 vs 10.3 us, fc2 40.5 vs 27.7 us against the same GEMMs with bf16 output).  The
+  // compute waves now issue all 16 row-segment loads of their 64x64 sub-tile up front, in the staged epilogue's (row, chunk)
+  // order, and the values wait in registers under the whole main loop.
+  typedef __attribute__((ext_vector_type(4))) float resid4_t;
+  constexpr bool RPRE_OK = sizeof(T) == 2 && TMW == 4 && (NLD == 0 || NLD == WM * WN);   // 256-VGPR budgets only
+  const bool resid_pre = RPRE_OK && !loader_wave && !split && g.resid != nullptr && !g.out_bf16 && g.act == COUNTR_ACT_NONE && g.C2 == nullptr &&
+                         g.nbatch <= 1 && ((g.ldc & 3) == 0) && (((uintptr_t)g.C & 15) == 0) && ((g.N & 3) == 0) && ((g.ldres & 3) == 0) &&
+                         (((uintptr_t)g.resid & 15) == 0);
+  auto stage_row = [&](int h, int r) {   // staged-epilogue row r (0..31) of half h -> row of the wave's 64-row sub-tile
+    return MPERM ? (((2 * h + ((r >> 2) & 1)) >> 2) * 64 + (r >> 3) * 16 + ((2 * h + ((r >> 2) & 1)) & 3) * 4 + (r & 3)) : (h * 32 + r);
+  };
+  resid4_t rpre[RPRE_OK ? 2 : 1][RPRE_OK ? 8 : 1];
+  if constexpr (RPRE_OK) {
+    if (resid_pre) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int idx = lane + 64 * j, r = idx >> 4, cc = idx & 15;
+          const int m = m0 + wm0 + stage_row(h, r), n = n0 + wn0 + cc * 4;
+          rpre[h][j] = resid4_t{0.f, 0.f, 0.f, 0.f};
+          if (m < g.M && n < g.N)
+            rpre[h][j] = __builtin_nontemporal_load(reinterpret_cast<const resid4_t*>(g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres + n));
+        }
+      asm volatile("" ::: "memory");
+    }
+  }
+
   if constexpr (sizeof(T) == 2) {
     // ---------------- bf16: LDS-DMA staging, two stages, tile t+1 in flight while tile t is multiplied
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -583,9 +613,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     // of a k-step are shared by its halves), so LDS round trips hide under the matrix pipe.
     constexpr int NH = TMW / 4, NS = 2 * NH;
     constexpr int XR = 4 * FragReads<MA>::N, WR = 4 * FragReads<MB>::N;   // LDS instructions per step for x / w fragments
-    auto mma_tile = [&](const char* sa_, const char* sb_, auto mid) {   // mid(): called between the two halves of the tile's steps
-      const uint32_t sa = lds_addr(sa_), sb = lds_addr(sb_);
-      bf16x8_t xf[2][4], wf[2][4];
+    // Fragment pipeline.  set_tile() names the staged tile the NEXT request() reads; step<s, NEXT> first issues the reads of what
+    // follows (NEXT = 1: step s+1 of the same tile; 2: step 0 of the tile named by set_tile -- the loop is rotated so that these
+    // first fragments of tile t+1 fly under the last MFMA step of tile t instead of behind an idle matrix pipe after every
+    // barrier; 0: nothing), waits for its own fragments and issues its 16 MFMAs.
+    uint32_t sa = 0, sb = 0;
+    bf16x8_t xf[2][4], wf[2][4];
+    auto set_tile = [&](const char* sa_, const char* sb_) { sa = lds_addr(sa_); sb = lds_addr(sb_); };
       auto request = [&](auto S) {
         constexpr int s = decltype(S)::value, kk = s / NH, h = s % NH;
 #if COUNTR_ABL == 2
@@ -612,12 +646,16 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         }
 #endif
       };
-      auto step = [&](auto S) {
-        constexpr int s = decltype(S)::value, kk = s / NH, h = s % NH;
-        if constexpr (s + 1 < NS) request(std::integral_constant<int, s + 1>{});
+      auto step = [&](auto S, auto NEXT_, auto WAIT_) {
+        constexpr int s = decltype(S)::value, kk = s / NH, h = s % NH, NEXT = decltype(NEXT_)::value;
+        constexpr bool WAIT = decltype(WAIT_)::value;   // false: the caller already waited for this step's fragments
+        static_assert(NEXT != 1 || s + 1 < NS, "no next step in this tile");
+        static_assert(NEXT != 2 || (((s & 1) == 1) && kk == 1), "the next tile's first request writes xf[0] / wf[0]");
+        if constexpr (NEXT == 1) request(std::integral_constant<int, s + 1>{});
+        if constexpr (NEXT == 2) request(std::integral_constant<int, 0>{});
 #if COUNTR_ABL != 2
-        constexpr int nxt = (s + 1 < NS) ? XR + (((s + 1) % NH) == 0 ? WR : 0) : 0;   // reads allowed to stay in flight
-        lds_wait<(nxt > 15 ? 15 : nxt)>(xf[s & 1], wf[kk]);                            // lgkmcnt is a 4-bit counter
+        constexpr int nxt = NEXT == 1 ? XR + (((s + 1) % NH) == 0 ? WR : 0) : (NEXT == 2 ? XR + WR : 0);   // reads allowed to stay in flight
+        if constexpr (WAIT) lds_wait<(nxt > 15 ? 15 : nxt)>(xf[s & 1], wf[kk]);                           // lgkmcnt is a 4-bit counter
 #endif
 #if COUNTR_ABL == 1
 #pragma unroll
@@ -640,15 +678,29 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
             accb[h * 4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[s & 1][tm], accb[h * 4 + tm], 0, 0, 0);
         }
       };
-      request(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 0>{});
-      if constexpr (NS == 2) mid();
-      step(std::integral_constant<int, 1>{});
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using YES = std::true_type; using NO = std::false_type;
+    auto wait_frags = [&](auto S) {   // all LDS reads issued so far have landed (fragments of step S threaded through)
+      constexpr int s = decltype(S)::value;
+      lds_wait<0>(xf[s & 1], wf[s / NH]);
+    };
+    // steps 0 .. NS-2 of the tile whose step-0 fragments have been requested already
+    auto steps_but_last = [&](auto mid) {
+      step(I0{}, I1{}, YES{});
       if constexpr (NS > 2) {
+        step(I1{}, I1{}, YES{});
         mid();
-        step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{});
+        step(I2{}, I1{}, YES{});
+      } else {
+        mid();
       }
+    };
+    // classic form: one whole tile, nothing in flight across its ends
+    auto mma_tile = [&](const char* sa_, const char* sb_, auto mid) {   // mid(): called between the two halves of the tile's steps
+      set_tile(sa_, sb_);
+      request(I0{});
+      steps_but_last(mid);
+      step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
     };
     auto nomid = [] {};
     auto main_loop = [&](auto FAST) {
@@ -676,6 +728,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
       // arrives only after it issued tile t-1's MFMAs (their fragments were read), a loader only after tile t has landed.
       constexpr int PER = DmaLoader<MA, BMt, NLW>::PASSES + DmaLoader<MB, BNt, NLW>::PASSES;
       static_assert((STAGES - 2) * PER <= 63, "vmcnt immediate");
+#ifdef COUNTR_GEMM_STAMP   // loaders: [1] load wait, [2] barrier, [3] DMA issue; compute waves: [2] barrier, [4] fragments + MFMA
+      uint64_t sk1 = 0, sk2 = 0, sk3 = 0, sk4 = 0;
+      const uint64_t sk0 = __builtin_readcyclecounter();
+#define SSTAMP(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define SSTAMP(x)
+#endif
       if (loader_wave) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -685,24 +744,58 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           }
         int islot = STAGES - 1;
         for (int t = 0; t < ntiles; ++t) {
+          SSTAMP(ua);
           if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          SSTAMP(ub);
           __builtin_amdgcn_s_barrier();
+          SSTAMP(uc);
           if (t + STAGES - 1 < ntiles) {
             char* nxt = smem + islot * (SA + SB);
             issueA(ktile(t + STAGES - 1), nxt);
             issueB(ktile(t + STAGES - 1), nxt + SA);
           }
           islot = (islot + 1 == STAGES) ? 0 : islot + 1;
+#ifdef COUNTR_GEMM_STAMP
+          { SSTAMP(ud); sk1 += ub - ua; sk2 += uc - ub; sk3 += ud - uc; }
+#endif
         }
       } else {
+        // rotated: [steps 0..NS-2 of tile t] -> last step's fragments landed -> barrier t+1 -> request tile t+1's first fragments
+        // -> last step's MFMAs of tile t.  (All LDS reads of tile t have completed before the barrier that lets the loaders
+        // refill its slot; the MFMAs behind it only read registers.)
         int slot = 0;
-        for (int t = 0; t < ntiles; ++t) {
+        if (ntiles > 0) {
           __builtin_amdgcn_s_barrier();
-          mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA, nomid);
+          set_tile(smem, smem + SA);
+          request(I0{});
+        }
+        for (int t = 0; t + 1 < ntiles; ++t) {
+          SSTAMP(ua);
+          steps_but_last(nomid);
+          wait_frags(std::integral_constant<int, NS - 1>{});
           slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+          SSTAMP(ub);
+          __builtin_amdgcn_s_barrier();
+          set_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
+          SSTAMP(uc);
+          step(std::integral_constant<int, NS - 1>{}, I2{}, NO{});
+#ifdef COUNTR_GEMM_STAMP
+          { SSTAMP(ud); sk2 += uc - ub; sk4 += (ub - ua) + (ud - uc); }
+#endif
+        }
+        if (ntiles > 0) {   // last tile: nothing follows
+          steps_but_last(nomid);
+          step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
         }
       }
+#ifdef COUNTR_GEMM_STAMP
+      if (g.nbatch == 1 && g.sC1 && lane == 0) {
+        float* d = reinterpret_cast<float*>(g.sC1) + ((int64_t)blockIdx.x * (NW + NLD) + (tid >> 6)) * 8;
+        d[0] = (float)(__builtin_readcyclecounter() - sk0); d[1] = (float)sk1; d[2] = (float)sk2; d[3] = (float)sk3; d[4] = (float)sk4;
+        d[5] = (float)ntiles; d[6] = loader_wave ? 1.f : 2.f;
+      }
+#endif
     } else if constexpr (STAGES >= 3) {
       // Deep pipeline for SMALL grids (<= 1 workgroup per CU, nothing else to hide the DMA round trip): STAGES-1 tiles are in
       // flight while one is multiplied.  Counted vmcnt: DMA loads retire in order, so "at most (STAGES-2) tiles' worth of
@@ -720,12 +813,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // tile t visible to all waves; every wave is done with the slot refilled below
+        set_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA);
+        request(I0{});                  // first fragments first: their LDS round trip runs under the DMA issue
         if (t + STAGES - 1 < ntiles) {
           char* nxt = smem + islot * (SA + SB);
           issueA(ktile(t + STAGES - 1), nxt);
           issueB(ktile(t + STAGES - 1), nxt + SA);
         }
-        mma_tile(smem + slot * (SA + SB), smem + slot * (SA + SB) + SA, nomid);
+        steps_but_last(nomid);
+        step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
         slot = (slot + 1 == STAGES) ? 0 : slot + 1;
         islot = (islot + 1 == STAGES) ? 0 : islot + 1;
       }
@@ -763,9 +859,12 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           }
         };
         STAMP(ta);
+        set_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA);
+        request(I0{});                        // first fragments first: their LDS round trip runs under the DMA issue below
         if (!late_group) issue_next();        // (one copy of the MFMA code: the branches wrap the DMA issue only)
         STAMP(tb);
-        mma_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA, [&] { if (late_group) issue_next(); });
+        steps_but_last([&] { if (late_group) issue_next(); });
+        step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
         STAMP(tc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(td);
@@ -935,8 +1034,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
                 }
               } else {
                 f32x4v_t v = *reinterpret_cast<const f32x4v_t*>(ost + r * PITCHO + cc * 16);
-                if constexpr (RESIDC)
-                  v += *reinterpret_cast<const f32x4v_t*>(g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres + n);
+                if constexpr (RESIDC) {
+                  if constexpr (RPRE_OK) {
+                    if (resid_pre) v += rpre[h][j];
+                    else v += *reinterpret_cast<const f32x4v_t*>(g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres + n);
+                  } else {
+                    v += *reinterpret_cast<const f32x4v_t*>(g.resid + (int64_t)(g.res_mod > 0 ? (m % g.res_mod) : m) * g.ldres + n);
+                  }
+                }
                 *reinterpret_cast<f32x4v_t*>(reinterpret_cast<float*>(g.C) + offC + (int64_t)m * g.ldc + n) = v;
               }
             }

@@ -18,6 +18,12 @@ for name, N, K in (("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)):
     torch.cuda.synchronize()
     d = dbg.view(-1, 8).cpu(); d = d[d[:, 0] > 0]
     nt = d[:, 5].mean().item()
+    if (d[:, 6] > 0).any():   # wave-specialised kernel: loaders (6 == 1) and compute waves (6 == 2) report different columns
+        ld, cp = d[d[:, 6] == 1], d[d[:, 6] == 2]
+        print("%s [wave-specialised]: k-tiles %.0f | loaders (%d): loop %.0f, per k-tile: load wait %.0f  barrier %.0f  dma issue %.0f | compute (%d): loop %.0f, per k-tile: barrier %.0f  frags+mfma %.0f"
+              % (name, nt, ld.shape[0], ld[:, 0].mean(), ld[:, 1].mean() / nt, ld[:, 2].mean() / nt, ld[:, 3].mean() / nt,
+                 cp.shape[0], cp[:, 0].mean(), cp[:, 2].mean() / nt, cp[:, 4].mean() / nt))
+        continue
     print("%s: %d waves, k-tiles %.0f; mean cycles per wave: loop total %.0f | per k-tile: dma issue %.0f  frags+mfma %.0f  load wait %.0f  barrier %.0f"
           % (name, d.shape[0], nt, d[:, 0].mean(), d[:, 1].mean() / nt, d[:, 2].mean() / nt, d[:, 3].mean() / nt, d[:, 4].mean() / nt))
     w = d.view(-1, 8, 8) if d.shape[0] % 8 == 0 else None
