@@ -5,9 +5,10 @@ The hot loop (:265-319) is the fused FinetuneStep: forward + masked-MSE + decode
 AdamW, graph-captured, bf16 (no GradScaler), LR schedule per iteration as util/lr_sched.py.  Launch one process per GPU
 with `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 FSC_finetune_cross.py ...`.
 Data: with the FSC147 files present (--data_path/--anno_file/--data_split_file/--im_dir) batches come from
-countr_amd/data/fsc147.py (PIL/scipy restatement of the reference's non-augmented train transform; the imgaug/cv2 augmentation
-pipeline of util/FSC147.py is out of scope); `--synthetic_steps K` trains on synthetic FSC147-shaped batches instead (K
-iterations per epoch) and is the automatic fallback when the dataset is absent."""
+countr_amd/data/fsc147.py (PIL/scipy/torch restatement of util/FSC147.py's train transform, with the noise / colour jitter / blur /
+affine / flip / mosaic augmentation when --do_aug is on, the reference's default; --class_file is needed then);
+`--synthetic_steps K` trains on synthetic FSC147-shaped batches instead (K iterations per epoch) and is the automatic fallback when
+the dataset is absent."""
 import argparse
 import json
 import random

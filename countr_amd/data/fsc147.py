@@ -1,9 +1,17 @@
 """FSC147 datasets with PIL + scipy only: the reference's loaders need torchvision / cv2 / imgaug,
-none of which exist offline.  Restated here: the NON-augmented train transform, the val transform and the pretrain transform of
-util/FSC147.py, and the dataset classes of FSC_finetune_cross.py:113-154 / FSC_pretrain.py:114-143.  The augmentation branch
-(Gaussian noise, colour jitter, blur, affine, flip, mosaic: util/FSC147.py:130-253) is out of scope; `do_aug=True` falls back to
-the non-augmented transform with a one-time warning.  Host-side code: it produces the [B,3,384,384] / [B,3,3,64,64] / [B,384,384]
-batches that FinetuneStep.load() / PretrainStep.load() stage into the engine.
+none of which exist offline.  Restated here: the train transform of util/FSC147.py with and without augmentation, the val transform
+and the pretrain transform, and the dataset classes of FSC_finetune_cross.py:113-154 / FSC_pretrain.py:114-143.  Host-side code: it
+produces the [B,3,384,384] / [B,3,3,64,64] / [B,384,384] batches that FinetuneStep.load() / PretrainStep.load() stage into the engine.
+
+Augmentation branch (util/FSC147.py:130-253).  What is pinned against the reference and what is not:
+  * the control flow, the order of draws from the `random` module, the mosaic (crop sizes, self / other-image branches, class test,
+    dot placement, the three blending passes) and the random crop are the reference's own arithmetic and are checked against golden
+    vectors produced by running util/FSC147.py itself (tools/oracle/make_golden_data.py: the mosaic output does not depend on the
+    third-party ops, which only feed the branch the mosaic discards);
+  * Gaussian noise is np.random.normal(0, 0.1) exactly as in the reference;
+  * ColorJitter / GaussianBlur (torchvision 0.14.1) and the random affine (imgaug 0.4) are re-implemented from their documented
+    semantics with this module's own parameter draws (same distributions, not the same random streams): "parity unpinned" for
+    those three ops -- neither library is installed, so no reference output exists to compare with.
 
 PIL's Image.resize(BILINEAR / BICUBIC) is what torchvision.transforms.Resize calls for PIL inputs; exemplar crops are resized
 as TENSORS by the reference (torchvision 0.14.1: bilinear, no antialias) == F.interpolate(mode="bilinear", align_corners=False)."""
@@ -11,7 +19,6 @@ import json
 import math
 import os
 import random
-import warnings
 
 import numpy as np
 import torch
@@ -80,6 +87,246 @@ def transform_train_noaug(image, rects, dots, rng=random):
     return {"image": crop.contiguous(), "boxes": boxes, "pos": pos, "gt_density": torch.from_numpy(dens), "m_flag": 0}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Train-time augmentation (util/FSC147.py:117-300 with aug_flag True)
+# ------------------------------------------------------------------------------------------------------------------
+def _gray(img):
+    return (0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2]).unsqueeze(0)
+
+
+def _blend(a, b, f):
+    return (f * a + (1.0 - f) * b).clamp(0, 1)
+
+
+def _rgb2hsv(img):
+    r, g, b = img[0], img[1], img[2]
+    maxc, minc = img.max(0).values, img.min(0).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    crd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    return torch.stack((h, s, maxc))
+
+
+def _hsv2rgb(img):
+    h, s, v = img[0], img[1], img[2]
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    p = (v * (1.0 - s)).clamp(0, 1)
+    q = (v * (1.0 - s * f)).clamp(0, 1)
+    t = (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
+    sel = [(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]
+    out = torch.zeros_like(img)
+    for k, (rr, gg, bb) in enumerate(sel):
+        m = i == k
+        out[0] += m * rr
+        out[1] += m * gg
+        out[2] += m * bb
+    return out
+
+
+def color_jitter(img, order, brightness, contrast, saturation, hue):
+    """transforms.ColorJitter on a [3, H, W] tensor in [0, 1] (torchvision 0.14.1 functional_tensor semantics): the four ops in the
+    drawn `order` (0 brightness, 1 contrast, 2 saturation, 3 hue); factor 1 (hue 0) is the identity."""
+    for op in order:
+        if op == 0:
+            img = _blend(img, torch.zeros_like(img), brightness)
+        elif op == 1:
+            img = _blend(img, _gray(img).mean(), contrast)
+        elif op == 2:
+            img = _blend(img, _gray(img), saturation)
+        else:
+            hsv = _rgb2hsv(img)
+            hsv[0] = torch.remainder(hsv[0] + hue, 1.0)
+            img = _hsv2rgb(hsv)
+    return img
+
+
+def gaussian_blur(img, kernel_size=(7, 9), sigma=1.0):
+    """transforms.GaussianBlur on a [C, H, W] tensor: separable kernel (kx, ky) of one sigma, reflect padding."""
+    def k1d(n):
+        x = torch.linspace(-(n - 1) * 0.5, (n - 1) * 0.5, n, dtype=img.dtype)
+        k = torch.exp(-0.5 * (x / sigma) ** 2)
+        return k / k.sum()
+    kx, ky = k1d(kernel_size[0]), k1d(kernel_size[1])
+    k2 = (ky[:, None] * kx[None, :]).expand(img.shape[0], 1, kernel_size[1], kernel_size[0])
+    pad = (kernel_size[0] // 2, kernel_size[0] // 2, kernel_size[1] // 2, kernel_size[1] // 2)
+    x = F.pad(img.unsqueeze(0), pad, mode="reflect")
+    return F.conv2d(x, k2.contiguous(), groups=img.shape[0])[0]
+
+
+def affine_matrix(h, w, rotate_deg, scale, shear_deg, tx_frac, ty_frac):
+    """Forward 3x3 matrix (x, y, 1) of iaa.Affine(rotate, scale, shear, translate_percent) about the image centre."""
+    cx, cy = w / 2.0 - 0.5, h / 2.0 - 0.5
+    r, sh = math.radians(rotate_deg), math.radians(shear_deg)
+    to0 = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]])
+    sc = np.diag([scale, scale, 1.0])
+    shm = np.array([[1, -math.tan(sh), 0], [0, 1, 0], [0, 0, 1.0]])
+    rot = np.array([[math.cos(r), -math.sin(r), 0], [math.sin(r), math.cos(r), 0], [0, 0, 1.0]])
+    back = np.array([[1, 0, cx + tx_frac * w], [0, 1, cy + ty_frac * h], [0, 0, 1.0]])
+    return back @ rot @ shm @ sc @ to0
+
+
+def warp_affine(img, M):
+    """Bilinear warp of a [C, H, W] tensor by the forward matrix M, zero fill (imgaug order=1, cval=0, mode='constant')."""
+    from scipy import ndimage
+    Mi = np.linalg.inv(M)
+    # ndimage works in (row, col) = (y, x): swap the axes of the inverse map
+    A = np.array([[Mi[1, 1], Mi[1, 0]], [Mi[0, 1], Mi[0, 0]]])
+    off = np.array([Mi[1, 2], Mi[0, 2]])
+    a = img.numpy()
+    out = np.stack([ndimage.affine_transform(a[c], A, offset=off, order=1, mode="constant", cval=0.0) for c in range(a.shape[0])])
+    return torch.from_numpy(out)
+
+
+def _scaled_dot(d, sh, sw, new_h, new_w):
+    return min(new_h - 1, int(d[1] * sh)), min(new_w - 1, int(d[0] * sw))   # (y, x) as util/FSC147.py:147,188
+
+
+def _resize_t(t, size):
+    return F.interpolate(t.unsqueeze(0), size=(size, size), mode="bilinear", align_corners=False)[0]
+
+
+def _mosaic_piece(img_t, dots, sh, sw, new_h, new_w, length, start_w, start_h, resize_l, count_dots):
+    """One quadrant source: a length x length crop of the CLEAN resized image, resized to resize_l, with its dot map
+    (util/FSC147.py:186-195, 222-233)."""
+    piece = _resize_t(img_t[:, start_h:start_h + length, start_w:start_w + length], resize_l)
+    dm = np.zeros((resize_l, resize_l), dtype="float32")
+    if count_dots:
+        for d in dots:
+            y, x = _scaled_dot(d, sh, sw, new_h, new_w)
+            if start_h <= y < start_h + length and start_w <= x < start_w + length:
+                dm[min(resize_l - 1, int((y - start_h) * resize_l / length))][min(resize_l - 1, int((x - start_w) * resize_l / length))] = 1
+    return piece, torch.from_numpy(dm)
+
+
+def _blend_pair(a, b, bl, resize_l, dim):
+    """Join two pieces along `dim` (1 = rows, 2 = columns of a [C, H, W] tensor) with the reference's 2*bl-wide linear cross-fade
+    (util/FSC147.py:235-253): the kept 192-wide cores are concatenated, then the bl lines either side of the seam are re-mixed
+    with the neighbour's overhanging lines."""
+    sl = lambda t, lo, hi: t.narrow(dim, lo, hi - lo)
+    out = torch.cat((sl(a, bl, resize_l - bl), sl(b, bl, resize_l - bl)), dim)
+    i = torch.arange(bl)
+    shape = [1, 1, 1]
+    shape[dim] = bl
+    w_new = ((bl - i).to(out.dtype) / (2 * bl)).view(shape)
+    w_old = ((i + bl).to(out.dtype) / (2 * bl)).view(shape)
+    hi = out.index_select(dim, 192 + i) * w_old + a.index_select(dim, resize_l - 1 - bl + i) * w_new
+    lo = out.index_select(dim, 191 - i) * w_old + b.index_select(dim, bl - i) * w_new
+    out.index_copy_(dim, 192 + i, hi)
+    out.index_copy_(dim, 191 - i, lo)
+    return out.clamp(0, 1)
+
+
+def mosaic(img_t, dots, sh, sw, im_id, ctx, rng):
+    """Random self / cross-image mosaic (util/FSC147.py:177-253) -> image [3, 384, 384], dot map [384, 384], m_flag."""
+    new_h, new_w = img_t.shape[1], img_t.shape[2]
+    bl = rng.randint(10, 20)
+    resize_l = 192 + 2 * bl
+    pieces, maps, m_flag = [], [], 0
+    if dots.shape[0] >= 70:
+        for _ in range(4):
+            length = rng.randint(150, 384)
+            start_w = rng.randint(0, new_w - length)
+            start_h = rng.randint(0, new_h - length)
+            p, m = _mosaic_piece(img_t, dots, sh, sw, new_h, new_w, length, start_w, start_h, resize_l, True)
+            pieces.append(p); maps.append(m)
+    else:
+        m_flag = 1
+        prob = rng.random()
+        gt_pos = rng.randint(0, 3) if prob > 0.25 else rng.randint(0, 4)   # 5 %: none of the four quadrants is the image itself
+        for i in range(4):
+            if i == gt_pos:
+                t_id, t_img, t_dots, t_sh, t_sw = im_id, img_t, dots, sh, sw
+            else:
+                t_id = ctx.train_set[rng.randint(0, len(ctx.train_set) - 1)]
+                t_dots = np.array(ctx.annotations[t_id]["points"])
+                timage = ctx.open_image(t_id)
+                th, tw = flex_resize(timage.size[1], timage.size[0])
+                t_sw, t_sh = float(tw) / timage.size[0], float(th) / timage.size[1]
+                from PIL import Image
+                t_img = to_tensor(timage.resize((tw, th), Image.BILINEAR))
+            th, tw = t_img.shape[1], t_img.shape[2]
+            length = rng.randint(250, 384)
+            start_w = rng.randint(0, tw - length)
+            start_h = rng.randint(0, th - length)
+            same = ctx.class_dict[im_id] == ctx.class_dict[t_id]
+            p, m = _mosaic_piece(t_img, t_dots, t_sh, t_sw, th, tw, length, start_w, start_h, resize_l, same)
+            pieces.append(p); maps.append(m)
+    core = lambda m, d: m.narrow(d, bl, resize_l - 2 * bl)
+    left = _blend_pair(pieces[0], pieces[1], bl, resize_l, 1)
+    right = _blend_pair(pieces[2], pieces[3], bl, resize_l, 1)
+    image = _blend_pair(left, right, bl, resize_l, 2)
+    dl = torch.cat((core(maps[0], 0), core(maps[1], 0)), 0)
+    dr = torch.cat((core(maps[2], 0), core(maps[3], 0)), 0)
+    dens = torch.cat((core(dl, 1), core(dr, 1)), 1)
+    return image, dens, m_flag
+
+
+class AugParams:
+    """The draws of the three third-party augmentations (distributions of util/FSC147.py:139,153-160,371-374)."""
+
+    def __init__(self, nprng=np.random):
+        self.order = [int(k) for k in nprng.permutation(4)]
+        self.brightness = float(nprng.uniform(0.75, 1.25))
+        self.contrast = float(nprng.uniform(0.85, 1.15))
+        self.saturation = float(nprng.uniform(0.85, 1.15))
+        self.hue = float(nprng.uniform(-0.15, 0.15))
+        self.sigma = float(nprng.uniform(0.1, 2.0))
+        self.rotate = float(nprng.uniform(-15, 15))
+        self.scale = float(nprng.uniform(0.8, 1.2))
+        self.shear = float(nprng.uniform(-10, 10))
+        self.tx = float(nprng.uniform(-0.2, 0.2))
+        self.ty = float(nprng.uniform(-0.2, 0.2))
+
+
+def transform_train_aug(image, rects, dots, im_id, ctx, rng=random, nprng=np.random, params=None):
+    """ResizeTrainImage.__call__ with aug_flag True (util/FSC147.py:117-300).  `rng` supplies the draws the reference takes from the
+    `random` module (same order), `nprng` the Gaussian noise and -- unless `params` is given -- the jitter / blur / affine draws."""
+    from PIL import Image
+    from scipy import ndimage
+    W, H = image.size
+    new_h, new_w = flex_resize(H, W)
+    sh, sw = float(new_h) / H, float(new_w) / W
+    img_t = to_tensor(image.resize((new_w, new_h), Image.BILINEAR))
+    mosaic_flag = rng.random() < 0.25
+    m_flag = 0
+    # noise -> colour jitter -> blur -> affine (image and dots) -> flip: always computed, as in the reference, although the mosaic
+    # branch below does not use the result
+    noise = torch.from_numpy(nprng.normal(0, 0.1, tuple(img_t.shape)))
+    aug = (img_t + noise).clamp(0, 1).float()
+    pr = params or AugParams(nprng)
+    aug = gaussian_blur(color_jitter(aug, pr.order, pr.brightness, pr.contrast, pr.saturation, pr.hue), (7, 9), pr.sigma)
+    M = affine_matrix(new_h, new_w, pr.rotate, pr.scale, pr.shear, pr.tx, pr.ty)
+    aug = warp_affine(aug, M)
+    dens = np.zeros((new_h, new_w), dtype="float32")
+    for d in dots:
+        y, x = _scaled_dot(d, sh, sw, new_h, new_w)
+        xa, ya, _ = M @ np.array([x, y, 1.0])
+        if 0 <= xa < new_w and 0 <= ya < new_h:       # KeypointsOnImage: dropped when it leaves the image
+            dens[int(ya)][int(xa)] = 1
+    dens = torch.from_numpy(dens)
+    if rng.random() > 0.5:
+        aug, dens = aug.flip(-1), dens.flip(-1)
+    if mosaic_flag:
+        out_img, out_dens, m_flag = mosaic(img_t, dots, sh, sw, im_id, ctx, rng)
+    else:
+        start_w = rng.randint(0, new_w - 1 - 383)
+        start_h = rng.randint(0, new_h - 1 - 383)
+        out_img = aug[:, start_h:start_h + 384, start_w:start_w + 384]
+        out_dens = dens[start_h:start_h + 384, start_w:start_w + 384]
+    out_dens = torch.from_numpy(ndimage.gaussian_filter(out_dens.numpy(), sigma=(1, 1), order=0) * 60)
+    boxes, _ = exemplar_crops(img_t, rects, sh, sw)     # exemplars come from the CLEAN resized image (util/FSC147.py:283)
+    return {"image": out_img.contiguous().float(), "boxes": boxes, "pos": torch.tensor([]), "gt_density": out_dens, "m_flag": m_flag}
+
+
 def transform_val(image, rects, dots):
     """ResizeValImage.__call__ (util/FSC147.py:316-366): 384x384, gaussian sigma 4 radius 7, x60."""
     from PIL import Image
@@ -138,19 +385,33 @@ def _open_rgb(path):
 
 
 class TrainData(Dataset):
-    """FSC_finetune_cross.py:113-154 -> (image, gt_density, n_dots, boxes, pos, m_flag, im_id)."""
-    _warned = False
+    """FSC_finetune_cross.py:113-154 -> (image, gt_density, n_dots, boxes, pos, m_flag, im_id).  With do_aug (the reference's
+    default) the train split goes through transform_train_aug; it needs args.class_file (ImageClasses_FSC147.txt) for the
+    cross-image mosaic, as util/FSC147.py:35-41 does."""
 
     def __init__(self, args, split="train", do_aug=True):
         anno, split_file, self.im_dir = _paths(args)
         self.annotations = json.load(open(anno))
-        self.img = list(json.load(open(split_file))[split])
+        splits = json.load(open(split_file))
+        self.img = list(splits[split])
         random.shuffle(self.img)
         self.split = split
-        if do_aug and split == "train" and not TrainData._warned:
-            warnings.warn("FSC147 augmentations (imgaug / cv2 / torchvision) are not available: using the reference's "
-                          "non-augmented train transform")
-            TrainData._warned = True
+        self.train_set = list(splits.get("train", []))
+        self.do_aug = bool(do_aug) and split == "train"
+        self.class_dict = {}
+        if self.do_aug:
+            cf = getattr(args, "class_file", None)
+            cf = cf if cf is None or os.path.isabs(cf) else os.path.join(args.data_path, cf)
+            if not cf or not os.path.exists(cf):
+                raise FileNotFoundError("--do_aug needs --class_file (ImageClasses_FSC147.txt): %r not found" % (cf,))
+            with open(cf) as f:
+                for line in f:
+                    parts = line.split()
+                    if parts:
+                        self.class_dict[parts[0]] = parts[1:]
+
+    def open_image(self, im_id):
+        return _open_rgb(os.path.join(self.im_dir, im_id))
 
     def __len__(self):
         return len(self.img)
@@ -160,8 +421,13 @@ class TrainData(Dataset):
         anno = self.annotations[im_id]
         dots = np.array(anno["points"])
         rects = [[b[0][1], b[0][0], b[2][1], b[2][0]] for b in anno["box_examples_coordinates"]]
-        image = _open_rgb(os.path.join(self.im_dir, im_id))
-        s = transform_train_noaug(image, rects, dots) if self.split == "train" else transform_val(image, rects, dots)
+        image = self.open_image(im_id)
+        if self.split != "train":
+            s = transform_val(image, rects, dots)
+        elif self.do_aug:
+            s = transform_train_aug(image, rects, dots, im_id, self)
+        else:
+            s = transform_train_noaug(image, rects, dots)
         return s["image"], s["gt_density"], len(dots), s["boxes"], s["pos"], s["m_flag"], im_id
 
 

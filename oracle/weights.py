@@ -171,7 +171,11 @@ def make_wide_inputs(seed, width, shots=3, height=384):
 DATA_CASES = [(640, 384), (384, 600), (500, 400), (900, 384), (300, 250)]   # (W, H) of the synthetic dataset items
 
 
-def make_fsc_item(k, w, h):
+AUG_ITEMS = DATA_CASES + [(700, 500)]     # the augmentation fixtures add one item with 80 dots (self-mosaic branch: >= 70)
+AUG_CLASSES = ["apples", "birds", "apples", "birds", "apples", "apples"]
+
+
+def make_fsc_item(k, w, h, ndots=25):
     """A synthetic FSC147 item (util/FSC147.py sample layout): RGB PIL image, three exemplar rectangles [y1, x1, y2, x2] in
     original pixel coordinates and dot annotations [x, y] -- deterministic from k."""
     from PIL import Image
@@ -179,12 +183,34 @@ def make_fsc_item(k, w, h):
     yy, xx = np.mgrid[0:h, 0:w]
     arr = np.stack([(xx * 255 // w), (yy * 255 // h), ((xx * 3 + yy * 5) % 256)], -1).astype(np.int32)
     arr = np.clip(arr + rs.randint(-20, 21, size=arr.shape), 0, 255).astype(np.uint8)
-    dots = np.stack([rs.uniform(2, w - 2, 25), rs.uniform(2, h - 2, 25)], 1)
+    dots = np.stack([rs.uniform(2, w - 2, ndots), rs.uniform(2, h - 2, ndots)], 1)
     rects = []
     for _ in range(3):
         x1, y1 = int(rs.uniform(0, w - 80)), int(rs.uniform(0, h - 80))
         rects.append([y1, x1, y1 + int(rs.uniform(20, 70)), x1 + int(rs.uniform(20, 70))])
     return Image.fromarray(arr), rects, dots
+
+
+def write_aug_dataset(root):
+    """The six-image dataset of the augmentation fixtures on disk (lossless PNG), in the FSC147 file layout the loaders read:
+    returns (annotation file, split file, class file, image dir, ids)."""
+    import json
+    import os
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    anno, ids = {}, []
+    for k, (w, h) in enumerate(AUG_ITEMS):
+        image, rects, dots = make_fsc_item(k, w, h, ndots=80 if k == 5 else 25)
+        im_id = "%d.png" % k
+        image.save(os.path.join(root, "images", im_id))
+        anno[im_id] = {"points": dots.tolist(),
+                       "box_examples_coordinates": [[[r[1], r[0]], [r[1], r[2]], [r[3], r[2]], [r[3], r[0]]] for r in rects]}
+        ids.append(im_id)
+    json.dump(anno, open(os.path.join(root, "anno.json"), "w"))
+    json.dump({"train": ids, "val": ids[:2], "test": ids[:2]}, open(os.path.join(root, "split.json"), "w"))
+    with open(os.path.join(root, "classes.txt"), "w") as f:
+        for im_id, c in zip(ids, AUG_CLASSES):
+            f.write("%s\t%s\n" % (im_id, c))
+    return os.path.join(root, "anno.json"), os.path.join(root, "split.json"), os.path.join(root, "classes.txt"), os.path.join(root, "images"), ids
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -75,6 +75,26 @@ def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
     assert json.loads([l for l in log.splitlines() if l.startswith("{")][-1])["images"] == 2
 
 
+def test_finetune_cli_with_augmentation(tmp_path):
+    """The reference's default: --do_aug on (noise, colour jitter, blur, affine, flip, mosaic through countr_amd/data/fsc147.py) with
+    the class file the cross-image mosaic needs; two DataLoader workers, as a user would run it."""
+    from oracle import weights as W
+    root = str(tmp_path / "data")
+    anno_f, split_f, class_f, im_dir, ids = W.write_aug_dataset(root)
+    out = str(tmp_path / "ft")
+    log = run(["FSC_finetune_cross.py", "--data_path", root, "--anno_file", "anno.json", "--data_split_file", "split.json",
+               "--im_dir", "images", "--class_file", "classes.txt", "--batch_size", "2", "--epochs", "2", "--warmup_epochs", "0",
+               "--num_workers", "2", "--output_dir", out, "--resume", "", "--log_every", "1", "--blr", "1e-3"])
+    lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
+    assert len(lines) == 6 and all(np.isfinite(l["loss"]) for l in lines)          # 6 images / batch 2, 2 epochs
+    assert os.path.exists(os.path.join(out, "checkpoint__finetuning_last.pth"))
+    # without the class file the augmented loader refuses to start (no silent fallback to the plain transform)
+    r = subprocess.run([sys.executable, "FSC_finetune_cross.py", "--data_path", root, "--anno_file", "anno.json", "--data_split_file",
+                        "split.json", "--im_dir", "images", "--class_file", "nope.txt", "--batch_size", "2", "--epochs", "1",
+                        "--output_dir", out, "--resume", ""], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "class_file" in r.stderr
+
+
 def test_pretrain_cli_on_files_and_synthetic_fallback(fake_fsc, tmp_path):
     out = str(tmp_path / "pre")
     log = run(["FSC_pretrain.py", "--data_path", fake_fsc, "--batch_size", "2", "--epochs", "1", "--warmup_epochs", "0",

@@ -103,3 +103,109 @@ def test_transforms_match_reference_golden():
             assert np.abs(got["gt_density"].numpy() - g["%s%d_density" % (tag, k)]).max() <= 1e-6, (tag, k)
             assert np.abs(got["boxes"].numpy() - g["%s%d_boxes" % (tag, k)]).max() <= 1e-6, (tag, k)
             assert np.array_equal(np.asarray(got["pos"]), g["%s%d_pos" % (tag, k)]), (tag, k)
+
+
+def _identity_params():
+    from countr_amd.data import fsc147 as D
+    p = D.AugParams(np.random.RandomState(0))
+    p.order, p.brightness, p.contrast, p.saturation, p.hue = [0, 1, 2, 3], 1.0, 1.0, 1.0, 0.0
+    p.sigma, p.rotate, p.scale, p.shear, p.tx, p.ty = 1e-4, 0.0, 1.0, 0.0, 0.0, 0.0
+    return p
+
+
+def test_augmented_transform_matches_reference_golden(tmp_path):
+    """ResizeTrainImage(do_aug=True) of util/FSC147.py run unchanged by tools/oracle/make_golden_data.py with IDENTITY stand-ins for the
+    three third-party ops (ColorJitter, GaussianBlur, imgaug affine): 8 mosaic cases (self-mosaic for the 80-dot image, cross-image
+    mosaic with the class test otherwise) and 4 noise + flip + random-crop cases.  transform_train_aug with identity parameters
+    must reproduce them: same `random` draw order, same noise, dot maps, blending and crops."""
+    from countr_amd.data import fsc147 as D
+    from oracle import weights as W
+    import types
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_aug.npz"))
+    anno_f, split_f, class_f, im_dir, ids = W.write_aug_dataset(str(tmp_path))
+    args = types.SimpleNamespace(data_path=str(tmp_path), anno_file=anno_f, data_split_file=split_f, im_dir=im_dir, class_file=class_f)
+    ds = D.TrainData(args, split="train", do_aug=True)
+    kinds = set()
+    for n in range(int(g["ncases"])):
+        k, seed, is_mosaic, m_flag, npos = (int(v) for v in g["c%d_meta" % n])
+        im_id = ids[k]
+        a = ds.annotations[im_id]
+        rects = [[b[0][1], b[0][0], b[2][1], b[2][0]] for b in a["box_examples_coordinates"]]
+        s = D.transform_train_aug(ds.open_image(im_id), rects, np.array(a["points"]), im_id, ds, rng=random.Random(seed),
+                                  nprng=np.random.RandomState(seed), params=_identity_params())
+        kinds.add((is_mosaic, m_flag))
+        assert s["m_flag"] == m_flag and s["pos"].numel() == npos == 0
+        img = s["image"].double()
+        assert img.shape == (3, 384, 384)
+        tol = 2e-6 if is_mosaic else 2e-5      # the crop path carries the blur / warp identities (fp32 round trips)
+        assert np.abs(img.numpy()[:, ::4, ::4] - g["c%d_image" % n]).max() <= tol, n
+        assert np.abs(img.sum(dim=(1, 2)).numpy() - g["c%d_image_sum" % n]).max() <= tol * 384 * 384
+        assert np.abs(img.sum(dim=(0, 2)).numpy() - g["c%d_rowsum" % n]).max() <= tol * 3 * 384
+        assert np.abs(s["gt_density"].numpy() - g["c%d_density" % n]).max() <= 1e-5, n
+        assert np.abs(s["boxes"].numpy() - g["c%d_boxes" % n]).max() <= 1e-6, n
+    assert kinds == {(1, 0), (1, 1), (0, 0)}     # self-mosaic, cross-image mosaic, plain crop all covered
+
+
+def test_colour_jitter_blur_and_affine_properties():
+    """The re-implemented third-party ops (no reference output exists offline): closed-form properties."""
+    from countr_amd.data import fsc147 as D
+    rs = np.random.RandomState(5)
+    img = torch.from_numpy(rs.uniform(0, 1, (3, 40, 52)).astype(np.float32))
+    # colour jitter: neutral factors are the identity in any order; saturation 0 = grayscale; brightness scales; hue keeps value
+    assert torch.allclose(D.color_jitter(img, [3, 1, 0, 2], 1.0, 1.0, 1.0, 0.0), img, atol=2e-6)
+    gray = D.color_jitter(img, [2], 1.0, 1.0, 0.0, 0.0)
+    assert torch.allclose(gray[0], gray[1]) and torch.allclose(gray[0], 0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2], atol=1e-6)
+    assert torch.allclose(D.color_jitter(img, [0], 0.5, 1.0, 1.0, 0.0), img * 0.5, atol=1e-6)
+    hue = D.color_jitter(img, [3], 1.0, 1.0, 1.0, 0.1)
+    assert torch.allclose(hue.max(0).values, img.max(0).values, atol=1e-5)          # V of HSV is untouched by a hue rotation
+    assert torch.allclose(D.color_jitter(hue, [3], 1.0, 1.0, 1.0, -0.1), img, atol=1e-4)
+    flat = torch.full((3, 20, 20), 0.3)
+    assert torch.allclose(D.color_jitter(flat, [1], 1.0, 1.7, 1.0, 0.0), flat, atol=1e-4)   # contrast about the (0.9999-weighted) gray mean
+    # blur: constant images are fixed points (reflect padding, kernel sums to 1); sigma -> 0 is the identity; energy shrinks
+    assert torch.allclose(D.gaussian_blur(flat, (7, 9), 1.3), flat, atol=1e-6)
+    assert torch.allclose(D.gaussian_blur(img, (7, 9), 1e-4), img, atol=1e-6)
+    b = D.gaussian_blur(img, (7, 9), 1.5)
+    assert b.shape == img.shape and b.var() < img.var()
+    from scipy import ndimage
+    ref = ndimage.gaussian_filter(img[0].numpy().astype(np.float64), sigma=1.5, mode="mirror", truncate=100)  # same gaussian, untruncated
+    assert np.abs(b[0, 12:-12, 12:-12].numpy() - ref[12:-12, 12:-12]).max() < 0.02
+    # affine: identity parameters are the identity; a pure translation moves pixels and key points alike; 90-degree-free check
+    M = D.affine_matrix(40, 52, 0.0, 1.0, 0.0, 0.0, 0.0)
+    assert np.allclose(M, np.eye(3)) and torch.allclose(D.warp_affine(img, M), img, atol=1e-6)
+    M = D.affine_matrix(40, 52, 0.0, 1.0, 0.0, 0.25, -0.1)            # +13 px in x, -4 px in y
+    w = D.warp_affine(img, M)
+    assert torch.allclose(w[:, 0:36, 13:52], img[:, 4:40, 0:39], atol=1e-5) and float(w[:, :, :13].abs().max()) == 0.0
+    assert np.allclose(M @ np.array([5.0, 10.0, 1.0]), [18.0, 6.0, 1.0])
+    M = D.affine_matrix(41, 41, 90.0, 1.0, 0.0, 0.0, 0.0)              # rotation about the centre pixel maps the grid onto itself
+    sq = torch.from_numpy(rs.uniform(0, 1, (1, 41, 41)).astype(np.float32))
+    r = D.warp_affine(sq, M)
+    inner = lambda t: t[:, 1:-1, 1:-1]        # border samples land a rounding error outside the image -> zero fill
+    assert torch.allclose(inner(r), inner(torch.rot90(sq, -1, (1, 2))), atol=1e-5) or torch.allclose(inner(r), inner(torch.rot90(sq, 1, (1, 2))), atol=1e-5)
+    M = D.affine_matrix(41, 41, 0.0, 1.2, 0.0, 0.0, 0.0)
+    assert np.allclose(M @ np.array([20.0, 20.0, 1.0]), [20.0, 20.0, 1.0])   # the centre is the fixed point of scale / shear / rotate
+
+
+def test_augmented_dataset_end_to_end(tmp_path):
+    """TrainData(do_aug=True): random parameters, 30 draws over all images -- shapes, finiteness, count bookkeeping (a non-mosaic sample
+    can only lose dots to the warp / crop; the density integrates to 60 per surviving dot) and the class-file requirement."""
+    from countr_amd.data import fsc147 as D
+    from oracle import weights as W
+    import types
+    anno_f, split_f, class_f, im_dir, ids = W.write_aug_dataset(str(tmp_path))
+    args = types.SimpleNamespace(data_path=str(tmp_path), anno_file=anno_f, data_split_file=split_f, im_dir=im_dir, class_file=class_f)
+    random.seed(3); np.random.seed(3)
+    ds = D.TrainData(args, split="train", do_aug=True)
+    flags = set()
+    for it in range(30):
+        image, dens, ndots, boxes, pos, m_flag, im_id = ds[it % len(ds)]
+        assert image.shape == (3, 384, 384) and image.dtype == torch.float32 and boxes.shape == (3, 3, 64, 64)
+        assert torch.isfinite(image).all() and -1e-5 <= float(image.min()) and float(image.max()) <= 1.0 + 1e-5
+        cnt = float(dens.sum()) / 60
+        assert abs(cnt - round(cnt)) < 1e-3 or cnt > 0          # gaussian of unit dots (mass leaks only at the border)
+        flags.add(int(m_flag))
+        if m_flag == 0 and ndots < 70:
+            assert cnt <= ndots + 1e-3
+    assert flags == {0, 1}
+    with pytest.raises(FileNotFoundError):
+        D.TrainData(types.SimpleNamespace(data_path=str(tmp_path), anno_file=anno_f, data_split_file=split_f, im_dir=im_dir,
+                                          class_file="missing.txt"), split="train", do_aug=True)

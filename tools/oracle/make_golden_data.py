@@ -9,10 +9,17 @@ third-party names are supplied by thin stand-ins with the documented behaviour o
   transforms.ToTensor       uint8 HWC -> float CHW / 255
   transforms.Compose        function composition
   TF.crop / TF.hflip        tensor slicing / flip
-  ColorJitter, GaussianBlur, RandomResizedCrop, RandomHorizontalFlip, Normalize: constructed at import time by the reference
-                            module but never CALLED on the non-augmented paths exercised here -> placeholders that raise if called
-  cv2, imgaug               imported at module level only; not used on these paths -> empty modules
-Output: tests/golden/data.npz; the test (tests/test_data_cpu.py) rebuilds the same synthetic images / annotations from seeds."""
+  RandomResizedCrop, RandomHorizontalFlip, Normalize: constructed at import time by the reference module but never CALLED on the
+                            paths exercised here -> placeholders that raise if called
+  cv2                       imported at module level only; not used on these paths -> empty module
+Augmented path (ResizeTrainImage with do_aug=True, second half of this script): ColorJitter, GaussianBlur and the imgaug affine are
+replaced by IDENTITY stand-ins (ColorJitter / GaussianBlur return their input, iaa.Sequential returns image and keypoints unchanged,
+Keypoint / KeypointsOnImage carry x, y and the is_out_of_image test).  What the goldens then pin is everything else the reference
+does around them, unchanged: the draw order from `random`, np.random.normal noise, dot maps, flip, random crop, and the whole mosaic
+(whose output never depends on the three replaced ops -- it is built from the clean resized image).  The product's own colour
+jitter / blur / affine are tested separately (identity parameters reproduce these goldens; closed-form properties otherwise).
+Output: tests/golden/data.npz, tests/golden/data_aug.npz; the tests (tests/test_data_cpu.py) rebuild the same synthetic images /
+annotations from seeds."""
 import os
 import random
 import sys
@@ -43,6 +50,8 @@ def install_stand_ins():
 
     class ToTensor:
         def __call__(self, img):
+            if isinstance(img, np.ndarray) and img.dtype != np.uint8:      # torchvision: non-uint8 arrays are only transposed
+                return torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
             return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
 
     class Compose:
@@ -67,8 +76,16 @@ def install_stand_ins():
     tv = types.ModuleType("torchvision")
     tr = types.ModuleType("torchvision.transforms")
     tr.Resize, tr.ToTensor, tr.Compose = Resize, ToTensor, Compose
-    for n in ("ColorJitter", "GaussianBlur", "RandomResizedCrop", "RandomHorizontalFlip", "Normalize"):
+    for n in ("RandomResizedCrop", "RandomHorizontalFlip", "Normalize"):
         setattr(tr, n, placeholder(n))
+
+    class Identity:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+    tr.ColorJitter = tr.GaussianBlur = Identity
     tf = types.ModuleType("torchvision.transforms.functional")
     tf.crop = lambda img, top, left, h, w: img[..., top:top + h, left:left + w]
     tf.hflip = lambda img: img.flip(-1)
@@ -77,7 +94,28 @@ def install_stand_ins():
     ia = types.ModuleType("imgaug")
     iaa = types.ModuleType("imgaug.augmenters")
     iab = types.ModuleType("imgaug.augmentables")
-    iab.Keypoint = iab.KeypointsOnImage = placeholder("imgaug")
+
+    class Keypoint:
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+        def is_out_of_image(self, image):
+            h, w = image.shape[0:2]
+            return self.x < 0 or self.x >= w or self.y < 0 or self.y >= h
+
+    class KeypointsOnImage:
+        def __init__(self, keypoints, shape):
+            self.keypoints, self.shape = keypoints, shape
+
+    class Sequential:
+        def __init__(self, children):
+            pass
+
+        def __call__(self, image, keypoints):
+            return image, keypoints
+    iab.Keypoint, iab.KeypointsOnImage = Keypoint, KeypointsOnImage
+    iaa.Sequential = Sequential
+    iaa.Affine = lambda **k: None
     ia.augmenters, ia.augmentables = iaa, iab
     sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.transforms.functional": tf,
                         "cv2": types.ModuleType("cv2"), "imgaug": ia, "imgaug.augmenters": iaa, "imgaug.augmentables": iab})
@@ -119,6 +157,44 @@ def main():
     np.savez_compressed(os.path.join(OUT, "data.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, float(np.asarray(v, np.float64).sum()))
+
+    # ---- augmented path (do_aug=True) on the six-image on-disk dataset
+    from PIL import Image
+    root = tempfile.mkdtemp()
+    anno_f, split_f, class_f, im_dir, ids = W.write_aug_dataset(root)
+    aargs = types.SimpleNamespace(im_dir=im_dir, anno_file=anno_f, data_split_file=split_f, do_aug=True, class_file=class_f)
+    aug_t = ref.ResizeTrainImage(aargs, do_aug=True)
+    annos = json.load(open(anno_f))
+    out = {}
+    cases = []
+    for k in (0, 2, 3, 5):
+        want = {"mosaic": 2, "crop": 1}
+        seed = 0
+        while any(want.values()):
+            seed += 1
+            kind = "mosaic" if random.Random(seed).random() < 0.25 else "crop"
+            if want[kind]:
+                want[kind] -= 1
+                cases.append((k, seed, kind))
+    for n, (k, seed, kind) in enumerate(cases):
+        im_id = ids[k]
+        image = Image.open(os.path.join(im_dir, im_id)); image.load()
+        a = annos[im_id]
+        dots = np.array(a["points"])
+        rects = [[b[0][1], b[0][0], b[2][1], b[2][0]] for b in a["box_examples_coordinates"]]
+        random.seed(seed); np.random.seed(seed)
+        s = aug_t({"image": image, "lines_boxes": rects, "dots": dots, "id": im_id, "m_flag": 0})
+        img = s["image"].double()
+        out["c%d_image" % n] = img.numpy()[:, ::4, ::4].astype(np.float32)
+        out["c%d_image_sum" % n] = img.sum(dim=(1, 2)).numpy()
+        out["c%d_rowsum" % n] = img.sum(dim=(0, 2)).numpy()
+        out["c%d_density" % n] = s["gt_density"].numpy().astype(np.float32)
+        out["c%d_boxes" % n] = s["boxes"].numpy()
+        out["c%d_meta" % n] = np.array([k, seed, int(kind == "mosaic"), int(s["m_flag"]), int(s["pos"].numel())])
+    out["ncases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "data_aug.npz"), **out)
+    for k, v in out.items():
+        print(k, np.asarray(v).shape, float(np.asarray(v, np.float64).sum()))
 
 
 if __name__ == "__main__":
