@@ -478,7 +478,7 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int row, int c16, in
 // 1-KiB LDS-DMA piece costs its wave ~60 issue cycles, about as much per k-tile as the tile's MFMAs: in one instruction stream
 // the two serialise, in two streams on the same SIMD they overlap.
 template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, int NLD = 0>
-__global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr_gemm_args g, const int skew_mul, const int conv_korder) {
+__global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr_gemm_args g, const int skew_mul) {
   constexpr bool SPEC = NLD > 0;   // NLD loader waves behind the WM*WN compute waves
   static_assert(TMW == 4 || TMW == 8, "wave tile is 64x64 or 128x64");
   static_assert(!SPEC || (sizeof(T) == 2 && STAGES >= 3), "wave specialisation: bf16 path, >= 3 LDS stages");
@@ -579,14 +579,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     // 128-byte k-columns.  In lock step they would all hit the few L2 channels that one k-column of a matrix with a
     // power-of-two-ish leading dimension maps to (partition camping).  Only the fp32 summation order changes.
     const int kskew = (MB == COUNTR_OP_IM2COL || ntiles == 0) ? 0 : (int)(((unsigned)lt * (unsigned)skew_mul) % (unsigned)ntiles);
-    // implicit-GEMM convolutions walk K as (channel chunk outer, tap inner) although K is stored [tap][Cin]: the 9 taps of one
-    // 64-channel chunk re-read the same 128-byte line segments of neighbouring pixels back to back, so the live set of an XCD's
-    // resident workgroups stays well inside its 4 MB L2 (tap-major order cycles through ALL channels of ~4k pixels = the whole
-    // L2 between two uses of a line: PMC showed 6-12x the algorithmic bytes coming over the fabric).  Summation order only.
-    const bool conv_order = (MA == COUNTR_OP_IM2ROW) && !split && (g.Cin % BK == 0) && (kend - kstart == 9 * g.Cin) && conv_korder;
-    const int nchunk = conv_order ? g.Cin / BK : 1;
+    // (A channel-chunk-outer / tap-inner walk of the convolutions' k-tiles was tried for L2 locality and removed in round 2: FETCH_SIZE
+    // 122 vs 115 MB x 2 per launch and 376 vs 373 us -- no effect; fabric traffic is 1.6 x the algorithmic input either way,
+    // profiles/r2_gemm_conv192_pmc.txt.)
     auto ktile = [&](int t) {
-      if (conv_order) { const int c = t / 9, tap = t - c * 9; return kstart + (tap * nchunk + c) * BK; }
       int tt = t + kskew; if (tt >= ntiles) tt -= ntiles; return kstart + tt * BK;
     };
     constexpr int NLW = SPEC ? NLD : NW;   // waves that stage tiles
@@ -1125,8 +1121,7 @@ int launch_variant(const countr_gemm_args& a, hipStream_t s) {
     attr_set = true;
   }
   static const int skew = [] { const char* e = getenv("COUNTR_GEMM_SKEW"); return e ? atoi(e) : 0; }();
-  static const int korder = [] { const char* e = getenv("COUNTR_CONV_KORDER"); return e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, NLD>), grid, dim3(64 * (WM * WN + NLD)), lds_bytes, s, a, skew, korder);
+  hipLaunchKernelGGL((gemm_kernel<T, MA, MB, STAGES, WM, WN, TMW, NLD>), grid, dim3(64 * (WM * WN + NLD)), lds_bytes, s, a, skew);
   COUNTR_LAUNCH_CHECK("countr_gemm");
 }
 
