@@ -166,7 +166,7 @@ def bench_pretrain(args, world, rank, dev):
                                    "random masking + fwd + all-patch MSE + full bwd + AdamW" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
             "final_loss": lv, "step_tflops": PRETRAIN_GF_PER_IMG * ips / 1e12}))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -214,7 +214,7 @@ def bench_infer(args, world, rank, dev):
             "config": {"workload": "zero-shot inference ViT-B/16 (mae_vit_base_patch16), 8 frames x 4 windows = batch 32 per GPU, "
                                    "forward + sliding-window blend + counts", "global_batch": world * 32, "parallelism": "replicas%d" % world},
             "windows_per_sec": 4 * ips, "mean_count": float(cnt.mean().item()), "fwd_tflops": 180.89e9 * 4 * ips / 1e12}))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -249,7 +249,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)" % (args.gpus, world))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("COUNTR_BENCH_INIT_PG") == "1":   # (the last: one-rank RCCL dry run, tests/test_ddp_gpu.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -331,7 +331,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

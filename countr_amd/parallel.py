@@ -8,6 +8,7 @@ bucket but the last overlaps the rest of backward on a side stream.  Averaging (
 communicated (the reference's DDP buckets all 98.9 M parameters).  Device-agnostic: the same code runs over
 RCCL on GPUs and over gloo in the CPU tests.
 """
+import os
 import random
 
 import torch
@@ -36,15 +37,18 @@ class GradSync:
         self.buckets = list(buckets) if buckets is not None else [tuple(bucket0), tuple(bucket_rest)]
         self.group = group
         self.world = world_size(group)
+        # COUNTR_FORCE_COMM=1: issue the collectives even in a one-rank group (sum over one rank = identity).  A single-GPU box can
+        # then run the REAL RCCL path -- communicator set-up, side stream, ordering against the graph replays (tests/test_ddp_gpu.py)
+        self.comm = self.world > 1 or (os.environ.get("COUNTR_FORCE_COMM", "0") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = None
         self._started = set()
-        if self.world > 1 and flat_grad.is_cuda:
+        if self.comm and flat_grad.is_cuda:
             self.stream = torch.cuda.Stream(device=flat_grad.device)
 
     def start(self, i):
         """Call when the gradients of bucket i are final; returns immediately on GPU (side stream)."""
         self._started.add(i)
-        if self.world == 1:
+        if not self.comm:
             return
         s, e = self.buckets[i]
         if e <= s:
@@ -65,7 +69,7 @@ class GradSync:
         no gradient this step) in one collective per contiguous run, then joins the side stream."""
         pending = [i for i in range(len(self.buckets)) if i not in self._started and i not in skip]
         self._started = set()
-        if self.world == 1:
+        if not self.comm:
             return
         runs = []
         for i in pending:

@@ -71,10 +71,11 @@ def run_pretrain(rank, world, per_rank, use_graph=True):
 
 if __name__ == "__main__":
     what, outdir = sys.argv[1], sys.argv[2]
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    m, losses = (run_finetune if what == "finetune" else run_pretrain)(rank, world, 2)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    m, losses = (run_finetune if what == "finetune" else run_pretrain)(rank, world, 2 if world > 1 else 4)
     torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters()}, "losses": losses},
                os.path.join(outdir, "%s_rank%d.pt" % (what, rank)))
     dist.barrier()

@@ -13,17 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(what, outdir):
+def launch(what, outdir, nproc=2, backend="gloo", extra_env=None):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), what, str(outdir)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), what, str(outdir), backend]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return [torch.load(os.path.join(outdir, "%s_rank%d.pt" % (what, k)), weights_only=False) for k in range(2)]
+    return [torch.load(os.path.join(outdir, "%s_rank%d.pt" % (what, k)), weights_only=False) for k in range(nproc)]
 
 
 @pytest.mark.parametrize("what", ["finetune", "pretrain"])
@@ -56,3 +56,34 @@ def test_bench_self_launch_two_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["value"] > 0
+
+
+@pytest.mark.parametrize("what", ["finetune", "pretrain"])
+def test_rccl_path_with_one_rank(what, tmp_path):
+    """The REAL RCCL path on the single GPU: backend "nccl" (= RCCL), a one-rank group, COUNTR_FORCE_COMM=1 so that GradSync issues
+    every bucket all-reduce (communicator set-up, collectives on the side stream between the graph replays, joins) although the
+    sum over one rank is the identity.  Result must be bit-identical to the same step without any communication."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_gpu_worker as Wk
+    (r0,) = launch(what, tmp_path, nproc=1, backend="nccl", extra_env={"COUNTR_FORCE_COMM": "1"})
+    single, losses = (Wk.run_finetune if what == "finetune" else Wk.run_pretrain)(0, 1, 4)
+    assert r0["losses"] == losses
+    for k, p in single.named_parameters():
+        assert torch.equal(p.detach().cpu(), r0["params"][k]), k
+
+
+def test_bench_rccl_one_rank():
+    """bench.py through torch.distributed.run with backend nccl on one rank and forced collectives: the launch line the driver uses
+    for N > 1, exercised as far as one GPU allows."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0
