@@ -1,9 +1,12 @@
-// Generic MFMA GEMM for gfx950 (MI355X): one 128x128 block tile, 4 waves (2x2) of 64x64, register-
-// staged double-buffered LDS, one barrier per K tile.  Operands are addressed through four modes
-// (row / col / 3x3-im2col-row / 3x3-im2col-col) so that nn.Linear forward, dgrad and wgrad, the
-// unfused attention products and the 3x3 convolutions (fwd, dgrad, wgrad) all run on this kernel.
-//   bf16: v_mfma_f32_16x16x32_bf16, K-strided operands read with ds_read_b64_tr_b16
-//   fp32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain) for the parity mode
+// Generic MFMA GEMM for gfx950 (MI355X).  Operands are addressed through four modes (row / col / 3x3-im2col-row / 3x3-im2col-col) so
+// that nn.Linear forward, dgrad and wgrad, the unfused attention products and the 3x3 convolutions (fwd, dgrad, wgrad) all run here.
+//   bf16: v_mfma_f32_16x16x32_bf16; tiles go global -> LDS by LDS-DMA (global_load_lds, XOR swizzle on the source address),
+//         fragments come back with ds_read_b128 / ds_read_b64_tr_b16 issued from inline asm (counted lgkmcnt / vmcnt, one barrier
+//         per k-tile).  Variants (launch()): 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (big grids); the same tile
+//         wave-specialised -- 4 compute + 4 loader waves on a 3-stage ring -- for grids of <= 256 tiles; 128x256 with 8 + 4 waves
+//         for the 192x192 convolutions.  Epilogues (bias / GELU / fp32 residual / bf16 or fp32 out / pre-activation copy) are
+//         compile-time variants staged through LDS into whole-row-segment stores.
+//   fp32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain), register-staged padded tiles -- the parity mode.
 // Reference call sites: models_crossvit.py:62,65,84-92,115-127; models_mae_cross.py:47-100,138,152.
 #include "common.cuh"
 #include <type_traits>
@@ -675,30 +678,26 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         }
       };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>; using YES = std::true_type; using NO = std::false_type;
+    using YES = std::true_type; using NO = std::false_type;
     auto wait_frags = [&](auto S) {   // all LDS reads issued so far have landed (fragments of step S threaded through)
       constexpr int s = decltype(S)::value;
       lds_wait<0>(xf[s & 1], wf[s / NH]);
     };
     // steps 0 .. NS-2 of the tile whose step-0 fragments have been requested already
-    auto steps_but_last = [&](auto mid) {
+    auto steps_but_last = [&] {
       step(I0{}, I1{}, YES{});
       if constexpr (NS > 2) {
         step(I1{}, I1{}, YES{});
-        mid();
         step(I2{}, I1{}, YES{});
-      } else {
-        mid();
       }
     };
     // classic form: one whole tile, nothing in flight across its ends
-    auto mma_tile = [&](const char* sa_, const char* sb_, auto mid) {   // mid(): called between the two halves of the tile's steps
+    auto mma_tile = [&](const char* sa_, const char* sb_) {
       set_tile(sa_, sb_);
       request(I0{});
-      steps_but_last(mid);
+      steps_but_last();
       step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
     };
-    auto nomid = [] {};
     auto main_loop = [&](auto FAST) {
       constexpr bool fast = decltype(FAST)::value;
       auto issueA = [&](int k0, char* lds) {
@@ -715,7 +714,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         issueB(ktile(t), smem + SA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma_tile(smem, smem + SA, nomid);
+        mma_tile(smem, smem + SA);
         __builtin_amdgcn_s_barrier();  // all fragment reads of this tile are consumed before it is overwritten
       }
     } else if constexpr (SPEC) {
@@ -768,7 +767,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         }
         for (int t = 0; t + 1 < ntiles; ++t) {
           SSTAMP(ua);
-          steps_but_last(nomid);
+          steps_but_last();
           wait_frags(std::integral_constant<int, NS - 1>{});
           slot = (slot + 1 == STAGES) ? 0 : slot + 1;
           SSTAMP(ub);
@@ -781,7 +780,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
 #endif
         }
         if (ntiles > 0) {   // last tile: nothing follows
-          steps_but_last(nomid);
+          steps_but_last();
           step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
         }
       }
@@ -816,7 +815,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           issueA(ktile(t + STAGES - 1), nxt);
           issueB(ktile(t + STAGES - 1), nxt + SA);
         }
-        steps_but_last(nomid);
+        steps_but_last();
         step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
         slot = (slot + 1 == STAGES) ? 0 : slot + 1;
         islot = (islot + 1 == STAGES) ? 0 : islot + 1;
@@ -829,14 +828,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      // 8-wave workgroups (one per CU): waves w and w + 4 share a SIMD and run in lock step behind the per-tile barrier, so a
-      // DMA issue phase common to all waves leaves the matrix pipes of the whole CU idle.  The second wave group therefore issues
-      // its share of tile t+1 in the MIDDLE of tile t: while one wave of a SIMD spends its ~60 cycles per 1-KiB piece, the other
-      // one multiplies.
-#ifndef COUNTR_GEMM_STAGGER
-#define COUNTR_GEMM_STAGGER 1
-#endif
-      const bool late_group = COUNTR_GEMM_STAGGER && (NW == 8) && wv >= 4;
+      // (Letting the second wave group of an 8-wave workgroup issue its share of tile t+1 in the MIDDLE of tile t was measured on the
+      // experimental 256x256 tile and changes nothing: profiles/r2_gemm_256x256_experiment.txt.)
 #ifdef COUNTR_GEMM_STAMP   // s_memtime anatomy (tools/stamp_gemm.py): per-wave cycles in DMA issue / MFMA steps / load wait / barrier
       uint64_t tki = 0, tkm = 0, tkw = 0, tkb = 0;
       const uint64_t tk0 = __builtin_readcyclecounter();
@@ -857,9 +850,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         STAMP(ta);
         set_tile(smem + cur * (SA + SB), smem + cur * (SA + SB) + SA);
         request(I0{});                        // first fragments first: their LDS round trip runs under the DMA issue below
-        if (!late_group) issue_next();        // (one copy of the MFMA code: the branches wrap the DMA issue only)
+        issue_next();
         STAMP(tb);
-        steps_but_last([&] { if (late_group) issue_next(); });
+        steps_but_last();
         step(std::integral_constant<int, NS - 1>{}, I0{}, YES{});
         STAMP(tc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -160,7 +160,9 @@ class Engine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.CountrError("the CounTR HIP engine needs a GPU device (no CPU fallback)")
-        _lib.check(self.L.countr_init(self.device.index or 0), "countr_init")
+        if self.device.index is None:      # plain "cuda": the calling thread's current device (rank k of a multi-GPU job), not 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        _lib.check(self.L.countr_init(self.device.index), "countr_init")
         self.cfg = cfg
         self.patch, self.D, self.depth, self.H, self.Dd, self.ddepth, self.Hd = cfg
         check_supported(cfg, img_size)

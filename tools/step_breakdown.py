@@ -10,13 +10,17 @@ db = sys.argv[1]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 marker = sys.argv[3] if len(sys.argv) > 3 else "adamw_kernel"
 skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-c = sqlite3.connect(db)
-tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
-if "kernels" in tabs:
-    q = "select name, start, end, grid_x, workgroup_x, grid_z from kernels order by start"
+if db.endswith(".csv"):      # rocprofv3 --output-format csv: <name>_kernel_trace.csv
+    import csv
+    rows = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]),
+             int(r["Grid_Size_Z"])) for r in csv.DictReader(open(db))]
+    rows.sort(key=lambda r: r[1])
 else:
-    raise SystemExit("no kernels view in %s: %s" % (db, tabs))
-rows = list(c.execute(q))
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    if "kernels" not in tabs:
+        raise SystemExit("no kernels view in %s: %s" % (db, tabs))
+    rows = list(c.execute("select name, start, end, grid_x, workgroup_x, grid_z from kernels order by start"))
 ends = [i for i, r in enumerate(rows) if marker in r[0]]
 if skip:
     ends = ends[:-skip]
