@@ -185,16 +185,32 @@ class _GraphStep:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
             phases = self._phases(key)
-            for i, (name, fn, gkey) in enumerate(phases):
-                self._run_phase(name, fn, gkey)
-                if last and i + 1 < len(phases):
-                    self.sync.start(i)
-            if last:
-                touched = frozenset(self._touched)
-                self.sync.finish(skip=tuple(self._comm_skip(touched)))
-                skip, zero = self._adam_sets(touched)
-                self._upload_hyper(skip)
-                self._run_phase("c", self._phase_c, (tuple(skip), tuple(zero)))
+            if self.use_graph and not self.sync.comm:
+                # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
+                # costs ~20 us of idle GPU (4 launches per step before).  The AdamW scalars are uploaded first; only phase c reads them.
+                ckey = None
+                if last:
+                    skip, zero = self._adam_sets(frozenset(self._touched))
+                    self._upload_hyper(skip)
+                    ckey = (tuple(skip), tuple(zero))
+
+                def whole(k, phases=phases):
+                    for _name, fn, gkey in phases:
+                        fn(gkey)
+                    if k[1] is not None:
+                        self._phase_c(k[1])
+                self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), ckey))
+            else:
+                for i, (name, fn, gkey) in enumerate(phases):
+                    self._run_phase(name, fn, gkey)
+                    if last and i + 1 < len(phases):
+                        self.sync.start(i)
+                if last:
+                    touched = frozenset(self._touched)
+                    self.sync.finish(skip=tuple(self._comm_skip(touched)))
+                    skip, zero = self._adam_sets(touched)
+                    self._upload_hyper(skip)
+                    self._run_phase("c", self._phase_c, (tuple(skip), tuple(zero)))
         torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
         if last:
             self.model.mark_weights_synced()
