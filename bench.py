@@ -278,7 +278,7 @@ def main():
 
     def one(k, S):
         imgs, boxes, gt, _ = batches[k % NB]
-        mask = (torch.rand(384, 384, device=dev, generator=mgen) < 0.8).float()
+        mask = torch.empty(384, 384, device=dev).bernoulli_(0.8, generator=mgen)
         step.load(imgs, boxes, gt, mask, S)
         return step.step(S)
 
