@@ -1157,7 +1157,16 @@ int launch(const countr_gemm_args& a, hipStream_t s) {
     // (fc2 4608x768x3072 37.4 -> 28.3 us, (row, col) dgrads -20...-25 %, conv 24x24 54.6 -> 34.8 us; with two workgroups per CU
     // available the plain kernel is faster: fc1 35 vs 43 us).
     static const int spec_max = [] { const char* e = getenv("COUNTR_GEMM_SPEC_MAX"); return e ? atoi(e) : 256; }();
-    if (t128 <= spec_max && ktiles >= 3) return launch_variant<T, MA, MB, 3, 2, 2, 4, 4>(a, s);
+    if (t128 <= spec_max && ktiles >= 3) {
+      // convolution wgrad: the im2col gather costs its loader ~16 VALU instructions per 1-KiB piece (pixel coordinates, bounds, select)
+      // and with 4 loader waves the compute waves wait for them (stamps: loaders 1303 cycles of issue per k-tile, compute 1117 +
+      // 246 at the barrier): 8 loader waves halve the per-wave share (192^2 480 -> 463 us, 96^2 117 -> 107.5, 24^2 25.5 -> 24.2)
+      if constexpr (MB == COUNTR_OP_IM2COL) {
+        static const int nld = [] { const char* e = getenv("COUNTR_GEMM_WGRAD_LOADERS"); return e ? atoi(e) : 8; }();
+        if (nld == 8) return launch_variant<T, MA, MB, 3, 2, 2, 4, 8>(a, s);
+      }
+      return launch_variant<T, MA, MB, 3, 2, 2, 4, 4>(a, s);
+    }
   }
   return launch_variant<T, MA, MB, 2, 2, 2>(a, s);
 }
