@@ -788,16 +788,29 @@ class Engine:
             for i in (3, 2, 1, 0):
                 hn = "decode_head%d" % i
                 HW = hs[i] * hs[i]
+                # GroupNorm parameter gradients: with deferred reductions the per-block partials {dbeta, dgamma, dw1}[256] stay in this
+                # layer's own workspace and are summed by the table launch that finishes the layer's conv wgrad anyway (they used to
+                # be 2-3 colsum launches of 16 workgroups each: ~80 us per step of latency-bound finishers)
+                defer = self.defer_reduce
+                gws = self._shared("gnbw%d" % i, B * 64 * 3 * 256 + 64 + 16 * B) if defer else gn_ws
+                if defer:
+                    self._claim(gws.data_ptr())
+                gpar = lambda n: None if defer else self._gp(n)
                 if i == 3:
                     self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), None, d1.data_ptr(), self._pp(hn + ".3.weight"),
                              hstats[i].data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(),
-                             self._gp(hn + ".1.weight"), self._gp(hn + ".1.bias"), self._gp(hn + ".3.weight"), self._gp(hn + ".3.bias"),
-                             gn_ws.data_ptr(), B, HW, 256, 8, code, self._acc)
+                             gpar(hn + ".1.weight"), gpar(hn + ".1.bias"), gpar(hn + ".3.weight"), self._gp(hn + ".3.bias"),
+                             gws.data_ptr(), B, HW, 256, 8, code, self._acc)
                 else:
                     self._op(ops, L.countr_upsample2x_bwd, dup.data_ptr(), dact.data_ptr(), B, hs[i], hs[i], 256, code)
                     self._op(ops, L.countr_groupnorm_relu_bwd, hc[i].data_ptr(), dact.data_ptr(), None, None, hstats[i].data_ptr(),
-                             self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), self._gp(hn + ".1.weight"),
-                             self._gp(hn + ".1.bias"), None, None, gn_ws.data_ptr(), B, HW, 256, 8, code, self._acc)
+                             self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), gpar(hn + ".1.weight"),
+                             gpar(hn + ".1.bias"), None, None, gws.data_ptr(), B, HW, 256, 8, code, self._acc)
+                if defer:
+                    nsl = B * L.countr_groupnorm_nsplit(HW)
+                    planes = [(0, hn + ".1.bias"), (1, hn + ".1.weight")] + ([(2, hn + ".3.weight")] if i == 3 else [])
+                    for plane, pname in planes:
+                        self._reduce_later(ops, gws.data_ptr(), gws.data_ptr() + plane * 256 * 4, self._gp(pname), nsl, 3 * 256, 256)
                 big = hs[i] >= 96   # each of these kernels fills the GPU on its own: forking only adds contention
                 if not big:
                     self._fork(ops)
