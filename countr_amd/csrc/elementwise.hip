@@ -450,11 +450,19 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     if (threadIdx.x == 0) gnorm_ws[1 + blockIdx.x] = sq;
   }
 }
-__global__ void gnorm_finish_kernel(float* __restrict__ ws, int nb) {
-  float s = 0.f;
-  for (int i = threadIdx.x; i < nb; i += 64) s += ws[1 + i];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) ws[0] = sqrtf(s);
+__global__ __launch_bounds__(1024) void gnorm_finish_kernel(float* __restrict__ ws, int nb) {   // nb <= 2048 partials: two independent loads per thread
+  __shared__ float part[16];
+  const int t = threadIdx.x;
+  const float a = t < nb ? ws[1 + t] : 0.f, b = t + 1024 < nb ? ws[1 + t + 1024] : 0.f;
+  const float s = wave_sum(a + b);     // fixed summation tree: deterministic
+  if ((t & 63) == 0) part[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += part[k];
+    ws[0] = sqrtf(tot);
+  }
 }
 
 }  // namespace
@@ -595,7 +603,7 @@ extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, v
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   const int nb = nblocks(total, 256, 2048);
   hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev, gnorm_ws);
-  if (gnorm_ws) hipLaunchKernelGGL(gnorm_finish_kernel, dim3(1), dim3(64), 0, STREAM(stream), gnorm_ws, nb);
+  if (gnorm_ws) hipLaunchKernelGGL(gnorm_finish_kernel, dim3(1), dim3(1024), 0, STREAM(stream), gnorm_ws, nb);
   COUNTR_LAUNCH_CHECK("countr_adamw_step");
 }
 
