@@ -492,6 +492,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
   // stage s: A tile at smem + 2*s*OP_BYTES, B tile right behind it
 
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef COUNTR_GEMM_STAMP   // kernel-level timeline per workgroup (absolute s_memtime): entry, loop start, loop end, exit
+  const uint64_t tl_entry = __builtin_readcyclecounter();
+  uint64_t tl_loop0 = 0, tl_loop1 = 0, tl_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TLX(k) tl_x[k] = __builtin_readcyclecounter()
+#else
+#define TLX(k)
+#endif
   const bool loader_wave = SPEC && (tid >> 6) >= WM * WN;
   const int wave = loader_wave ? (tid >> 6) - WM * WN : (tid >> 6);   // index inside its role
   const int tilesN = (g.N + BNt - 1) / BNt;
@@ -559,6 +566,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     return MPERM ? (((2 * h + ((r >> 2) & 1)) >> 2) * 64 + (r >> 3) * 16 + ((2 * h + ((r >> 2) & 1)) & 3) * 4 + (r & 3)) : (h * 32 + r);
   };
   resid4_t rpre[RPRE_OK ? 2 : 1][RPRE_OK ? 8 : 1];
+  TLX(0);
   if constexpr (RPRE_OK) {
     if (resid_pre) {
 #pragma unroll
@@ -591,8 +599,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     constexpr int NLW = SPEC ? NLD : NW;   // waves that stage tiles
     DmaLoader<MA, BMt, NLW> la;
     DmaLoader<MB, BNt, NLW> lb;
+    TLX(1);
     la.init(dA, m0, kstart, wv, lane);
     lb.init(dB, n0, kstart, wv, lane);
+    TLX(2);
     // uniform-base addressing when every k-tile of this launch is full and the operands span < 4 GiB (see DmaLoader); the
     // whole main loop is instantiated twice so that the fast variant carries no per-lane pointer selects
     const bool fullk = ((kend - kstart) % BK) == 0;
@@ -870,7 +880,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
 #endif
     }
     };
+#ifdef COUNTR_GEMM_STAMP
+    tl_loop0 = __builtin_readcyclecounter();
+#endif
     if (fast_addr) main_loop(std::true_type{}); else main_loop(std::false_type{});
+#ifdef COUNTR_GEMM_STAMP
+    tl_loop1 = __builtin_readcyclecounter();
+#endif
     // deep rings have no barrier behind the last tile: one here (all waves, loaders included) frees the ring for the staged epilogue
     if constexpr (STAGES >= 3) __builtin_amdgcn_s_barrier();
     if (loader_wave) return;   // no barrier after this point
@@ -967,6 +983,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
       bv[tn][0] = bv[tn][1] = bv[tn][2] = bv[tn][3] = 0.f;
       if (has_bias && nb + tn * 4 < g.N) ld4<float>(g.bias + nb + tn * 4, bv[tn]);
     }
+    TLX(3);
     if constexpr (!GENERIC && sizeof(T) == 2 && (TMW % 2 == 0)) {
       // Staged epilogue: a lane's natural stores are 8-byte (bf16) / 16-byte (fp32) pieces of 16 different rows per instruction
       // (4 lanes share a row): measured 8-24 % of a forward GEMM (COUNTR_ABL=5).  Instead the wave writes 32 rows x 64 columns of
@@ -1007,6 +1024,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
+          if (h == 0) TLX(4);
 #pragma unroll
           for (int j = 0; j < (32 * CPRW) / 64; ++j) {
             const int idx = lane + 64 * j, r = idx / CPRW, cc = idx % CPRW;
@@ -1037,7 +1055,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
+          if (h == 0) TLX(5);
         }
+        TLX(6);
         return;
       }
     }
@@ -1098,6 +1118,17 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     else if (g.act == COUNTR_ACT_NONE && !hb && hr) epilogue(false_type{}, true_type{}, A0{}, false_type{}, false_type{});
     else epilogue(false_type{}, false_type{}, A0{}, false_type{}, true_type{});
   }
+#ifdef COUNTR_GEMM_STAMP
+  if (g.nbatch == 1 && g.sC1 && tid == 0) {   // [workgroup][4] x uint64 behind the per-wave records (float offset 400000)
+    uint64_t* t = reinterpret_cast<uint64_t*>(reinterpret_cast<float*>(g.sC1) + 400000) + (int64_t)blockIdx.x * 4;
+    const uint64_t tl_pre = __builtin_readcyclecounter();   // before waiting for the store acknowledgements
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t[0] = tl_entry; t[1] = tl_loop0; t[2] = tl_loop1; t[3] = __builtin_readcyclecounter();
+    uint64_t* x = reinterpret_cast<uint64_t*>(reinterpret_cast<float*>(g.sC1) + 500000) + (int64_t)blockIdx.x * 8;
+    for (int k = 0; k < 7; ++k) x[k] = tl_x[k];
+    x[7] = tl_pre;
+  }
+#endif
 }
 
 template <typename T, int MA, int MB, int STAGES, int WM, int WN, int TMW = 4, int NLD = 0>
