@@ -95,6 +95,39 @@ def test_finetune_cli_with_augmentation(tmp_path):
     assert r.returncode != 0 and "class_file" in r.stderr
 
 
+def test_demo_zero_cli(tmp_path):
+    """demo_zero.py (reference flags): a directory of frames, counts printed per image, viz_<name>.jpg written at the input size;
+    the windows of all frames share forwards and give the same counts as one image per forward."""
+    import re
+    from PIL import Image
+    src = tmp_path / "frames"
+    src.mkdir()
+    rs = np.random.RandomState(3)
+    sizes = {"a.jpg": (640, 360), "b.png": (960, 540), "c.png": (500, 384), "d.png": (300, 600)}     # d: narrower than a window
+    for name, (w, h) in sizes.items():
+        Image.fromarray(rs.randint(0, 255, size=(h, w, 3)).astype(np.uint8)).save(src / name)
+    counts = {}
+    for grp in ("8", "1"):
+        out = tmp_path / ("out" + grp)
+        log = run(["demo_zero.py", "--input_path", str(src), "--output_path", str(out), "--model_path", "", "--precision", "fp32",
+                   "--group_images", grp])
+        got = dict(re.findall(r"\] (\S+):\tcount =\s*([-0-9.]+)", log))
+        assert set(got) == set(sizes), log
+        counts[grp] = {k: float(v) for k, v in got.items()}
+        for name, (w, h) in sizes.items():
+            viz = out / ("viz_%s.jpg" % name.split(".")[0])
+            assert viz.exists() and Image.open(viz).size == (w, h)
+    assert counts["8"]["d.png"] == 0.0                       # 192 px wide after the resize: the window loop never runs
+    for k in sizes:
+        assert abs(counts["8"][k] - counts["1"][k]) <= 0.01 + 1e-3 * abs(counts["1"][k]), (k, counts)
+    # single file + a missing checkpoint fails like the reference's torch.load
+    log = run(["demo_zero.py", "--input_path", str(src / "a.jpg"), "--output_path", str(tmp_path / "o"), "--model_path", "", "--no_viz"])
+    assert log.startswith("Count:") or "Count:" in log
+    r = subprocess.run([sys.executable, "demo_zero.py", "--input_path", str(src / "a.jpg"), "--model_path", "/nonexistent.pth"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+
+
 def test_pretrain_cli_on_files_and_synthetic_fallback(fake_fsc, tmp_path):
     out = str(tmp_path / "pre")
     log = run(["FSC_pretrain.py", "--data_path", fake_fsc, "--batch_size", "2", "--epochs", "1", "--warmup_epochs", "0",
