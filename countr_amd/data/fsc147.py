@@ -413,6 +413,16 @@ class TrainData(Dataset):
     def open_image(self, im_id):
         return _open_rgb(os.path.join(self.im_dir, im_id))
 
+    def _worker_nprng(self):
+        """numpy generator of THIS loader process for the augmentation draws.  DataLoader seeds `random` and torch per worker but
+        not numpy: with the global np.random every worker would draw the same noise / jitter / affine sequence (the reference's
+        np.random.normal has exactly that flaw; its torchvision / imgaug draws do not)."""
+        pid = os.getpid()
+        if getattr(self, "_nprng_pid", None) != pid:
+            self._nprng_pid = pid
+            self._nprng = np.random.RandomState(torch.initial_seed() % (2 ** 32))
+        return self._nprng
+
     def __len__(self):
         return len(self.img)
 
@@ -425,7 +435,7 @@ class TrainData(Dataset):
         if self.split != "train":
             s = transform_val(image, rects, dots)
         elif self.do_aug:
-            s = transform_train_aug(image, rects, dots, im_id, self)
+            s = transform_train_aug(image, rects, dots, im_id, self, nprng=self._worker_nprng())
         else:
             s = transform_train_noaug(image, rects, dots)
         return s["image"], s["gt_density"], len(dots), s["boxes"], s["pos"], s["m_flag"], im_id
