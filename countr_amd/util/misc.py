@@ -28,9 +28,13 @@ def init_distributed_mode(args):
         args.world_size = int(os.environ["WORLD_SIZE"])
         args.gpu = int(os.environ.get("LOCAL_RANK", 0))
         args.distributed = True
+        # COUNTR_DIST_BACKEND=gloo: dry run of an N-rank job on fewer GPUs (RCCL refuses two ranks per device); ranks then share devices
+        backend = os.environ.get("COUNTR_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            args.gpu %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(args.gpu)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size,
+        dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size,
                                 rank=args.rank)
         dist.barrier()
     else:

@@ -95,6 +95,34 @@ def test_finetune_cli_with_augmentation(tmp_path):
     assert r.returncode != 0 and "class_file" in r.stderr
 
 
+def test_finetune_cli_two_ranks_on_one_gpu(tmp_path):
+    """FSC_finetune_cross.py under torch.distributed.run with two ranks sharing the GPU (COUNTR_DIST_BACKEND=gloo): env-driven init,
+    DistributedSampler shards, the m_flag MAX all-reduce of the mosaic rule, gradient all-reduce inside the step, loss / validation
+    metric reductions, rank-0-only checkpoints (util/misc.py:225-257, FSC_finetune_cross.py:178-183,230,276-284)."""
+    import socket
+    from oracle import weights as W
+    root = str(tmp_path / "data")
+    W.write_aug_dataset(root)
+    out = str(tmp_path / "ft")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), "FSC_finetune_cross.py", "--data_path", root, "--anno_file", "anno.json", "--data_split_file", "split.json", "--im_dir",
+           "images", "--class_file", "classes.txt", "--batch_size", "1", "--epochs", "2", "--warmup_epochs", "0", "--num_workers", "0",
+           "--output_dir", out, "--resume", "", "--log_every", "1", "--blr", "1e-3"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 6 and all(np.isfinite(l["loss"]) for l in lines)      # 6 images / (2 ranks x batch 1) = 3 steps x 2 epochs, rank 0 logs
+    # as in the reference, every rank evaluates ITS shard of the validation split and prints its own line (no reduction;
+    # FSC_finetune_cross.py:329-350,421-422), and rank 0's figure selects the minMAE checkpoint
+    assert len([l for l in r.stdout.splitlines() if l.startswith("[Val Epoch #")]) == 4
+    assert os.path.exists(os.path.join(out, "checkpoint__finetuning_last.pth"))
+    assert os.path.exists(os.path.join(out, "checkpoint__finetuning_minMAE.pth"))
+
+
 def test_demo_zero_cli(tmp_path):
     """demo_zero.py (reference flags): a directory of frames, counts printed per image, viz_<name>.jpg written at the input size;
     the windows of all frames share forwards and give the same counts as one image per forward."""
