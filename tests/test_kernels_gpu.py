@@ -426,3 +426,26 @@ def test_flash_attention_bwd(hip, B, N, H, dh):
     assert torch.isfinite(dqkv.float()).all()
     for slot, name in enumerate(("dq", "dk", "dv")):
         assert relerr(dqkv[:, :, slot], x.grad[:, :, slot]) < 2.5e-2, name   # bf16 P/dS operands and bf16 outputs
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_conv_shadows_permutations(hip, dt):
+    """countr_conv_shadows: torch OIHW conv weights -> the forward operand [Co][tap][Ci] (OHWI) and the dgrad operand
+    [Ci][8 - tap][Co] (transposed, taps reversed: the flipped kernel of the transposed convolution), several convolutions per
+    launch, ragged channel counts included (tiles are 32 x 32)."""
+    import ctypes as C
+    shapes = [(256, 512), (128, 64), (40, 24), (33, 65)]
+    ws = [torch.randn(co, ci, 3, 3, device="cuda") for co, ci in shapes]
+    wf = [torch.full((co, 9, ci), float("nan"), device="cuda", dtype=dt) for co, ci in shapes]
+    wd = [torch.full((ci, 9, co), float("nan"), device="cuda", dtype=dt) for co, ci in shapes]
+    n = len(shapes)
+    vp, ip = C.c_void_p * n, C.c_int * n
+    _lib.check(hip.countr_conv_shadows(n, vp(*[w.data_ptr() for w in ws]), vp(*[w.data_ptr() for w in wf]), vp(*[w.data_ptr() for w in wd]),
+                                       ip(*[s[0] for s in shapes]), ip(*[s[1] for s in shapes]), ip(*[9] * n), 1 if dt == torch.bfloat16 else 0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv_shadows")
+    torch.cuda.synchronize()
+    for w, f, d in zip(ws, wf, wd):
+        co, ci = w.shape[:2]
+        ref_f = w.reshape(co, ci, 9).permute(0, 2, 1).to(dt)
+        ref_d = w.reshape(co, ci, 9).flip(2).permute(1, 2, 0).to(dt)
+        assert torch.equal(f, ref_f) and torch.equal(d, ref_d)
