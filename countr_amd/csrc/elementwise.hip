@@ -344,22 +344,23 @@ struct ConvShadowTable {
   void* wd[8];
   int co[8], ci[8], taps[8];
 };
-// One block = a 32 (co) x 32 (ci) tile of one convolution with all its taps: the torch OIHW source [co][ci][tap] is read as 32 runs of
-// 32 x taps contiguous floats, the OHWI form [co][tap][ci] is written with ci fastest and the dgrad form [ci][taps-1-tap][co] -- the
-// transpose -- with co fastest out of LDS, so all three streams are coalesced (the element-per-thread version gathered the source
-// with a 36-byte stride and paid six integer divisions per element: 36 us per step for 4.5 M weights).
+// One block = a 32 (co) x 8 (ci) tile of one convolution with all its taps: the torch OIHW source [co][ci][tap] is read as 32 runs of
+// 8 x taps contiguous floats, the OHWI form [co][tap][ci] is written with ci fastest and the dgrad form [ci][taps-1-tap][co] -- the
+// transpose -- with co fastest out of LDS (the element-per-thread version gathered the source with a 36-byte stride and paid six
+// integer divisions per element).  Small tiles on purpose: the whole job is 4.5 M weights, so it needs many short blocks, not few long ones.
+constexpr int CS_CI = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void conv_shadows_kernel(const ConvShadowTable t) {
-  __shared__ float tile[32][32 * 9 + 1];
+  __shared__ float tile[32][CS_CI * 9 + 1];
   const int e = blockIdx.y;
   const int Co = t.co[e], Ci = t.ci[e], taps = t.taps[e];
-  const int tiles_ci = (Ci + 31) / 32, ntiles = ((Co + 31) / 32) * tiles_ci;
+  const int tiles_ci = (Ci + CS_CI - 1) / CS_CI, ntiles = ((Co + 31) / 32) * tiles_ci;
   const float* __restrict__ src = t.src[e];
   T* __restrict__ wf = reinterpret_cast<T*>(t.wf[e]);
   T* __restrict__ wd = reinterpret_cast<T*>(t.wd[e]);
-  const int run = 32 * taps;                      // floats per co row of the tile (taps <= 9)
+  const int run = CS_CI * taps;                   // floats per co row of the tile (taps <= 9)
   for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-    const int co0 = (tl / tiles_ci) * 32, ci0 = (tl % tiles_ci) * 32;
+    const int co0 = (tl / tiles_ci) * 32, ci0 = (tl % tiles_ci) * CS_CI;
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * run; i += 256) {
       const int r = i / run, c = i - r * run;     // c = ci_local * taps + tap
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_shadows_kernel(const ConvShadowTable
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * run; i += 256) {
       {  // OHWI [Co][tap][Ci]: lanes walk ci
-        const int cl = i & 31, rt = i >> 5, tap = rt % taps, r = rt / taps;
+        const int cl = i % CS_CI, rt = i / CS_CI, tap = rt % taps, r = rt / taps;
         const int co = co0 + r, ci = ci0 + cl;
         if (co < Co && ci < Ci) stf<T>(wf + ((int64_t)co * taps + tap) * Ci + ci, tile[r][cl * taps + tap]);
       }
@@ -590,7 +591,7 @@ extern "C" int countr_conv_shadows(int n, const float* const* src, void* const* 
   }
   for (int i = 0; i < n; ++i)
     if (taps[i] > 9) { countr_set_error("countr_conv_shadows: at most 9 taps"); return -1; }
-  dim3 grid(nblocks(big, 32 * 32 * 9, 512), n);   // one block per 32 x 32 x taps tile of the largest convolution
+  dim3 grid(nblocks(big, 32 * CS_CI * 9, 1024), n);   // one block per 32 x 8 x taps tile of the largest convolution
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv_shadows_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), t);
   else hipLaunchKernelGGL(conv_shadows_kernel<float>, grid, dim3(256), 0, STREAM(stream), t);
   COUNTR_LAUNCH_CHECK("countr_conv_shadows");
