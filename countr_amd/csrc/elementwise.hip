@@ -29,6 +29,25 @@ __global__ void im2patch_kernel(const float* __restrict__ img, T* __restrict__ o
   }
 }
 
+// patch sizes that are a multiple of 8 (ViT-B/16): 8 consecutive px per thread -- two 16-byte reads, one 16 / 32-byte store, 32-bit
+// index arithmetic once per 8 elements (the scalar kernel pays five 64-bit divisions per element: 18 us for the 8 x 384 x 384 batch)
+template <typename T>
+__global__ __launch_bounds__(256) void im2patch_vec8_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W,
+                                                            int p, int gh, int gw) {
+  const int p8 = p >> 3, K8 = 3 * p * p8;                // 8-element groups per patch row / per token
+  const int total = B * gh * gw * K8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k8 = i % K8, t = i / K8;
+    const int j = t % gw, t2 = t / gw, ii = t2 % gh, b = t2 / gh;
+    const int c = k8 / (p * p8), r = k8 - c * p * p8, py = r / p8, px = (r - py * p8) << 3;
+    const float* src = img + (((int64_t)b * 3 + c) * H + ii * p + py) * W + j * p + px;
+    float v[8];
+    ld4<float>(src, *reinterpret_cast<float(*)[4]>(v));
+    ld4<float>(src + 4, *reinterpret_cast<float(*)[4]>(v + 4));
+    st8<T>(out + (int64_t)i * 8, v);
+  }
+}
+
 // ---------------- first exemplar conv: in fp32 NCHW [S,3,H,W], w fp32 [64,3,3,3], out NHWC [S,H,W,64]
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
@@ -496,6 +515,12 @@ extern "C" int countr_im2patch(const float* img, void* out, int B, int H, int W,
   if (!img || !out || patch <= 0) { countr_set_error("countr_im2patch: bad args"); return -1; }
   const int gh = H / patch, gw = W / patch;
   const int64_t total = (int64_t)B * gh * gw * 3 * patch * patch;
+  if ((patch & 7) == 0 && (W & 3) == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 31) == 0 && total / 8 < (int64_t)0x7fffffff) {
+    const int nb = nblocks(total / 8);
+    if (dtype == COUNTR_BF16) hipLaunchKernelGGL(im2patch_vec8_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), img, (bf16_t*)out, B, H, W, patch, gh, gw);
+    else hipLaunchKernelGGL(im2patch_vec8_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), img, (float*)out, B, H, W, patch, gh, gw);
+    COUNTR_LAUNCH_CHECK("countr_im2patch");
+  }
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(im2patch_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), img, (bf16_t*)out, B, H, W, patch, gh, gw);
   else hipLaunchKernelGGL(im2patch_kernel<float>, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), img, (float*)out, B, H, W, patch, gh, gw);
   COUNTR_LAUNCH_CHECK("countr_im2patch");
