@@ -76,6 +76,21 @@ def test_forward_fp32_matches_reference_golden(fp32_model, name):
     assert np.abs(cnt - np.array(meta["count_" + name])).max() < 0.5
 
 
+def test_forward_fp32_batch8_matches_oracle(fp32_model):
+    """BASELINE config 2's batch (B = 8, 3 exemplars) in the fp32 parity mode against the oracle on the same inputs: the goldens stop
+    at B = 2, and batch 8 takes other tile / split-K choices through the same kernels."""
+    m, sd = fp32_model
+    imgs, boxes, _gt, _mask = W.make_inputs(batch=8, shots=3, seed=21)
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    with torch.no_grad():
+        ref = R.forward(sd, imgs, boxes, 3).numpy()
+    with torch.no_grad():
+        out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3).cpu().numpy()
+    assert out.shape == (8, 384, 384)
+    assert rel(out, ref) < 1e-3, rel(out, ref)
+    assert np.abs(out.reshape(8, -1).sum(1) / 60 - ref.reshape(8, -1).sum(1) / 60).max() < 0.5
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_forward_bf16_close_to_reference_golden(bf16_model, name):
     m, _ = bf16_model
