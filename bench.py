@@ -27,7 +27,6 @@ MFMA_BF16_PEAK = 2.5e15
 def cpu_baseline(batch=4, steps=4, threads=None):
     """The oracle (CPU restatement of the reference, validated against it) timed on this host's cores.
     Threads are capped at 32: torch-CPU on all 256 hardware threads of the GPU box is ~100x slower (oversubscription)."""
-    import numpy as np
     from oracle import countr_ref as R, weights as W
     threads = threads or min(os.cpu_count(), 32)
     torch.set_num_threads(threads)

@@ -5,10 +5,8 @@ Mirrors the hot loop of the reference (FSC_finetune_cross.py:265-319; util/misc.
 per-step host syncs; bf16 needs no GradScaler.  With use_graph=True each phase is captured once per shot_num into a
 hipGraph and replayed (torch.cuda.CUDAGraph is only the capture/replay handle; every node is one of our kernels).
 """
-import ctypes as C
 
 import torch
-import torch.distributed as dist
 
 from . import _lib
 from .parallel import GradSync
