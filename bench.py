@@ -88,6 +88,8 @@ def attention_roofline(model, batch, iters=20, instep_passes=6):
         empty.append(z0.elapsed_time(z1) * 1e3)
     med = lambda v: sorted(v)[len(v) // 2]
     us = med(with_att) - med(without)
+    if not us > 0.25 * med(direct):      # (never seen) a disturbed run: fall back to the plain bracket rather than report nonsense
+        us = med(direct)
     one = []
     eng._attention_fwd(one, p, p.buf["qkv"], p.buf["att"], batch, eng.H, eng.D, prescaled=eng.prescale_q)
     for _ in range(3):
