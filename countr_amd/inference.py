@@ -46,22 +46,65 @@ def _bucket(n, max_batch):
     return min(b, max_batch)
 
 
+def blend_windows_batched(outputs, starts, width, height=384):
+    """blend_windows for n images of the SAME width at once: outputs [n, len(starts), height, 384] -> [n, height, width].  The
+    same sequential arithmetic per image (previously covered columns: old / 2 + new / 2), one set of launches for all of them."""
+    n = outputs.shape[0]
+    dm = torch.zeros(n, height, width, device=outputs.device, dtype=outputs.dtype)
+    prev = -1
+    for k, start in enumerate(starts):
+        out = outputs[:, k]
+        ov = prev - start + 1
+        if ov > 0:
+            dm[:, :, start:prev + 1] = dm[:, :, start:prev + 1] / 2 + out[:, :, :ov] / 2
+        dm[:, :, prev + 1:start + 384] = out[:, :, max(ov, 0):]
+        prev = start + 383
+    return dm
+
+
 @torch.no_grad()
 def density_maps(model, images, boxes, shot_num, max_batch=32):
     """Stitched densities of SEVERAL images in as few forwards as possible: images = [[1, 3, 384, w_i], ...], boxes = per image
     [1, >= shot_num, 3, 64, 64] (anything when shot_num == 0) -> [[384, w_i], ...].  Every 384-px window of every image is an
     independent forward of the reference (FSC_test_cross(few-shot).py:326-349, demo_zero.py:49-72), so the windows of all images
-    are concatenated and run in chunks of up to max_batch (zero-shot 1920x1080 frames: 8 images x 4 windows = one batch of 32)."""
+    are concatenated and run in chunks of up to max_batch (zero-shot 1920x1080 frames: 8 images x 4 windows = one batch of 32).
+    Images of equal width (video frames) are cut into windows and blended together: one strided copy per window position and one
+    blend pass for the whole group instead of one per image (the per-image torch launches were ~10 % of the 8-frame call)."""
     shot_num = int(shot_num)
     dev = images[0].device
+    h = images[0].shape[-2]
     plan = [(i, s) for i, im in enumerate(images) for s in window_starts(im.shape[-1])]
+    # runs of consecutive images with one width: (first image, count, width).  Their windows are consecutive rows of the plan
+    # (image-major), so window position k of the whole run is the strided slice rows[k::nwin] -- no index tensors, no host sync
+    runs, i = [], 0
+    while i < len(images):
+        j = i
+        while j + 1 < len(images) and images[j + 1].shape[-1] == images[i].shape[-1]:
+            j += 1
+        runs.append((i, j - i + 1, images[i].shape[-1]))
+        i = j + 1
+    first_row, r = {}, 0
+    for i, im in enumerate(images):
+        first_row[i] = r
+        r += len(window_starts(im.shape[-1]))
+    stacked = {i0: torch.cat(images[i0:i0 + n], 0) for i0, n, w in runs if n > 1 and window_starts(w)}
     outs = []
     for c0 in range(0, len(plan), max_batch):
         chunk = plan[c0:c0 + max_batch]
         nb = _bucket(len(chunk), max_batch)
-        wins = torch.zeros(nb, 3, images[0].shape[-2], 384, device=dev, dtype=torch.float32)
-        for j, (i, s) in enumerate(chunk):
-            wins[j] = images[i][0, :, :, s:s + 384]
+        wins = torch.zeros(nb, 3, h, 384, device=dev, dtype=torch.float32)
+        done = set()
+        for i0, n, w in runs:                    # whole runs that lie inside this chunk: one strided copy per window position
+            st = window_starts(w)
+            r0 = first_row[i0] - c0
+            if i0 not in stacked or r0 < 0 or r0 + n * len(st) > len(chunk):
+                continue
+            for k, s0 in enumerate(st):
+                wins[r0 + k:r0 + n * len(st):len(st)] = stacked[i0][:, :, :, s0:s0 + 384]
+            done.update(range(r0, r0 + n * len(st)))
+        for j, (i, s0) in enumerate(chunk):
+            if j not in done:
+                wins[j] = images[i][0, :, :, s0:s0 + 384]
         if shot_num > 0:
             bx = torch.zeros(nb, shot_num, 3, 64, 64, device=dev, dtype=torch.float32)
             for j, (i, _s) in enumerate(chunk):
@@ -69,16 +112,21 @@ def density_maps(model, images, boxes, shot_num, max_batch=32):
         else:
             bx = torch.zeros(nb, 0, device=dev)
         outs.append(model(wins, bx, shot_num)[:len(chunk)].clone())
-    outs = torch.cat(outs, 0) if outs else None
-    res, k = [], 0
-    for i, im in enumerate(images):
-        h, w = im.shape[-2], im.shape[-1]
+    outs = torch.cat(outs, 0) if len(outs) > 1 else (outs[0] if outs else None)
+    res = [None] * len(images)
+    for i0, n, w in runs:
         starts = window_starts(w)
         if not starts:
-            res.append(torch.zeros(h, w, device=dev))       # narrower than a window: the reference's loop never runs
+            for i in range(i0, i0 + n):
+                res[i] = torch.zeros(h, w, device=dev)      # narrower than a window: the reference's loop never runs
             continue
-        res.append(blend_windows(outs[k:k + len(starts)], starts, w, h))
-        k += len(starts)
+        k0 = first_row[i0]
+        if n > 1:
+            dm = blend_windows_batched(outs[k0:k0 + n * len(starts)].view(n, len(starts), h, 384), starts, w, h)
+            for k in range(n):
+                res[i0 + k] = dm[k]
+        else:
+            res[i0] = blend_windows(outs[k0:k0 + len(starts)], starts, w, h)
     return res
 
 
