@@ -234,8 +234,13 @@ class MaeEngine(Engine):
         B, N = ids_shuffle.shape
         K = p.buf["keep_src"].numel() // B
         ids_shuffle = ids_shuffle.to(self.device, torch.int64)
-        ids_restore = torch.argsort(ids_shuffle, dim=1)
-        base = torch.arange(B, device=self.device).unsqueeze(1)
+        cache = p.buf.get("_mask_consts")
+        if cache is None or cache[0].shape[0] != B:
+            cache = p.buf["_mask_consts"] = (torch.arange(B, device=self.device).unsqueeze(1),
+                                             torch.arange(N, device=self.device).unsqueeze(0).expand(B, N).contiguous())
+        base, pos = cache
+        # ids_restore = argsort(ids_shuffle) (models_mae_noct.py:122) is the inverse permutation: one scatter instead of a second sort
+        ids_restore = torch.empty_like(ids_shuffle).scatter_(1, ids_shuffle, pos)
         keep = ids_shuffle[:, :K]
         p.buf["keep_pos"].copy_(keep.reshape(-1))
         p.buf["keep_src"].copy_((keep + base * N).reshape(-1))
