@@ -99,6 +99,7 @@ _SIGS = {
     "countr_masked_mse_workspace_floats": [_i],
     "countr_masked_mse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "countr_adamw_gnorm_floats": [],
+    "countr_splitk_finish": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "countr_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp],
 }
 _RESTYPES = {"countr_xattn_bwd_workspace_floats": C.c_int64}

@@ -214,6 +214,7 @@ class Engine:
         # 6.20 ms serial (graph fork/join + the CNN's workgroups displacing GEMM tiles), forward only 3.13 vs 3.16 ms: off by
         # default, COUNTR_OVERLAP_EXEMPLAR=1 enables it
         self.overlap_exemplar = os.environ.get("COUNTR_OVERLAP_EXEMPLAR", "0") == "1"
+        self.act_splitk = os.environ.get("COUNTR_ACT_SPLITK", "1") != "0"     # split-K + finisher for few-tile, long-K forward GEMMs
 
     def _make_layout(self, named_shapes):
         return ParamLayout(named_shapes)
@@ -571,11 +572,30 @@ class Engine:
                    sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
         self._join(ops)
 
-    # 3x3 conv (NHWC, pad 1) as implicit GEMM
+    def _act_splitk(self, M, N, K):
+        """Split-K factor for a forward-type GEMM (bf16 mode): launches with few 128x128 tiles and a long K leave most CUs idle behind
+        a serial k loop (decode_head0 forward: 72 tiles x 72 k-tiles = 44 us; exemplar conv4 dgrad: 24 x 72 = 43 us); cutting K over
+        the idle CUs + one finisher pass (countr_splitk_finish) is 2-3x faster there.  1 = no split."""
+        if self.code != BF16 or not self.act_splitk:
+            return 1
+        tiles = -(-M // 128) * -(-N // 128)
+        ktiles = K // 64
+        if tiles > 96 or ktiles < 24:
+            return 1
+        return max(1, min(8, 256 // tiles, ktiles // 8))
+
+    # 3x3 conv (NHWC, pad 1) as implicit GEMM (forward, and dgrad with the dgrad-form weights)
     def _conv_fwd(self, ops, x, w_ohwi, bias_ptr, out, Bn, H, W, Cin, Cout):
+        M, K = Bn * H * W, 9 * Cin
+        sk = self._act_splitk(M, Cout, K)
+        if sk > 1:
+            part = self._shared("actsk", sk * M * Cout)
+            self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), partial=part.data_ptr(), ldb=K, ldc=Cout,
+                       M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, splitk=sk)
+            self._op(ops, self.L.countr_splitk_finish, part.data_ptr(), out.data_ptr(), bias_ptr, sk, M, Cout, int(out.dtype == torch.bfloat16))
+            return
         self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), C=out.data_ptr(), bias=bias_ptr,
-                   ldb=9 * Cin, ldc=Cout, M=Bn * H * W, N=Cout, K=9 * Cin, H=H, W=W, Cin=Cin,
-                   out_bf16=int(out.dtype == torch.bfloat16))
+                   ldb=K, ldc=Cout, M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, out_bf16=int(out.dtype == torch.bfloat16))
 
     def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout, bias_name=None):
         bk = 64 if self.code == BF16 else 32
@@ -896,9 +916,7 @@ class Engine:
                                  ws.data_ptr(), BS, 64, 64, code, self._acc)
                     else:
                         self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i], bias_name=wn[:-6] + "bias")
-                        self._gemm(ops, code, OP_IM2ROW, OP_ROW, A=dc[i].data_ptr(), B=self.Wd[wn].data_ptr(), C=dpl[i - 1].data_ptr(),
-                                   ldb=9 * chans[i], ldc=chans[i - 1], M=BS * sizes[i] * sizes[i], N=chans[i - 1], K=9 * chans[i],
-                                   H=sizes[i], W=sizes[i], Cin=chans[i], out_bf16=int(code == BF16))
+                        self._conv_fwd(ops, dc[i], self.Wd[wn], None, dpl[i - 1], BS, sizes[i], sizes[i], chans[i], chans[i - 1])
             self._flush_reductions(p)
         self._acc = 0
         return p

@@ -88,6 +88,12 @@ int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void
 int countr_splitk_reduce(const float* partial, float* out, int splitk, int M, int N, int perm_taps,
                          int accumulate, const float* rowsum_partial, float* rowsum_out, void* stream);
 
+/* Finisher of a split-K GEMM whose result is an ACTIVATION (forward / dgrad with few tiles and a long K, e.g. the 24x24 and 8x8
+ * convolutions: Conv2d forward models_mae_cross.py:47-100 and its input gradient): out[M][N] (fp32 or bf16, dense) =
+ * sum_z partial[z][M][N] (+ bias[n]).  N % 4 == 0. */
+int countr_splitk_finish(const float* partial, void* out, const float* bias, int splitk, int M, int N, int out_bf16,
+                         void* stream);
+
 /* Many deferred slab reductions in ONE launch (the wgrad / bias-gradient / LayerNorm dgamma-dbeta finishers of a backward phase;
  * replaces the per-parameter accumulation of autograd's AccumulateGrad nodes, util/misc.py:266-280 loss_scaler -> backward()).
  * table: device int64 [n][8] rows {partial (const float*), out (float*), nslabs | accumulate << 32 | wide << 33, slab stride

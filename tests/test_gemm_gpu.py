@@ -379,3 +379,31 @@ def test_reduce_table_matches_individual_reductions(hip):
     torch.cuda.synchronize()
     for i, (out, ref) in enumerate(checks):
         assert (out - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0), i
+
+
+@pytest.mark.parametrize("obf", [0, 1])
+def test_splitk_finish_matches_unsplit_conv(hip, obf):
+    """Forward-type split-K (few tiles, long K: the 24x24 / 8x8 convolutions of the bf16 engine): implicit-GEMM conv with
+    splitk = 4 into fp32 partials + countr_splitk_finish (sum, bias, output dtype) against the same conv in one launch."""
+    Bn, H, W, Cin, Cout = 3, 8, 8, 512, 256
+    x = _mk((Bn, H, W, Cin), torch.bfloat16, 31)
+    w = _mk((Cout, 9 * Cin), torch.bfloat16, 32) * 0.05
+    bias = _mk((Cout,), torch.float32, 33)
+    M, K = Bn * H * W, 9 * Cin
+    odt = torch.bfloat16 if obf else torch.float32
+    ref = torch.empty((M, Cout), device="cuda", dtype=odt)
+    a = _lib.GemmArgs(); a.alpha = 1.0; a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    a.A, a.B, a.C, a.bias = x.data_ptr(), w.data_ptr(), ref.data_ptr(), bias.data_ptr()
+    a.ldb, a.ldc, a.M, a.N, a.K, a.H, a.W, a.Cin, a.out_bf16 = K, Cout, M, Cout, K, H, W, Cin, obf
+    _lib.check(hip.countr_gemm(C.byref(a), 1, 2, 0, _stream()), "gemm")
+    part = torch.full((4, M, Cout), float("nan"), device="cuda")
+    out = torch.full((M, Cout), float("nan"), device="cuda", dtype=odt)
+    b = _lib.GemmArgs(); b.alpha = 1.0; b.nbatch = 1; b.nb1 = 1; b.splitk = 4
+    b.A, b.B, b.partial = x.data_ptr(), w.data_ptr(), part.data_ptr()
+    b.ldb, b.ldc, b.M, b.N, b.K, b.H, b.W, b.Cin = K, Cout, M, Cout, K, H, W, Cin
+    _lib.check(hip.countr_gemm(C.byref(b), 1, 2, 0, _stream()), "gemm split")
+    _lib.check(hip.countr_splitk_finish(part.data_ptr(), out.data_ptr(), bias.data_ptr(), 4, M, Cout, obf, _stream()), "finish")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    scale = ref.float().abs().max().item()
+    assert (out.float() - ref.float()).abs().max().item() <= (8e-3 if obf else 2e-5) * scale
