@@ -572,22 +572,21 @@ class Engine:
                    sC0=N * 3 * Dm, sC1=dh, out_bf16=ob, **nb)
         self._join(ops)
 
-    def _act_splitk(self, M, N, K):
-        """Split-K factor for a forward-type GEMM (bf16 mode): launches with few 128x128 tiles and a long K leave most CUs idle behind
-        a serial k loop (decode_head0 forward: 72 tiles x 72 k-tiles = 44 us; exemplar conv4 dgrad: 24 x 72 = 43 us); cutting K over
-        the idle CUs + one finisher pass (countr_splitk_finish) is 2-3x faster there.  1 = no split."""
-        if self.code != BF16 or not self.act_splitk:
+    def _act_splitk(self, HW, K):
+        """Split-K factor for a forward-type convolution (bf16 mode).  On the small maps (<= 24x24 per image) the implicit GEMM has
+        few 128x128 tiles and a long K -- decode_head0 forward: 72 tiles x 72 k-tiles = 44 us on a quarter of the CUs; exemplar conv4
+        dgrad: 24 x 72 = 43 us -- so K is cut over the idle CUs and a finisher pass (countr_splitk_finish) adds the slabs.  The factor
+        depends on the LAYER only (map size, K), never on the batch: the fp32 summation tree of a sample is the same in every batch
+        (tests/test_properties_gpu.py: sample i alone == sample i in a batch, bit for bit).  1 = no split."""
+        if self.code != BF16 or not self.act_splitk or HW > 576:
             return 1
-        tiles = -(-M // 128) * -(-N // 128)
         ktiles = K // 64
-        if tiles > 96 or ktiles < 24:
-            return 1
-        return max(1, min(8, 256 // tiles, ktiles // 8))
+        return 8 if ktiles >= 64 else (4 if ktiles >= 32 else 1)
 
     # 3x3 conv (NHWC, pad 1) as implicit GEMM (forward, and dgrad with the dgrad-form weights)
     def _conv_fwd(self, ops, x, w_ohwi, bias_ptr, out, Bn, H, W, Cin, Cout):
         M, K = Bn * H * W, 9 * Cin
-        sk = self._act_splitk(M, Cout, K)
+        sk = self._act_splitk(H * W, K)
         if sk > 1:
             part = self._shared("actsk", sk * M * Cout)
             self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), partial=part.data_ptr(), ldb=K, ldc=Cout,
