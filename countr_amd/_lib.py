@@ -81,7 +81,7 @@ _SIGS = {
     "countr_softmax_bwd": [_vp, _vp, _vp, _i64, _i, _f, _i, _vp],
     "countr_xattn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "countr_xattn_bwd_workspace_floats": [_i, _i, _i, _i],
-    "countr_xattn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_xattn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "countr_im2patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "countr_conv3x3_c3_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "countr_conv3x3_c3_wgrad_nblocks": [],

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const T* __restrict__ q,
 
 // dkv[b][which][j][:] = sum over the blocks of batch b
 __global__ void xattn_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dk, float* __restrict__ dv,
-                                        int blocks_per_b, int S, int D) {
+                                        bf16_t* __restrict__ dk_bf16, bf16_t* __restrict__ dv_bf16, int blocks_per_b, int S, int D) {
   const int b = blockIdx.y;
   const int tot = 2 * S * D;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,6 +216,8 @@ __global__ void xattn_bwd_finish_kernel(const float* __restrict__ partial, float
   const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   const int which = i / (S * D), r = i - which * S * D;
   (which == 0 ? dk : dv)[(int64_t)b * S * D + r] = s;
+  bf16_t* const t = which == 0 ? dk_bf16 : dv_bf16;    // optional bf16 copy: the operand of the wk / wv wgrad and dgrad GEMMs
+  if (t) t[(int64_t)b * S * D + r] = f2bf(s);
 }
 
 }  // namespace
@@ -257,7 +259,7 @@ extern "C" int64_t countr_xattn_bwd_workspace_floats(int B, int N, int S, int D)
 // dk, dv: fp32 [B, S, D] (overwritten)
 extern "C" int countr_xattn_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, float* dk, float* dv,
                                 float* workspace, int B, int N, int S, int D, int heads, int ldkv, float scale, int dtype,
-                                void* stream) {
+                                void* dk_bf16, void* dv_bf16, void* stream) {
   if (!q || !k || !v || !dout || !dq || !dk || !dv || !workspace || S < 1 || S > XS || D != 512 || heads * 32 != D) { countr_set_error("countr_xattn_bwd: bad args"); return -1; }
   const int bpb = (N + XATTN_ROWS_PER_BLOCK - 1) / XATTN_ROWS_PER_BLOCK;
   const size_t lds = (size_t)4 * 2 * S * D * sizeof(float);
@@ -276,6 +278,7 @@ extern "C" int countr_xattn_bwd(const void* q, const void* k, const void* v, con
   if (dtype == COUNTR_BF16) COUNTR_XB_DISPATCH(bf16_t); else COUNTR_XB_DISPATCH(float);
 #undef COUNTR_XB_DISPATCH
 #undef COUNTR_XB_LAUNCH
-  hipLaunchKernelGGL(xattn_bwd_finish_kernel, dim3((2 * S * D + 255) / 256, B), dim3(256), 0, STREAM(stream), workspace, dk, dv, bpb, S, D);
+  hipLaunchKernelGGL(xattn_bwd_finish_kernel, dim3((2 * S * D + 255) / 256, B), dim3(256), 0, STREAM(stream), workspace, dk, dv,
+                     (bf16_t*)dk_bf16, (bf16_t*)dv_bf16, bpb, S, D);
   COUNTR_LAUNCH_CHECK("countr_xattn_bwd");
 }

@@ -872,11 +872,11 @@ class Engine:
                 # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
                 self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
                 self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
-                         dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code)
+                         dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code,
+                         dkT.data_ptr() if dkT is not None else None, dvT.data_ptr() if dvT is not None else None)
                 self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
                 g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=gxT)
-                dk_t = self._cast(ops, dk, dkT, B * Sy * Dd)
-                dv_t = self._cast(ops, dv, dvT, B * Sy * Dd)
+                dk_t, dv_t = (dk, dv) if dkT is None else (dkT, dvT)    # bf16 copies come out of the cross-attention backward
                 for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
                     self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
                     self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,

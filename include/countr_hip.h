@@ -167,9 +167,10 @@ int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, i
 int countr_xattn_fwd(const void* q, const void* k, const void* v, void* out, int B, int N, int S, int D,
                      int heads, int ldkv, float scale, int dtype, void* stream);
 int64_t countr_xattn_bwd_workspace_floats(int B, int N, int S, int D);
+/* dk / dv: fp32 [B*S, D]; dk_bf16 / dv_bf16 (optional): bf16 copies of the same sums -- the operands of the wk / wv backward GEMMs */
 int countr_xattn_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, float* dk,
                      float* dv, float* workspace, int B, int N, int S, int D, int heads, int ldkv, float scale,
-                     int dtype, void* stream);
+                     int dtype, void* dk_bf16, void* dv_bf16, void* stream);
 
 /* -------- data movement / elementwise */
 /* timm PatchEmbed gather (models_mae_cross.py:138): img fp32 NCHW -> patches [B*gh*gw, 3*p*p], k=(c,py,px) */

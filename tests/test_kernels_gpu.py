@@ -192,7 +192,10 @@ def test_cross_attention_fwd_bwd(hip, S, tdt, code, tol):
     dq = torch.empty_like(qd)
     dk = torch.empty((B, S, D), device="cuda"); dv = torch.empty((B, S, D), device="cuda")
     ws = torch.empty(hip.countr_xattn_bwd_workspace_floats(B, N, S, D), device="cuda")
-    _lib.check(hip.countr_xattn_bwd(P(qd), P(kd), P(vd), P(dod), P(dq), P(dk), P(dv), P(ws), B, N, S, D, Hh, D, scale, code, st()))
+    dkb = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16); dvb = torch.empty_like(dkb)
+    _lib.check(hip.countr_xattn_bwd(P(qd), P(kd), P(vd), P(dod), P(dq), P(dk), P(dv), P(ws), B, N, S, D, Hh, D, scale, code, P(dkb), P(dvb), st()))
+    torch.cuda.synchronize()
+    assert torch.equal(dkb, dk.to(torch.bfloat16)) and torch.equal(dvb, dv.to(torch.bfloat16))     # the optional bf16 copies
     oref.backward(do.double())
     assert relerr(dq, qr.grad) < tol
     assert relerr(dk, kr.grad) < 1e-3 and relerr(dv, vr.grad) < 1e-3
