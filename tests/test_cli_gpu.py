@@ -104,15 +104,19 @@ def test_finetune_cli_two_ranks_on_one_gpu(tmp_path):
     root = str(tmp_path / "data")
     W.write_aug_dataset(root)
     out = str(tmp_path / "ft")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), "FSC_finetune_cross.py", "--data_path", root, "--anno_file", "anno.json", "--data_split_file", "split.json", "--im_dir",
-           "images", "--class_file", "classes.txt", "--batch_size", "1", "--epochs", "2", "--warmup_epochs", "0", "--num_workers", "0",
-           "--output_dir", out, "--resume", "", "--log_every", "1", "--blr", "1e-3"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_DIST_BACKEND="gloo"))
+    def cmd():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                str(port), "FSC_finetune_cross.py", "--data_path", root, "--anno_file", "anno.json", "--data_split_file", "split.json", "--im_dir",
+                "images", "--class_file", "classes.txt", "--batch_size", "1", "--epochs", "2", "--warmup_epochs", "0", "--num_workers", "0",
+                "--output_dir", out, "--resume", "", "--log_every", "1", "--blr", "1e-3"]
+    for _attempt in range(2):        # one more try on another port if the process group fails to come up
+        r = subprocess.run(cmd(), cwd=ROOT, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_DIST_BACKEND="gloo"))
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 6 and all(np.isfinite(l["loss"]) for l in lines)      # 6 images / (2 ranks x batch 1) = 3 steps x 2 epochs, rank 0 logs

@@ -13,16 +13,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(what, outdir, nproc=2, backend="gloo", extra_env=None):
+def run_retry(make_cmd, env, attempts=2):
+    """Multi-process launches rendezvous over a fresh local port; a transient start-up failure of the process group (seen once in
+    ~30 runs on the GPU pool: RCCL communicator set-up) gets one more attempt on another port before the test fails."""
+    r = None
+    for _ in range(attempts):
+        r = subprocess.run(make_cmd(), cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        if r.returncode == 0:
+            break
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+def free_port():
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), what, str(outdir), backend]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return sk.getsockname()[1]
+
+
+def launch(what, outdir, nproc=2, backend="gloo", extra_env=None):
+    cmd = lambda: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                   "--master-port", str(free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), what, str(outdir), backend]
+    run_retry(cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {})))
     return [torch.load(os.path.join(outdir, "%s_rank%d.pt" % (what, k)), weights_only=False) for k in range(nproc)]
 
 
@@ -51,9 +64,8 @@ def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` started like the N = 1 run (no torch.distributed.run) re-launches itself with one rank per
     requested GPU and reports n_gpus = 2 (gloo on the single GPU of this box)."""
     import json
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r = run_retry(lambda: [sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                  dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["value"] > 0
 
@@ -76,14 +88,8 @@ def test_bench_rccl_one_rank():
     """bench.py through torch.distributed.run with backend nccl on one rank and forced collectives: the launch line the driver uses
     for N > 1, exercised as far as one GPU allows."""
     import json
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1"))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cmd = lambda: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                   "--master-port", str(free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    r = run_retry(cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1"))
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0
