@@ -431,8 +431,8 @@ class Engine:
         """Split-K factor of a wgrad GEMM: as many slabs as keep the launch within 256 workgroups, i.e. one wave-specialised
         workgroup per CU (measured against the former 512-workgroup target: finetune step -2 %, pretrain step -6 %, and fewer
         fp32 slabs to reduce)."""
-        if 128 < tiles <= 256:      # one slab would leave CUs idle, two make a 2-workgroup-per-CU launch of the plain kernel
-            return min(2, ktiles)    # (fc1 wgrad 3072x768, 144 tiles: 26.5 vs 29.1 us)
+        # (round 1 gave 129..256-tile wgrads two slabs on the plain kernel -- fc1 wgrad 3072x768, 144 tiles: 26.5 vs 29.1 us; since the
+        # wave-specialised loop hides its first-fragment latency one slab wins: 24.5 vs 28.1 us, MAE pretrain step 8.78 -> 8.66 ms)
         return max(1, min(64, ktiles, 256 // max(tiles, 1)))
 
     # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
