@@ -210,10 +210,10 @@ class Engine:
         self._sides = None
         # fork/join of the independent backward branches (wgrad | dgrad | bias grad): measured a wash (9.62 vs 9.56 ms); COUNTR_PARALLEL_LANES=1
         self.parallel_lanes = os.environ.get("COUNTR_PARALLEL_LANES", "0") == "1"
-        # forward: exemplar CNN (small launches) on a side lane beside the encoder.  Measured on MI355X at B = 8: finetune step 6.45 vs
-        # 6.20 ms serial (graph fork/join + the CNN's workgroups displacing GEMM tiles), forward only 3.13 vs 3.16 ms: off by
-        # default, COUNTR_OVERLAP_EXEMPLAR=1 enables it
-        self.overlap_exemplar = os.environ.get("COUNTR_OVERLAP_EXEMPLAR", "0") == "1"
+        # forward: the exemplar CNN (~20 launches of fewer than 200 workgroups, ~0.25 ms serial) runs on a side lane beside the encoder.
+        # Round 1 measured this as a loss (6.45 vs 6.20 ms, four graph launches per step); with the whole step in ONE graph it
+        # gains 50-70 us per step at B = 8 (5.63 -> 5.57 ms, three A/B pairs on one box).  COUNTR_OVERLAP_EXEMPLAR=0 serialises again.
+        self.overlap_exemplar = os.environ.get("COUNTR_OVERLAP_EXEMPLAR", "1") != "0"
         self.act_splitk = os.environ.get("COUNTR_ACT_SPLITK", "1") != "0"     # split-K + finisher for few-tile, long-K forward GEMMs
 
     def _make_layout(self, named_shapes):
