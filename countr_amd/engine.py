@@ -346,6 +346,8 @@ class Engine:
         for fn, args, _keep in ops:
             if fn is None:
                 kind = args[0]
+                if kind == "tokready":
+                    continue
                 if kind[0] == "x":           # forward overlap of the exemplar CNN with the encoder (overlap_exemplar)
                     if not self.overlap_exemplar:
                         continue
@@ -374,6 +376,24 @@ class Engine:
             rc = fn(*args, st)
             if rc != 0:
                 _lib.check(rc, getattr(fn, "__name__", "countr op"))
+
+    def run_backward_rest_and_tok(self, lists):
+        """bwd_rest followed by bwd_tok -- or, in bf16 mode with lanes enabled, the exemplar-token backward (~20 launches of fewer than
+        200 workgroups, serial in their own dependency chain) on a side lane beside what is left of the decoder-block backward once
+        dy_tok is final (block 0's self-attention backward and decoder_embed).  The two branches share no scratch buffer in bf16 mode
+        (fp32 mode's unfused bias gradients use one column-sum workspace: it stays serial).  Only for a step without a collective
+        between the two lists (one rank)."""
+        m = next((k for k, op in enumerate(lists.bwd_rest) if op[0] is None and op[1][0] == "tokready"), None)
+        if m is None or not self.overlap_exemplar or self.code != BF16 or os.environ.get("COUNTR_OVERLAP_TOKBWD", "1") == "0":
+            self.run(lists.bwd_rest)
+            self.run(lists.bwd_tok)
+            return
+        comb = getattr(lists, "_bwd_comb", None)
+        if comb is None:
+            mark = lambda *a: (None, a, None)
+            comb = lists._bwd_comb = (lists.bwd_rest[:m] + [mark("xfork"), mark("xlane", 1)] + lists.bwd_tok + [mark("xlane", 0)]
+                                      + lists.bwd_rest[m + 1:] + [mark("xjoin")])
+        self.run(comb)
 
     # ---- deferred reductions: the split-K slabs of a wgrad, the fused bias-gradient row sums and the LayerNorm dgamma / dbeta block
     # partials are not finished by one ~5-9 us launch each but collected per launch list and summed by ONE table-driven launch
@@ -882,6 +902,8 @@ class Engine:
                     self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,
                                        resid=(None if first_tok else dy_tok), out_bf16=False)
                     first_tok = False
+                if i == 0:
+                    ops.append((None, ("tokready",), None))   # dy_tok is final: the exemplar-token backward may start (run_backward_rest_and_tok)
                 # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
                 self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
                 if d["lse"] is not None:

@@ -82,6 +82,11 @@ class _GraphStep:
     def _phases(self, key):     # [(name, launcher, graph key)]: forward + loss + first backward part, then the remaining backward parts
         raise NotImplementedError
 
+    def _run_phases_merged(self, phases):
+        """All phases of a (micro-)step back to back (one rank: nothing to exchange between them)."""
+        for _name, fn, gkey in phases:
+            fn(gkey)
+
     def _comm_skip(self, touched):
         """Gradient buckets that are not all-reduced in this step (nobody has a gradient for them)."""
         return ()
@@ -193,8 +198,7 @@ class _GraphStep:
                     ckey = (tuple(skip), tuple(zero))
 
                 def whole(k, phases=phases):
-                    for _name, fn, gkey in phases:
-                        fn(gkey)
+                    self._run_phases_merged(phases)
                     if k[1] is not None:
                         self._phase_c(k[1])
                 self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), ckey))
@@ -269,6 +273,18 @@ class FinetuneStep(_GraphStep):
     def _phase_b2(self, key):
         S, acc = key
         self.eng.run(self._lists(self.eng.plan(self.B, S, True), acc).bwd_tok)
+
+    def _run_phases_merged(self, phases):
+        """a, then b and b2 together: the exemplar-token backward runs beside the tail of the decoder-block backward."""
+        (_a, fa, ka), (_b, _fb, (S, acc)), (_b2, _fb2, (_S2, acc_tok)) = phases
+        fa(ka)
+        p = self.eng.plan(self.B, S, True)
+        rest, tok = self._lists(p, acc), self._lists(p, acc_tok)
+        if rest is tok:
+            self.eng.run_backward_rest_and_tok(rest)
+        else:                                        # (gradient accumulation with a changing shot_num: the two lists differ in their accumulate flags)
+            self.eng.run(rest.bwd_rest)
+            self.eng.run(tok.bwd_tok)
 
     def _phases(self, S):
         acc = int(self._micro > 0)
