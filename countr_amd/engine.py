@@ -727,6 +727,16 @@ class Engine:
                 last = i == 3
                 self._op(ops, L.countr_instnorm_relu_pool_fwd, c[i].data_ptr(), (ytok if last else pl[i]).data_ptr(), stats[i].data_ptr(),
                          BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code, in_ws.data_ptr())
+        # the cross-attention keys / values depend on the exemplar tokens only: all blocks' wk / wv projections (tiny GEMMs, 4 tiles each)
+        # follow the tokens directly -- with exemplars that is inside the side lane that runs beside the encoder
+        kv = []
+        for i in range(self.ddepth):
+            b = "decoder_blocks.%d" % i
+            k_, v_ = A(b + ".k", (B * Sy, Dd), T), A(b + ".v", (B * Sy, Dd), T)
+            self._linear(ops, ytok, b + ".attn.wk.weight", k_, B * Sy, Dd, Dd)
+            self._linear(ops, ytok, b + ".attn.wv.weight", v_, B * Sy, Dd, Dd)
+            kv.append((k_, v_))
+        if S > 0:
             p.ex_range = (ex0, len(ops))
         blk = []
         for i in range(self.ddepth):
@@ -748,13 +758,10 @@ class Engine:
             d["n1"] = A(b + ".n1", (rows, Dd), T)
             d["m1"], d["r1"] = A(b + ".m1", (rows,), f32), A(b + ".r1", (rows,), f32)
             d["q"] = A(b + ".q", (rows, Dd), T)
-            d["k"] = A(b + ".k", (B * Sy, Dd), T)
-            d["v"] = A(b + ".v", (B * Sy, Dd), T)
+            d["k"], d["v"] = kv[i]
             d["xo"] = A(b + ".xo", (rows, Dd), T)
             self._layernorm(ops, x1, b + ".norm1", d["n1"], rows, Dd, d["m1"], d["r1"])
             self._linear(ops, d["n1"], b + ".attn.wq.weight", d["q"], rows, Dd, Dd)
-            self._linear(ops, ytok, b + ".attn.wk.weight", d["k"], B * Sy, Dd, Dd)
-            self._linear(ops, ytok, b + ".attn.wv.weight", d["v"], B * Sy, Dd, Dd)
             self._op(ops, L.countr_xattn_fwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), d["xo"].data_ptr(), B, N, Sy, Dd,
                      Hd, Dd, (Dd // Hd) ** -0.5, code)
             x2 = A(b + ".x2", (rows, Dd), f32)
