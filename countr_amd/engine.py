@@ -703,10 +703,12 @@ class Engine:
         self._linear(ops, latent, "decoder_embed.weight", xs[0], rows, Dd, D, resid=self._pp("decoder_pos_embed"), res_mod=N)
         ytok = A("ytok", (B * Sy, Dd), T)
         if S == 0:
-            # y = shot_token broadcast over the batch (models_mae_cross.py:176): gemm-free broadcast via cast with ld trick
-            for b_ in range(B):
-                self._op(ops, L.countr_cast_permute, self._pp("shot_token"), ytok.data_ptr() + b_ * Dd * ytok.element_size(), Dd, 0, 0,
-                         0, 0, code)
+            # y = shot_token broadcast over the batch (models_mae_cross.py:176): ONE row gather with an all-zero index (it was one cast
+            # launch per batch element: 32 tiny launches in front of every B = 32 inference forward)
+            zidx = A("ytok_idx", (B,), torch.int32)
+            if not self._sizing:
+                zidx.zero_()
+            self._op(ops, L.countr_gather_rows, self._pp("shot_token"), zidx.data_ptr(), ytok.data_ptr(), None, None, 0, B, Dd, F32, code)
         else:
             ex0 = len(ops)
             BS = B * S
