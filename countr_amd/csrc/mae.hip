@@ -83,6 +83,41 @@ __global__ __launch_bounds__(256) void patch_mse_finish_kernel(const float* __re
   if (threadIdx.x == 0) loss[0] = a * inv;
 }
 
+// All index buffers of random_masking (models_mae_noct.py:119-132) from ids_shuffle [B][N] (the argsort of the noise) in one launch:
+// thread (b, j) with s = ids_shuffle[b][j]: ids_restore[b][s] = j (the inverse permutation = argsort(ids_shuffle), :122); kept tokens
+// (j < K): keep_pos = s, keep_src = s + b N, restore_src[b N + s] = j + b K, mask = 0; masked ones: mask_src[b (N-K) + j-K] = s + b N,
+// restore_src[b N + s] = -1 (-> mask_token in the unshuffle gather), mask = 1.
+__global__ __launch_bounds__(256) void mae_indices_kernel(const long long* __restrict__ ids_shuffle, long long* __restrict__ ids_restore,
+                                                          int* __restrict__ keep_pos, int* __restrict__ keep_src,
+                                                          int* __restrict__ restore_src, int* __restrict__ mask_src,
+                                                          float* __restrict__ mask, int B, int N, int K) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * N) return;
+  const int b = i / N, j = i - b * N;
+  const int s = (int)ids_shuffle[i];
+  ids_restore[b * N + s] = j;
+  if (j < K) {
+    keep_pos[b * K + j] = s;
+    keep_src[b * K + j] = s + b * N;
+    restore_src[b * N + s] = j + b * K;
+    mask[b * N + s] = 0.f;
+  } else {
+    mask_src[b * (N - K) + j - K] = s + b * N;
+    restore_src[b * N + s] = -1;
+    mask[b * N + s] = 1.f;
+  }
+}
+
+extern "C" int countr_mae_indices(const long long* ids_shuffle, long long* ids_restore, int* keep_pos, int* keep_src, int* restore_src,
+                                  int* mask_src, float* mask, int B, int N, int K, void* stream) {
+  if (!ids_shuffle || !ids_restore || !keep_pos || !keep_src || !restore_src || !mask || B < 1 || N < 1 || K < 1 || K > N || (K < N && !mask_src)) {
+    countr_set_error("countr_mae_indices: bad args"); return -1;
+  }
+  hipLaunchKernelGGL(mae_indices_kernel, dim3((B * N + 255) / 256), dim3(256), 0, STREAM(stream), ids_shuffle, ids_restore, keep_pos,
+                     keep_src, restore_src, mask_src, mask, B, N, K);
+  COUNTR_LAUNCH_CHECK("countr_mae_indices");
+}
+
 extern "C" int countr_gather_rows(const void* src, const int* idx, void* dst, const float* default_row, const float* add, int add_mod,
                                   int rows, int cols, int src_dtype, int dst_dtype, void* stream) {
   if (!src || !dst || rows < 1 || cols < 4 || (cols & 3)) { countr_set_error("countr_gather_rows: null pointer or cols not a multiple of 4"); return -1; }

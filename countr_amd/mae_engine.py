@@ -230,24 +230,15 @@ class MaeEngine(Engine):
     # ------------------------------------------------------------------ execution API
     def set_masking(self, p, ids_shuffle):
         """ids_shuffle [B, N] (argsort of the per-sample noise, models_mae_noct.py:119-121) -> the plan's index buffers
-        and the binary mask (:128-132).  Index arithmetic only (torch int ops on tiny tensors)."""
+        and the binary mask (:128-132): one launch (countr_mae_indices; it was ~14 torch int ops on tiny tensors per step)."""
         B, N = ids_shuffle.shape
         K = p.buf["keep_src"].numel() // B
-        ids_shuffle = ids_shuffle.to(self.device, torch.int64)
-        cache = p.buf.get("_mask_consts")
-        if cache is None or cache[0].shape[0] != B:
-            cache = p.buf["_mask_consts"] = (torch.arange(B, device=self.device).unsqueeze(1),
-                                             torch.arange(N, device=self.device).unsqueeze(0).expand(B, N).contiguous())
-        base, pos = cache
-        # ids_restore = argsort(ids_shuffle) (models_mae_noct.py:122) is the inverse permutation: one scatter instead of a second sort
-        ids_restore = torch.empty_like(ids_shuffle).scatter_(1, ids_shuffle, pos)
-        keep = ids_shuffle[:, :K]
-        p.buf["keep_pos"].copy_(keep.reshape(-1))
-        p.buf["keep_src"].copy_((keep + base * N).reshape(-1))
-        p.buf["restore_src"].copy_(torch.where(ids_restore < K, ids_restore + base * K, torch.full_like(ids_restore, -1)).reshape(-1))
-        if K < N:
-            p.buf["mask_src"].copy_((ids_shuffle[:, K:] + base * N).reshape(-1))
-        p.buf["mask"].copy_((ids_restore >= K).float())
+        ids_shuffle = ids_shuffle.to(self.device, torch.int64).contiguous()
+        ids_restore = torch.empty_like(ids_shuffle)
+        _lib.check(self.L.countr_mae_indices(ids_shuffle.data_ptr(), ids_restore.data_ptr(), p.buf["keep_pos"].data_ptr(),
+                                             p.buf["keep_src"].data_ptr(), p.buf["restore_src"].data_ptr(),
+                                             p.buf["mask_src"].data_ptr() if K < N else None, p.buf["mask"].data_ptr(), B, N, K,
+                                             self._stream()), "mae_indices")
         return ids_restore
 
     def loss_launch(self, p, B, norm_pix, grad_scale=1.0, with_grad=True):

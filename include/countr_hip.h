@@ -224,6 +224,12 @@ int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow
  * default_row/add may be NULL, add_mod <= 0 means add[r,:].  cols % 4 == 0; src/dst dtype codes independent.  Covers
  * random_masking's gather of kept tokens (:125-126), the unshuffle with mask tokens + decoder_pos_embed (:166-172) and
  * the backward of both. */
+/* index buffers of random_masking (:119-132) from ids_shuffle [B][N] int64 (argsort of the noise): ids_restore [B][N] int64 (its
+ * inverse permutation), keep_pos / keep_src [B*K] int32 (kept token = position s, row s + b N of the patch matrix), restore_src
+ * [B*N] int32 (row of the kept-token matrix, or -1 = mask token), mask_src [B*(N-K)] int32 (rows of the masked tokens; may be NULL
+ * when K == N), mask [B*N] fp32 (1 = masked). */
+int countr_mae_indices(const long long* ids_shuffle, long long* ids_restore, int* keep_pos, int* keep_src, int* restore_src,
+                       int* mask_src, float* mask, int B, int N, int K, void* stream);
 int countr_gather_rows(const void* src, const int* idx, void* dst, const float* default_row, const float* add, int add_mod,
                        int rows, int cols, int src_dtype, int dst_dtype, void* stream);
 /* forward_loss (:181-198): target = patchify(imgs) in (py,px,c) order (:84-96), optional norm_pix (unbiased var, eps 1e-6),
