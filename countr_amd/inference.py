@@ -92,7 +92,7 @@ def density_maps(model, images, boxes, shot_num, max_batch=32):
     for c0 in range(0, len(plan), max_batch):
         chunk = plan[c0:c0 + max_batch]
         nb = _bucket(len(chunk), max_batch)
-        wins = torch.zeros(nb, 3, h, 384, device=dev, dtype=torch.float32)
+        wins = (torch.empty if nb == len(chunk) else torch.zeros)(nb, 3, h, 384, device=dev, dtype=torch.float32)   # padding rows only need defined values
         done = set()
         for i0, n, w in runs:                    # whole runs that lie inside this chunk: one strided copy per window position
             st = window_starts(w)
@@ -111,7 +111,8 @@ def density_maps(model, images, boxes, shot_num, max_batch=32):
                 bx[j] = boxes[i][0, :shot_num]
         else:
             bx = torch.zeros(nb, 0, device=dev)
-        outs.append(model(wins, bx, shot_num)[:len(chunk)].clone())
+        o = model(wins, bx, shot_num)[:len(chunk)]
+        outs.append(o.clone() if c0 + max_batch < len(plan) else o)    # the engine's output buffer lives until the next forward
     outs = torch.cat(outs, 0) if len(outs) > 1 else (outs[0] if outs else None)
     res = [None] * len(images)
     for i0, n, w in runs:
