@@ -379,8 +379,8 @@ class Engine:
 
     def run_backward_rest_and_tok(self, lists):
         """bwd_rest followed by bwd_tok -- or, in bf16 mode with lanes enabled, the exemplar-token backward (~20 launches of fewer than
-        200 workgroups, serial in their own dependency chain) on a side lane beside what is left of the decoder-block backward once
-        dy_tok is final (block 0's self-attention backward and decoder_embed).  The two branches share no scratch buffer in bf16 mode
+        200 workgroups, serial in their own dependency chain, headed by the K / V input-gradient GEMMs that build dy_tok) on a side lane
+        beside what is left of the decoder-block backward once block 0's cross-attention backward has produced the last dK / dV.  The two branches share no scratch buffer in bf16 mode
         (fp32 mode's unfused bias gradients use one column-sum workspace: it stays serial).  Only for a step without a collective
         between the two lists (one rank)."""
         m = next((k for k, op in enumerate(lists.bwd_rest) if op[0] is None and op[1][0] == "tokready"), None)
@@ -883,13 +883,15 @@ class Engine:
             dproj_in = A("dproj_in", (rows, Dd), T)
             dqkv = A("dqkv", (rows, 3 * Dd), T)
             dq = A("dq", (rows, Dd), T)
-            dk = A("dk", (B * Sy, Dd), f32)
-            dv = A("dv", (B * Sy, Dd), f32)
-            dkT = A("dkT", (B * Sy, Dd), T) if code == BF16 else None
-            dvT = A("dvT", (B * Sy, Dd), T) if code == BF16 else None
+            # one dK / dV per block: their input gradients (-> dy_tok, read only by the exemplar-token backward) are emitted at
+            # the head of bwd_tok, off the decoder's own dependency chain
+            dk_b = [A("dk%d" % i, (B * Sy, Dd), f32) for i in range(self.ddepth)]
+            dv_b = [A("dv%d" % i, (B * Sy, Dd), f32) for i in range(self.ddepth)]
+            dkT_b = [A("dkT%d" % i, (B * Sy, Dd), T) if code == BF16 else None for i in range(self.ddepth)]
+            dvT_b = [A("dvT%d" % i, (B * Sy, Dd), T) if code == BF16 else None for i in range(self.ddepth)]
             dy_tok = A("dy_tok", (B * Sy, Dd), f32)
             xws = self._shared("xattn", L.countr_xattn_bwd_workspace_floats(B, N, Sy, Dd))
-            first_tok = True
+            tok_dgrads = []
             for i in reversed(range(self.ddepth)):
                 b = "decoder_blocks.%d" % i
                 d = blk[i]
@@ -900,19 +902,18 @@ class Engine:
                 g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=gxT)
                 # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
                 self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
+                dk, dv, dkT, dvT = dk_b[i], dv_b[i], dkT_b[i], dvT_b[i]
                 self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
                          dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code,
                          dkT.data_ptr() if dkT is not None else None, dvT.data_ptr() if dvT is not None else None)
+                if i == 0:
+                    ops.append((None, ("tokready",), None))   # every block's dK / dV is final: the exemplar-token backward may start (run_backward_rest_and_tok)
                 self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
                 g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=gxT)
                 dk_t, dv_t = (dk, dv) if dkT is None else (dkT, dvT)    # bf16 copies come out of the cross-attention backward
                 for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
                     self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
-                    self._linear_dgrad(ops, g_kv, b + ".attn.%s.weight" % nm, dy_tok, B * Sy, Dd, Dd,
-                                       resid=(None if first_tok else dy_tok), out_bf16=False)
-                    first_tok = False
-                if i == 0:
-                    ops.append((None, ("tokready",), None))   # dy_tok is final: the exemplar-token backward may start (run_backward_rest_and_tok)
+                    tok_dgrads.append((g_kv, b + ".attn.%s.weight" % nm))
                 # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
                 self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
                 if d["lse"] is not None:
@@ -925,8 +926,10 @@ class Engine:
                 g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=gxT)
             # ---- decoder_embed (no dgrad: the encoder is frozen)
             self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
-            # ---- exemplar tokens
+            # ---- exemplar tokens: dy_tok = sum over blocks of dK Wk + dV Wv
             ops = lists.bwd_tok
+            for j, (g_kv, wn) in enumerate(tok_dgrads):
+                self._linear_dgrad(ops, g_kv, wn, dy_tok, B * Sy, Dd, Dd, resid=(None if j == 0 else dy_tok), out_bf16=False)
             if S == 0:
                 ws = self._shared("colsum", 256 * 4096)
                 self._op(ops, L.countr_colsum, dy_tok.data_ptr(), self._gp("shot_token"), ws.data_ptr(), B, Dd, F32, self._acc)
