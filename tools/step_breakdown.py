@@ -48,8 +48,9 @@ for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-86s %6.1f /step %8.1f us avg %8.1f us/step %5.1f%%" % (k[:86], n / nsteps, t / n, t / nsteps, 100 * t / busy))
 if sys.argv[-1] == "seq":
     a, b = ends[-2] + 1, ends[-1] + 1
-    prev = rows[a - 1][2]
-    for name, s, e, gx, wx, gz in rows[a:b]:
+    prev = t0 = rows[a - 1][2]
+    for name, s, e, gx, wx, gz in rows[a:b]:     # start / end offsets from the step's start show which launches overlap (side lanes)
         n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
-        print("%-72s wgs=%5d z=%2d %7.1f us  gap %5.1f" % (n, gx // max(wx, 1), gz, (e - s) / 1e3, (s - prev) / 1e3))
-        prev = e
+        print("%-72s wgs=%5d z=%2d %7.1f us  gap %5.1f  [%8.1f .. %8.1f]" % (n, gx // max(wx, 1), gz, (e - s) / 1e3, (s - prev) / 1e3,
+                                                                           (s - t0) / 1e3, (e - t0) / 1e3))
+        prev = max(prev, e)
