@@ -10,8 +10,6 @@ pre-allocated buffers, hipGraph-replayable), different graph: the whole model tr
   backward         autograd of the above        encoder + decoder ViT blocks (flash attention backward in bf16 mode)
 Gradient buckets: 0 = decoder side (final first), 1..3 = encoder thirds from the top (mae_bucket_fn).
 """
-import math
-
 import torch
 
 from . import _lib

@@ -5,8 +5,6 @@ import json
 import os
 import socket
 
-import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

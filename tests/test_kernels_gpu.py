@@ -3,7 +3,6 @@
 set by bf16 rounding of inputs/outputs (2^-8), stated per test."""
 import ctypes as C
 
-import numpy as np
 import pytest
 import torch
 

@@ -5,7 +5,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from oracle import mae_ref as M
 from oracle import weights as W

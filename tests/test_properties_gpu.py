@@ -1,7 +1,6 @@
 """GPU: size-independent properties of the hot path at BASELINE.json's full size (ViT-B/16, batch 8, 384x384, 3 exemplars, bf16)
 where the CPU oracle would take minutes: per-sample independence, determinism, exact linearity of the backward pass in dL/dout,
 exemplar-order invariance, masking equivalence of the MAE encoder, and loss-mask semantics of the fused step."""
-import numpy as np
 import pytest
 import torch
 
