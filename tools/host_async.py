@@ -11,6 +11,8 @@ model = models_mae_cross.mae_vit_base_patch16(precision="bf16").to(dev).train()
 step = FinetuneStep(model, batch=8, lr=1e-5, weight_decay=0.05, use_graph=True)
 imgs, boxes, gt, _ = make_batch(8, shots=3, seed=0, device=dev)
 mask = (torch.rand(384, 384, device=dev) < 0.8).float()
+if "host" in sys.argv[1:]:     # the DataLoader's hand-over: pinned host tensors, staged over PCIe by load()
+    imgs, boxes, gt, mask = (t.cpu().pin_memory() for t in (imgs, boxes, gt, mask))
 for _ in range(4):
     step.load(imgs, boxes, gt, mask, 3); step.step(3)
 torch.cuda.synchronize()
