@@ -168,14 +168,15 @@ def test_all_shot_counts_interleaved_with_graphs():
 
 def test_host_batches_are_staged_and_match_device_batches():
     """load() accepts the DataLoader's host tensors (staged over a copy stream behind the previous step's compute): the step
-    results are bit-identical to feeding the same batches as device tensors, also when the staging buffers are reused."""
+    results are bit-identical to feeding the same batches as device tensors, also when the (three round-robin) staging slots are
+    reused -- seven steps walk the ring twice."""
     from countr_amd.trainer import FinetuneStep
     res = {}
     for mode in ("device", "host"):
         m, _ = make("bf16")
         step = FinetuneStep(m, batch=2, lr=1e-4, use_graph=True)
         out = []
-        for it in range(4):
+        for it in range(7):
             arrs = W.make_inputs(batch=2, shots=3, seed=30 + it)
             ts = [torch.from_numpy(a) for a in arrs]
             ts = [t.pin_memory() for t in ts] if mode == "host" else [t.cuda() for t in ts]
