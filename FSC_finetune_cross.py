@@ -110,6 +110,9 @@ def main(args):
         n_iter = args.synthetic_steps if args.synthetic_steps > 0 else 50
         n_val = max(1, n_iter // 4)
     loss_mask_gen = torch.Generator(device=device).manual_seed(seed)
+    # mosaics only come out of the augmented loader: without it no rank ever bans shot_num 0 and there is nothing to agree on
+    flag_group = (torch.distributed.new_group(backend="gloo") if misc.get_world_size() > 1 and loader is not None and args.do_aug
+                  else None)
     val_rng = random.Random(seed + 7919)      # the reference draws the validation shot_num per rank from `random` (:338)
     min_MAE = 99999.0                         # :253
     B = args.batch_size
@@ -132,9 +135,9 @@ def main(args):
             else:
                 imgs, boxes, gt, mask = make_batch(B, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
                 mosaic = False
-            if misc.get_world_size() > 1:            # shot_num is shared by all ranks, so is the ban: any rank with a Type-2 mosaic
-                flag = torch.tensor([int(mosaic)], device=device)
-                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if flag_group is not None:               # shot_num is shared by all ranks, so is the ban: any rank with a Type-2 mosaic.
+                flag = torch.tensor([int(mosaic)])   # Host data, host collective (gloo): reading a device flag back would drain the
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=flag_group)   # GPU queue every step
                 mosaic = bool(flag.item())
             # :276-284: "If there is at least one image in the batch using Type 2 Mosaic, 0-shot is banned."
             S = shared_shot_num(epoch * n_iter + it, seed=args.seed, allow_zero=not mosaic)
