@@ -188,8 +188,8 @@ __device__ __forceinline__ float reduce_same_chanvec(float v, float* sm /* [8][3
 }
 
 // the same for NV values at once: two barriers in total instead of two per value (a block's reduction tail was 32-48 barriers)
-template <int NV>
-__device__ __forceinline__ void reduce_vec_same_chanvec(float (&v)[NV], float* sm /* [4][32][NV] */) {
+template <int NV, int NW = 4>
+__device__ __forceinline__ void reduce_vec_same_chanvec(float (&v)[NV], float* sm /* [NW][32][NV] */) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = xor32_sum(v[i]);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void reduce_vec_same_chanvec(float (&v)[NV], float* s
   for (int i = 0; i < NV; ++i) {
     float r = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) r += sm[(w * 32 + (threadIdx.x & 31)) * NV + i];
+    for (int w = 0; w < NW; ++w) r += sm[(w * 32 + (threadIdx.x & 31)) * NV + i];
     v[i] = r;
   }
 }
@@ -334,13 +334,14 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
 // Backward pass 1: per-channel sums of g = dy * 1[y>0] and g * xhat over a pixel split.
 // dy is either a tensor (T) or, for the fused 1x1 head, d1[b,p] * w1[c].
 // partial layout: [B][ns][3][C] = {sum g, sum g*xhat, sum d1*y (dw1, head only)}
-template <typename T>
-__global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void gn_relu_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const float* __restrict__ d1, const float* __restrict__ w1,
                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ partial,
                                                                  int HW, int G) {
-  __shared__ float smv[4 * 32 * 8];
+  constexpr int NW = NT / 64, SLOTS = NT / 32;
+  __shared__ float smv[NW * 32 * 8];
   const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
   const int per = (HW + ns - 1) / ns;
   const int p0 = split * per, p1 = min(HW, p0 + per);
@@ -356,11 +357,11 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
   for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sgx[e] = 0.f; sw[e] = 0.f; }
   const int64_t base = (int64_t)b * HW * GN_C;
   constexpr int U = 4;
-  for (int pb = p0 + slot; pb < p1; pb += 8 * U) {
+  for (int pb = p0 + slot; pb < p1; pb += SLOTS * U) {
     float v[U][8], d[U][8], dd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = pb + 8 * u;
+      const int p = pb + SLOTS * u;
       dd[u] = 0.f;
       if (p < p1) {
         ld8<T>(x + base + (int64_t)p * GN_C + cv * 8, v[u]);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (pb + 8 * u >= p1) continue;
+      if (pb + SLOTS * u >= p1) continue;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xh = (v[u][e] - mu) * rs;
@@ -383,9 +384,9 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const T* __rest
     }
   }
   float* o = partial + ((int64_t)b * ns + split) * 3 * GN_C;
-  reduce_vec_same_chanvec<8>(sg, smv);
-  reduce_vec_same_chanvec<8>(sgx, smv);
-  if (w1) reduce_vec_same_chanvec<8>(sw, smv);
+  reduce_vec_same_chanvec<8, NW>(sg, smv);
+  reduce_vec_same_chanvec<8, NW>(sgx, smv);
+  if (w1) reduce_vec_same_chanvec<8, NW>(sw, smv);
   if (threadIdx.x < 32) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -940,11 +941,16 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   float* gmean = workspace + (int64_t)B * ns * 3 * GN_C + 64;  // [B][G][2] behind the partials and the d1 sums
   if (G != 8) { countr_set_error("countr_groupnorm_relu_bwd: G must be 8"); return -1; }
   if (dtype == COUNTR_BF16) {
-    hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    // threads per block of the reduction pass: 512 (16 pixel slots) keeps more loads in flight per CU than 256 (finetune step
+    // -20 us, two A/B pairs); 1024 falls off a cliff (+230 us: 128-VGPR budget)
+    static const int nt = [] { const char* e = getenv("COUNTR_GN_BWD_NT"); return e ? atoi(e) : 512; }();
+    if (nt == 1024) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 1024>), dim3(ns, B), dim3(1024), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    else if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);
   } else {
-    hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<float, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, gmean, (float*)dx, HW, G, ns);
   }
