@@ -70,6 +70,7 @@ _SIGS = {
     "countr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "countr_colsum_partials": [_vp, _vp, _i, _i, _i, _vp],
     "countr_groupnorm_nsplit": [_i],
+    "countr_groupnorm_bwd_image_sums_offset": [_i, _i],
     "countr_groupnorm_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "countr_groupnorm_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "countr_instnorm_workspace_floats": [_i, _i],
@@ -103,7 +104,7 @@ _SIGS = {
     "countr_splitk_finish": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "countr_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp],
 }
-_RESTYPES = {"countr_xattn_bwd_workspace_floats": C.c_int64}
+_RESTYPES = {"countr_xattn_bwd_workspace_floats": C.c_int64, "countr_groupnorm_bwd_image_sums_offset": C.c_int64}
 
 
 def check(rc, what=""):

@@ -399,9 +399,11 @@ __global__ __launch_bounds__(NT) void gn_relu_bwd_reduce_kernel(const T* __restr
 
 // Backward pass 1b (one block per image): per-(image, group) means of g*gamma and g*gamma*xhat from the split partials.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                              float* __restrict__ gm /* [B][G][2] */, int HW, int G, int ns) {
+                                                              float* __restrict__ gm /* [B][G][2] */,
+                                                              float* __restrict__ per_image /* [B][3][C]: the image's split sums */,
+                                                              int HW, int G, int ns) {
   const int b = blockIdx.x, c = threadIdx.x;  // 256 channels
-  float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: the loop is load-latency bound
+  float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, w4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: the loop is load-latency bound
   int s = 0;
   for (; s + 4 <= ns; s += 4) {
 #pragma unroll
@@ -409,14 +411,21 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
       const float* o = partial + ((int64_t)b * ns + s + u) * 3 * GN_C;
       a4[u] += o[c];
       q4[u] += o[GN_C + c];
+      w4[u] += o[2 * GN_C + c];
     }
   }
   for (; s < ns; ++s) {
     const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
     a4[0] += o[c];
     q4[0] += o[GN_C + c];
+    w4[0] += o[2 * GN_C + c];
   }
   float a = (a4[0] + a4[1]) + (a4[2] + a4[3]), q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+  // the parameter gradients {dbeta, dgamma, dw1} are sums over ALL images and splits: hand the per-image sums on, so that whoever
+  // finishes them adds B rows instead of walking B * ns partials (192x192: 512) in one serial chain per channel
+  per_image[((int64_t)b * 3 + 0) * GN_C + c] = a;
+  per_image[((int64_t)b * 3 + 1) * GN_C + c] = q;
+  per_image[((int64_t)b * 3 + 2) * GN_C + c] = (w4[0] + w4[1]) + (w4[2] + w4[3]);
   const float ga = gamma[c];
   a *= ga; q *= ga;
   const int cpg = GN_C / G;  // 32 channels per group: reduce inside each 32-lane half wave
@@ -903,6 +912,9 @@ static int gn_splits(int HW) {
   return ns < 1 ? 1 : ns;
 }
 extern "C" int countr_groupnorm_nsplit(int HW) { return gn_splits(HW); }
+// float offset, inside countr_groupnorm_relu_bwd's workspace, of the per-image sums [B][3][C] = {sum g, sum g*xhat, sum d1*y} its
+// finalize pass leaves behind (the workspace therefore needs B*ns*3*C + 64 + 16*B + B*3*C floats)
+extern "C" long long countr_groupnorm_bwd_image_sums_offset(int B, int HW) { return (long long)B * gn_splits(HW) * 3 * GN_C + 64 + 16 * B; }
 // forward statistics: their partials ({mean, M2} per group) are combined in parallel by gn_stats_finalize_kernel, so the big maps
 // can be cut finer than the backward's (whose finishers walk the splits): 144 pixels per block, at most 128 blocks per image
 static int gn_splits_fwd(int HW) {
@@ -939,26 +951,28 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   const int ns = gn_splits(HW);
   const int nblk = min((HW + 7) / 8, 512);
   float* gmean = workspace + (int64_t)B * ns * 3 * GN_C + 64;  // [B][G][2] behind the partials and the d1 sums
+  float* per_image = gmean + 16 * B;                           // [B][3][C] behind that (countr_groupnorm_bwd_image_sums_offset)
   if (G != 8) { countr_set_error("countr_groupnorm_relu_bwd: G must be 8"); return -1; }
   if (dtype == COUNTR_BF16) {
-    // threads per block of the reduction pass: 512 (16 pixel slots) keeps more loads in flight per CU than 256 (finetune step
-    // -20 us, two A/B pairs); 1024 falls off a cliff (+230 us: 128-VGPR budget)
-    static const int nt = [] { const char* e = getenv("COUNTR_GN_BWD_NT"); return e ? atoi(e) : 512; }();
+    // threads per block of the reduction pass: 512 (16 pixel slots) keeps more loads in flight per CU than 256 (96x96: 31.6 -> 20.8 us,
+    // 48x48 and 24x24: 17.4 -> 11.6 us); 1024 falls off a cliff (step +230 us: 128-VGPR budget)
+    static const int nt_env = [] { const char* e = getenv("COUNTR_GN_BWD_NT"); return e ? atoi(e) : 0; }();
+    const int nt = nt_env ? nt_env : (w1 ? 256 : 512);   // (the fused-head form -- 192x192, x only -- is better off with 256: 41.4 vs 44.4 us)
     if (nt == 1024) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 1024>), dim3(ns, B), dim3(1024), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     else if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, HW, G, ns);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);
   } else {
     hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<float, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, HW, G, ns);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, gmean, (float*)dx, HW, G, ns);
   }
   // parameter gradients: partial[p] = {sum g (dbeta) [C], sum g*xhat (dgamma) [C], sum d1*y (dw1) [C]}
   float* outs[3] = {dbeta, dgamma, dw1};
   for (int i = 0; i < 3; ++i) {
     if (!outs[i]) continue;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(GN_C / 16), dim3(256), 0, STREAM(stream), workspace + i * GN_C, outs[i], B * ns, GN_C,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(GN_C / 16), dim3(256), 0, STREAM(stream), per_image + i * GN_C, outs[i], B, GN_C,
                        (int64_t)3 * GN_C, accumulate);
   }
   if (db1 && d1) {  // the reduce/apply kernels are done with the first 64 floats of row 0's third plane only via dw1: use the tail

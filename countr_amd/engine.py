@@ -788,7 +788,7 @@ class Engine:
         cin = [Dd, 256, 256, 256]
         hin = [dn]
         hc, hstats = [], []
-        gn_ws = self._shared("gn", B * 64 * 3 * 256 + 64 + 16 * B)
+        gn_ws = self._shared("gn", B * 64 * 3 * 256 + 64 + 16 * B + B * 3 * 256)
         o1 = A("o1", (B, hs[3] * hs[3]), f32)
         out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
         hact_tmp = self._shared("hact_tmp", B * hs[2] * hs[2] * 256, T)
@@ -840,7 +840,7 @@ class Engine:
                 # layer's own workspace and are summed by the table launch that finishes the layer's conv wgrad anyway (they used to
                 # be 2-3 colsum launches of 16 workgroups each: ~80 us per step of latency-bound finishers)
                 defer = self.defer_reduce
-                gws = self._shared("gnbw%d" % i, B * 64 * 3 * 256 + 64 + 16 * B) if defer else gn_ws
+                gws = self._shared("gnbw%d" % i, B * 64 * 3 * 256 + 64 + 16 * B + B * 3 * 256) if defer else gn_ws
                 if defer:
                     self._claim(gws.data_ptr())
                 gpar = lambda n: None if defer else self._gp(n)
@@ -855,10 +855,11 @@ class Engine:
                              self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), dpre.data_ptr(), gpar(hn + ".1.weight"),
                              gpar(hn + ".1.bias"), None, None, gws.data_ptr(), B, HW, 256, 8, code, self._acc)
                 if defer:
-                    nsl = B * L.countr_groupnorm_nsplit(HW)
+                    # the backward's finalize pass leaves per-IMAGE sums behind the split partials: B rows to add, not B * nsplit
+                    img = gws.data_ptr() + 4 * L.countr_groupnorm_bwd_image_sums_offset(B, HW)
                     planes = [(0, hn + ".1.bias"), (1, hn + ".1.weight")] + ([(2, hn + ".3.weight")] if i == 3 else [])
                     for plane, pname in planes:
-                        self._reduce_later(ops, gws.data_ptr(), gws.data_ptr() + plane * 256 * 4, self._gp(pname), nsl, 3 * 256, 256)
+                        self._reduce_later(ops, gws.data_ptr(), img + plane * 256 * 4, self._gp(pname), B, 3 * 256, 256)
                 big = hs[i] >= 96   # each of these kernels fills the GPU on its own: forking only adds contention
                 if not big:
                     self._fork(ops)

@@ -122,8 +122,11 @@ int countr_colsum_partials(const float* partial, float* out, int nparts, int C, 
 
 /* -------- GroupNorm(8, 256) + ReLU on NHWC maps (decode_head*: models_mae_cross.py:80-100).
  * With w1 != NULL the 1x1 conv 256->1 of decode_head3 (:99) is fused: out1[b,p] = sum_c y*w1[c] + b1 and
- * y may be NULL.  stats: fp32 [B][G][2] (mean, rstd) output.  workspace: fp32 >= B*nsplit*3*256 + 64 + 16*B. */
+ * y may be NULL.  stats: fp32 [B][G][2] (mean, rstd) output.  workspace: fp32 >= B*nsplit*3*256 + 64 + 16*B (forward),
+ * + B*3*256 (backward: behind the split partials its finalize pass leaves the per-image sums [B][3][256] = {sum g, sum g*xhat,
+ * sum d1*y} at float offset countr_groupnorm_bwd_image_sums_offset(B, HW), for callers that finish dbeta / dgamma / dw1 themselves). */
 int countr_groupnorm_nsplit(int HW);
+long long countr_groupnorm_bwd_image_sums_offset(int B, int HW);
 int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
                               const float* b1, float* out1, float* stats, float* workspace, int B, int HW,
                               int C, int G, float eps, int dtype, void* stream);

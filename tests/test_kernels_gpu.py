@@ -84,7 +84,7 @@ def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
     b1 = torch.tensor([0.05])
     d1 = rnd((B, HW), 10)
     ns = hip.countr_groupnorm_nsplit(HW)
-    ws = torch.empty(B * ns * 3 * Cc + 64 + 16 * B, device="cuda")
+    ws = torch.empty(B * ns * 3 * Cc + 64 + 16 * B + B * 3 * Cc, device="cuda")
     stats = torch.empty((B, G, 2), device="cuda")
     xd, gd, bd = x.cuda(), g.cuda(), b.cuda()
     y = torch.empty((B, HW, Cc), device="cuda", dtype=tdt)
