@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
       if (pix < p1) {
         if (k == 27) v = 1.f;
         else {
-          const int x = (int)(pix % W), y = (int)((pix / W) % H), s = (int)(pix / ((int64_t)W * H));
+          const int pi = (int)pix, x = pi % W, y = (pi / W) % H, s = pi / (W * H);   // S * H * W < 2^31 (checked on the host)
           const int c = k / 9, r = k - c * 9, ky = r / 3, kx = r - ky * 3;
           const int yy = y + ky - 1, xx = x + kx - 1;
           if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = in[(((int64_t)s * 3 + c) * H + yy) * W + xx];
@@ -140,22 +140,24 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
   }
 }
 
-// partial [nb][64][28] -> dw [64][27] (torch OIHW order co, c, ky, kx == k) and db [64]; a block sums 16 outputs with 16 slab
-// groups of nb / 16 blocks each and combines them in LDS (4 lanes per output walking nb / 4 slabs serially took 21.8 us)
-__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                      float* __restrict__ db, int nb, int accumulate) {
-  __shared__ float red[16][17];
+// partial [nb][64][28] -> dw [64][27] (torch OIHW order co, c, ky, kx == k) and db [64]; a block sums 16 outputs with 64 slab
+// groups of nb / 64 blocks each and combines them in LDS (4 lanes per output walking nb / 4 slabs serially took 21.8 us; 16 groups:
+// 10.5 us at 256 slabs, 15.3 at 512)
+constexpr int C3F_GROUPS = 64;   // slab groups per block: 1024 threads = 16 outputs x 64 groups
+__global__ __launch_bounds__(16 * C3F_GROUPS) void conv3x3_c3_wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                                  float* __restrict__ db, int nb, int accumulate) {
+  __shared__ float red[C3F_GROUPS][17];
   const int c = threadIdx.x & 15, gq = threadIdx.x >> 4;
   const int o = blockIdx.x * 16 + c;
   float s = 0.f;
   if (o < 64 * 28)
-    for (int b = gq; b < nb; b += 16) s += partial[(int64_t)b * (64 * 28) + o];
+    for (int b = gq; b < nb; b += C3F_GROUPS) s += partial[(int64_t)b * (64 * 28) + o];
   red[gq][c] = s;
   __syncthreads();
   if (gq || o >= 64 * 28) return;
   float tot = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) tot += red[k][c];
+  for (int k = 0; k < C3F_GROUPS; ++k) tot += red[k][c];
   const int co = o / 28, k = o - co * 28;
   float* dst = (k == 27) ? (db + co) : (dw + co * 27 + k);
   *dst = accumulate ? *dst + tot : tot;
@@ -554,14 +556,19 @@ extern "C" int countr_conv3x3_c3_fwd(const float* in, const float* w, const floa
   COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_fwd");
 }
 
-extern "C" int countr_conv3x3_c3_wgrad_nblocks(void) { return 256; }
+extern "C" int countr_conv3x3_c3_wgrad_nblocks(void) {
+  // 24 boxes of 64x64 (98304 pixels): 256 blocks 49.0 + 10.5 us (finish), 512: 32.3 + 15.3, 1024: 39.1 + 25.5 -- with the 16-group finish
+  static const int nb = [] { const char* e = getenv("COUNTR_C3_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+  return nb;
+}
 extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* dw, float* db, float* workspace, int S, int H,
                                        int W, int dtype, int accumulate, void* stream) {
   if (!in || !dy || !dw || !db || !workspace) { countr_set_error("countr_conv3x3_c3_wgrad: null"); return -1; }
+  if ((int64_t)S * H * W >= (int64_t)1 << 31) { countr_set_error("countr_conv3x3_c3_wgrad: more than 2^31 pixels"); return -1; }
   const int nb = countr_conv3x3_c3_wgrad_nblocks();
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const bf16_t*)dy, workspace, S, H, W);
   else hipLaunchKernelGGL(conv3x3_c3_wgrad_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, (const float*)dy, workspace, S, H, W);
-  hipLaunchKernelGGL(conv3x3_c3_wgrad_finish_kernel, dim3((64 * 28 + 15) / 16), dim3(256), 0, STREAM(stream), workspace, dw, db, nb, accumulate);
+  hipLaunchKernelGGL(conv3x3_c3_wgrad_finish_kernel, dim3((64 * 28 + 15) / 16), dim3(16 * C3F_GROUPS), 0, STREAM(stream), workspace, dw, db, nb, accumulate);
   COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_wgrad");
 }
 
