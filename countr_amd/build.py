@@ -36,9 +36,13 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")) + [os.path.abspath(__file__)]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr):
+            continue   # object newer than its source and every shared header: keep it (gemm.hip alone takes ~90 s)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

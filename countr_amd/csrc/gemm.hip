@@ -1297,6 +1297,8 @@ extern "C" int countr_reduce_table(const long long* table, int n, int total_bloc
   COUNTR_LAUNCH_CHECK("countr_reduce_table");
 }
 
+int countr_lean_linear(const countr_gemm_args* a, hipStream_t s);   // linear.hip: 1 = does not qualify
+
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
   if ((a->splitk > 1 && !a->partial) || (a->partial && a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
@@ -1311,6 +1313,10 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   if (modeB == COUNTR_OP_COL && (a->N % epc)) { countr_set_error("countr_gemm: N must be a multiple of the chunk for COL B"); return -1; }
   if ((modeA == COUNTR_OP_IM2ROW || modeB == COUNTR_OP_IM2COL) && (a->Cin % 64 || a->H <= 0 || a->W <= 0)) { countr_set_error("countr_gemm: conv modes need Cin % 64 == 0"); return -1; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_ROW && modeB == COUNTR_OP_ROW && a->act <= COUNTR_ACT_GELU) {
+    const int rc = countr_lean_linear(a, s);   // full-tile nn.Linear forward shapes: the lean kernel of linear.hip
+    if (rc != 1) return rc;
+  }
   if (dtype == COUNTR_BF16) return dispatch<bf16_t>(*a, modeA, modeB, s);
   if (dtype == COUNTR_F32) return dispatch<float>(*a, modeA, modeB, s);
   countr_set_error("countr_gemm: bad dtype");

@@ -1,0 +1,473 @@
+// Lean nn.Linear forward for gfx950: out = epilogue(x W^T + b), x [M,K] bf16 row-major, W [N,K] bf16 row-major, FULL tiles only
+// (M % 128 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned operands).  countr_gemm() routes the (ROW, ROW) bf16 launches that qualify
+// here; everything else (ragged shapes, fp32 parity mode, dgrad / wgrad / convolutions) stays on gemm_kernel in gemm.hip.
+//
+// Why a second kernel.  The generic kernel's workgroup spends ~14 k cycles outside its main loop on the encoder shapes
+// (profiles/r2_gemm_kernel_timeline.txt): bounds-checked, 64-bit, per-element-predicated address arithmetic issued by ONE wave per SIMD
+// (a lone wave issues a VALU every ~5.5 cycles, profiles/r2_issue_microbench.txt), 16-wide MFMAs whose issue slots hide almost nothing, a
+// libm-shaped GELU (~20 VALU per element), and loader waves that have left before the epilogue starts.  Here:
+//   * v_mfma_f32_32x32x16_bf16 (half the matrix instructions per flop; ~4 issue slots of cover under each), 64x64 wave tile = 2x2 tiles,
+//     fragments by ds_read_b128 from XOR-swizzled 128-byte rows (swizzle on the LDS-DMA source address, slot = chunk ^ ((row >> 1) & 7));
+//   * W rows are read in the permuted order p(8a + 4h + b) = 16h + 4a + b, so that a lane's 16 accumulator registers of a tile are 16
+//     CONSECUTIVE output columns;
+//   * no bounds checks, 32-bit offsets from scalar bases, bias / residual fetched before the main loop;
+//   * epilogue: raw fp32 accumulators -> LDS -> row segments; bias, GELU, residual, rounding happen on the read-back side, where every
+//     wave of the workgroup takes part (in the wave-specialised form the four loader waves do half of it);
+//   * GELU as x * sigmoid(x (c0 + c1 x^2 + c2 x^4)) on packed fp32 pairs: |error| <= 2.6e-5 absolute against the erf form (bf16 output
+//     resolution is 4e-3 relative), 6 VALU + 2 transcendentals per element pair-half instead of ~20.
+// Launch forms: <NLD = 4> 4 compute + 4 loader waves, 3-stage LDS ring, one workgroup per CU (grids of <= 256 tiles);
+//               <NLD = 0> 4 waves that stage and multiply, 2 stages, two workgroups per CU (bigger grids).
+// Reference call sites: models_crossvit.py:62,65 (Mlp), :84,92 (Attention qkv / proj), :115-127 (CrossAttention), models_mae_cross.py:152.
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+#ifndef LIN_ABL
+#define LIN_ABL 0   // timing experiments (tools/exp_lin.sh, results are WRONG): 1 = no MFMA, 2 = no fragment reads, 3 = no DMA after the first tiles
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef const __attribute__((address_space(1))) void* glb_vptr_t;
+typedef __attribute__((address_space(3))) const char* lds_cptr_t;
+
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RES = 2 };
+
+struct LinArgs {
+  const char* A;       // [M, lda] bf16
+  const char* W;       // [N, ldw] bf16
+  char* C;             // bf16 or fp32 [M, ldc]
+  char* C2;            // EPI_GELU: optional bf16 pre-activation copy
+  const float* bias;   // [N] or null
+  const float* resid;  // EPI_RES: fp32 [*, ldres]
+  int M, N, K;
+  int lda, ldw, ldc, ldres;   // elements
+  int res_mod, tilesN;
+};
+
+constexpr int STAGE_BYTES = 32768, B_OFF = 16384;
+constexpr int OPITCH = 64 * 4 + 16;   // staging pitch of a 64-column fp32 row
+
+template <typename F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ uint32_t lds_u32(const char* p) { return (uint32_t)(uintptr_t)(lds_cptr_t)p; }
+
+template <int OFF> __device__ __forceinline__ bf16x8_t ds_read128(uint32_t a) {
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+// wait until at most PENDING LDS reads are outstanding; the fragments are threaded through so that their MFMAs stay behind the wait
+template <int PENDING> __device__ __forceinline__ void frag_wait(bf16x8_t (&f)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(PENDING));
+}
+
+// x * Phi(x) as x * sigmoid(x (c0 + c1 x^2 + c2 x^4)), coefficients fitted (minimax over [-9, 9], tools/fit_gelu.py) and pre-multiplied
+// by -log2(e); the polynomial argument is clamped to |x| <= 8 (the fitted quartic turns around near |x| = 10).
+__device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -8.f, 8.f), __builtin_amdgcn_fmed3f(x[1], -8.f, 8.f)};
+  const f32x2_t x2 = xc * xc;
+  const f32x2_t k0 = {-2.30112137f, -2.30112137f}, k1 = {-0.10677575f, -0.10677575f}, k2 = {1.01426498e-3f, 1.01426498e-3f};
+  f32x2_t t = __builtin_elementwise_fma(x2, k2, k1);
+  t = __builtin_elementwise_fma(t, x2, k0);
+  const f32x2_t u = t * xc;
+  const f32x2_t one = {1.f, 1.f};
+  const f32x2_t e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+  const f32x2_t d = e + one;
+  const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return x * r;
+}
+
+template <int NLD, int EPI, int STAGES>
+__global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g) {
+  constexpr bool SPEC = NLD > 0;
+  static_assert(SPEC ? (STAGES >= 3 && STAGES <= 5) : STAGES == 2, "ring depth");
+  constexpr int NLW = SPEC ? NLD : 4;           // waves that stage tiles
+  constexpr int PASSES = 128 / (8 * NLW);       // 1-KiB pieces per operand per staging wave per k-tile
+  static_assert(NLW == 4, "row swizzle below assumes 32-row passes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = SPEC && wv >= 4;
+  const int cw = wv & 3;                         // compute-wave index / loader index
+  // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns one contiguous range of the (tile_m, tile_n) space
+  int lt;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int ntiles = g.K >> 6;
+
+  // ---- LDS-DMA set-up (staging waves): piece (pass i, wave w) = rows [32 i + 8 w, +8) of the 128-row tile, lane -> (row, 16-byte slot)
+  const int drow = cw * 8 + (lane >> 3);
+  const int dchunk = (lane & 7) ^ (((cw & 1) << 2) | (lane >> 4));        // = slot ^ ((row >> 1) & 7), pass-independent
+  const uint32_t voffA = (uint32_t)((drow * g.lda + dchunk * 8) * 2);
+  const uint32_t voffB = (uint32_t)((drow * g.ldw + dchunk * 8) * 2);
+  const char* baseA = g.A + (int64_t)m0 * g.lda * 2;
+  const char* baseB = g.W + (int64_t)n0 * g.ldw * 2;
+  const uint32_t passA = (uint32_t)g.lda * 64u, passB = (uint32_t)g.ldw * 64u;   // 32 rows further, bytes
+  auto issue = [&](int t, int slot) {
+#if LIN_ABL == 3
+    if (t >= 2) return;
+#endif
+    char* dst = smem + slot * STAGE_BYTES + cw * 1024;
+    const char* ua = baseA + t * 128;
+    const char* ub = baseB + t * 128;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i)
+      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ua + i * passA + voffA), (lds_vptr_t)(dst + i * 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i)
+      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ub + i * passB + voffB), (lds_vptr_t)(dst + B_OFF + i * 4096), 16, 0, 0);
+  };
+
+  // loader waves start the ring before anything else; the memory clobber keeps the prefetch loads below BEHIND these in issue order
+  // (the first wait of the loader loop counts them: vmcnt = one tile + NPRE younger loads)
+  if constexpr (SPEC) {
+    if (loader) {
+#pragma unroll
+      for (int s_ = 0; s_ < STAGES - 1; ++s_)
+        if (s_ < ntiles) issue(s_, s_);
+    }
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- read-back geometry (epilogue): which rows / columns this wave's lanes finish
+  // SPEC: wave w (0..7) finishes rows [32 (w >> 2), +32) of compute wave (w & 3)'s 64x64 sub-tile; plain: its own 64 rows in two passes.
+  const int sub = cw;                                   // sub-tile whose staging region this wave reads
+  const int sm0 = m0 + (sub >> 1) * 64, sn0 = n0 + (sub & 1) * 64;
+  constexpr bool OBF = EPI != EPI_RES;
+  // bf16 out: lane -> 8 columns (2 fp32 chunks), 8 lanes per row;  fp32 out: lane -> 4 columns, 16 lanes per row
+  const int ccol = OBF ? (lane & 7) * 8 : (lane & 15) * 4;
+  const int rrow = OBF ? (lane >> 3) : (lane >> 4);     // + 8 j (bf16) / 4 j (fp32)
+  constexpr int RSTEP = OBF ? 8 : 4, NIT_HALF = 32 / RSTEP;     // iterations per 32 rows
+  const int half0 = SPEC ? (wv >> 2) : 0;               // SPEC: the one 32-row half this wave finishes
+  float bcol[OBF ? 8 : 4];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + sn0 + ccol);
+    bcol[0] = b0.x; bcol[1] = b0.y; bcol[2] = b0.z; bcol[3] = b0.w;
+    if constexpr (OBF) {
+      const float4 b1 = *reinterpret_cast<const float4*>(g.bias + sn0 + ccol + 4);
+      bcol[4] = b1.x; bcol[5] = b1.y; bcol[6] = b1.z; bcol[7] = b1.w;
+    }
+  }
+  // residual prefetch (SPEC): the 8 row segments this wave will add, fetched before the main loop
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  f4_t rpre[(SPEC && EPI == EPI_RES) ? 8 : 1];
+  if constexpr (SPEC && EPI == EPI_RES) {
+    const int mrow0 = sm0 + half0 * 32 + rrow;
+    if (g.res_mod > 0) {   // row modulo (pos-embed adds): one division, then steps of 4 rows with a conditional wrap
+      int mr = mrow0 % g.res_mod;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rpre[j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g.resid + (int64_t)mr * g.ldres + sn0 + ccol));
+        mr += 4; if (mr >= g.res_mod) mr -= g.res_mod;
+      }
+    } else {
+      const float* rb = g.resid + (int64_t)mrow0 * g.ldres + sn0 + ccol;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rpre[j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(rb + (int64_t)(4 * j) * g.ldres));
+    }
+  }
+
+  // ---- fragment addresses (compute waves): byte offsets inside a stage for k-step kk; tile tm / tn = +4096 in the offset field
+  const int wm = cw >> 1, wn = cw & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int prow = ((l31 >> 2) & 1) * 16 + ((l31 >> 3) & 3) * 4 + (l31 & 3);            // W row permutation p(l31)
+  const int swx = (l31 >> 1) & 7, sww = (prow >> 1) & 7;
+  uint32_t xoff[4], woff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    xoff[kk] = (uint32_t)((wm * 64 + l31) * 128 + (((kk * 2 + lh) ^ swx) << 4));
+    woff[kk] = (uint32_t)(B_OFF + (wn * 64 + prow) * 128 + (((kk * 2 + lh) ^ sww) << 4));
+  }
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  bf16x8_t fr[4][4];   // [set][x0, x1, w0, w1]; SPEC: set = k-step
+  uint32_t sbase = lds_u32(smem);
+  auto request = [&](auto KK, int set) {
+    constexpr int kk = decltype(KK)::value;
+    const uint32_t xa = sbase + xoff[kk], wa = sbase + woff[kk];
+#if LIN_ABL == 2
+    for (int q = 0; q < 4; ++q) fr[set][q] = __builtin_bit_cast(bf16x8_t, u32x4_t{xa, wa, (uint32_t)q, 1u});
+    return;
+#endif
+    fr[set][0] = ds_read128<0>(xa);
+    fr[set][1] = ds_read128<4096>(xa);
+    fr[set][2] = ds_read128<0>(wa);
+    fr[set][3] = ds_read128<4096>(wa);
+  };
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#if LIN_ABL == 1
+      { const u32x4_t a_ = __builtin_bit_cast(u32x4_t, fr[set][2 + tn]), b_ = __builtin_bit_cast(u32x4_t, fr[set][tm]);
+        acc[tm][tn][0] += __uint_as_float(a_[0] ^ b_[0]); acc[tm][tn][5] += __uint_as_float(a_[1] ^ b_[1]);
+        acc[tm][tn][10] += __uint_as_float(a_[2] ^ b_[2]); acc[tm][tn][15] += __uint_as_float(a_[3] ^ b_[3]); }
+#else
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[set][2 + tn], fr[set][tm], acc[tm][tn], 0, 0, 0);
+#endif
+  };
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+  // k-steps 0..2 of the tile whose step-0 fragments (set 0) are already requested; leaves step 3 (set 1) requested
+  auto steps012 = [&] {
+    request(K1{}, 1); frag_wait<4>(fr[0]); mma(0); __builtin_amdgcn_sched_barrier(0);
+    request(K2{}, 0); frag_wait<4>(fr[1]); mma(1); __builtin_amdgcn_sched_barrier(0);
+    request(K3{}, 1); frag_wait<4>(fr[0]); mma(0); __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if constexpr (SPEC) {
+    if (loader) {
+      // loader waves: keep STAGES-1 tiles in flight; tile t has landed when at most (STAGES-2) tiles' worth of loads are outstanding
+      constexpr int NPRE = (OBF ? 2 : 1) + (EPI == EPI_RES ? 8 : 0);   // bias / residual loads issued after the first STAGES-1 tiles
+      int islot = STAGES - 1;
+#ifdef LIN_STAMP   // s_memtime anatomy (tools/stamp_lin.py): loaders [1] load wait [2] barrier [3] DMA issue; compute waves [2] barrier [4] the rest
+      uint64_t sk1 = 0, sk2 = 0, sk3 = 0;
+      const uint64_t sk0 = __builtin_readcyclecounter(), sr0 = wall_clock64();
+#define LSTAMP(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define LSTAMP(x)
+#endif
+      for (int t = 0; t < ntiles; ++t) {
+        LSTAMP(ua);
+        if (t == 0 && STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 2 * PASSES + NPRE) : "memory");
+        else if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 2 * PASSES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LSTAMP(ub);
+        __builtin_amdgcn_s_barrier();
+        LSTAMP(uc);
+        if (t + STAGES - 1 < ntiles) issue(t + STAGES - 1, islot);
+        islot = (islot + 1 == STAGES) ? 0 : islot + 1;
+#ifdef LIN_STAMP
+        { LSTAMP(ud); sk1 += ub - ua; sk2 += uc - ub; sk3 += ud - uc; }
+#endif
+      }
+#ifdef LIN_STAMP
+      if (lane == 0 && g.C2 && EPI != EPI_GELU) {
+        float* d = reinterpret_cast<float*>(g.C2) + ((int64_t)blockIdx.x * 8 + wv) * 8;
+        d[0] = (float)(__builtin_readcyclecounter() - sk0); d[1] = (float)sk1; d[2] = (float)sk2; d[3] = (float)sk3;
+        d[5] = (float)ntiles; d[6] = 1.f; d[7] = (float)(wall_clock64() - sr0);
+      }
+#endif
+    } else {
+      // compute waves.  One fragment set per k-step of a tile; the reads of k-step s+2 are issued one by one BETWEEN the MFMAs of
+      // k-step s (a ds_read_b128 issues under the 32 cycles of the MFMA in front of it; four reads in a row behind four MFMAs left the
+      // matrix pipe idle for the issue time of the last three: 740 cycles per k-tile with NO DMA traffic at all,
+      // profiles/r3_linear_ablation.txt), so a set has a full k-step (128 matrix cycles) to land.  At the tile boundary: k-step 2's
+      // MFMAs (no reads), every read of tile t landed, barrier t+1 (the loaders may now refill tile t's slot; tile t+1 is visible),
+      // then k-step 3's MFMAs carry the EIGHT reads of tile t+1's k-steps 0 and 1.
+      int slot = 0, t = 0;
+#ifdef LIN_STAMP
+      uint64_t ck2 = 0;
+      const uint64_t ck0 = __builtin_readcyclecounter(), cr0 = wall_clock64();
+#endif
+      __builtin_amdgcn_s_barrier();
+      uint32_t xa, wa;
+      auto addr = [&](auto KK) { constexpr int kk = decltype(KK)::value; xa = sbase + xoff[kk]; wa = sbase + woff[kk]; };
+#if LIN_ABL == 2
+#define LIN_RD(SET, Q, OFF, A) fr[SET][Q] = __builtin_bit_cast(bf16x8_t, u32x4_t{A, (uint32_t)(OFF), (uint32_t)(Q), 1u})
+#else
+#define LIN_RD(SET, Q, OFF, A) fr[SET][Q] = ds_read128<OFF>(A)
+#endif
+#if LIN_ABL == 1
+#define LIN_MM(SET, TM, TN) { const u32x4_t a_ = __builtin_bit_cast(u32x4_t, fr[SET][2 + TN]), b_ = __builtin_bit_cast(u32x4_t, fr[SET][TM]); \
+        acc[TM][TN][0] += __uint_as_float(a_[0] ^ b_[0]); acc[TM][TN][5] += __uint_as_float(a_[1] ^ b_[1]); \
+        acc[TM][TN][10] += __uint_as_float(a_[2] ^ b_[2]); acc[TM][TN][15] += __uint_as_float(a_[3] ^ b_[3]); }
+#else
+#define LIN_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[SET][2 + TN], fr[SET][TM], acc[TM][TN], 0, 0, 0)
+#endif
+#define LIN_SB __builtin_amdgcn_sched_barrier(0)
+      // MFMAs of set U with the four reads of set R (addresses xa / wa) between them
+#define LIN_STEP_RD(U, R) LIN_MM(U, 0, 0); LIN_SB; LIN_RD(R, 0, 0, xa); LIN_SB; LIN_MM(U, 0, 1); LIN_SB; LIN_RD(R, 2, 0, wa); LIN_SB; \
+                          LIN_MM(U, 1, 0); LIN_SB; LIN_RD(R, 1, 4096, xa); LIN_SB; LIN_MM(U, 1, 1); LIN_SB; LIN_RD(R, 3, 4096, wa); LIN_SB
+#define LIN_STEP(U) LIN_MM(U, 0, 0); LIN_MM(U, 0, 1); LIN_MM(U, 1, 0); LIN_MM(U, 1, 1); LIN_SB
+      addr(K0{}); LIN_RD(0, 0, 0, xa); LIN_RD(0, 1, 4096, xa); LIN_RD(0, 2, 0, wa); LIN_RD(0, 3, 4096, wa);
+      addr(K1{}); LIN_RD(1, 0, 0, xa); LIN_RD(1, 1, 4096, xa); LIN_RD(1, 2, 0, wa); LIN_RD(1, 3, 4096, wa);
+      LIN_SB;
+      // (the loop body is the same for every tile, the last included: its barrier is the "ring free" barrier the loaders join after
+      // their loop, and its eight look-ahead reads fetch stale ring bytes that nobody uses -- a peeled last tile made the register
+      // allocator copy all 64 accumulator registers once per tile)
+      for (; t < ntiles; ++t) {
+        addr(K2{}); frag_wait<4>(fr[0]); LIN_STEP_RD(0, 2);
+        addr(K3{}); frag_wait<4>(fr[1]); LIN_STEP_RD(1, 3);
+        frag_wait<4>(fr[2]); LIN_STEP(2);
+        frag_wait<0>(fr[3]);
+        slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+        LSTAMP(va);
+        __builtin_amdgcn_s_barrier();
+#ifdef LIN_STAMP
+        { LSTAMP(vb); ck2 += vb - va; }
+#endif
+        sbase = lds_u32(smem) + slot * STAGE_BYTES;
+        addr(K0{});
+        LIN_MM(3, 0, 0); LIN_SB; LIN_RD(0, 0, 0, xa); LIN_RD(0, 2, 0, wa); LIN_SB;
+        LIN_MM(3, 0, 1); LIN_SB; LIN_RD(0, 1, 4096, xa); LIN_RD(0, 3, 4096, wa); LIN_SB;
+        addr(K1{});
+        LIN_MM(3, 1, 0); LIN_SB; LIN_RD(1, 0, 0, xa); LIN_RD(1, 2, 0, wa); LIN_SB;
+        LIN_MM(3, 1, 1); LIN_SB; LIN_RD(1, 1, 4096, xa); LIN_RD(1, 3, 4096, wa); LIN_SB;
+      }
+      frag_wait<0>(fr[0]); frag_wait<0>(fr[1]);   // the stale look-ahead reads must have returned before their registers are reused
+#ifdef LIN_STAMP
+      if (lane == 0 && g.C2 && EPI != EPI_GELU) {
+        float* d = reinterpret_cast<float*>(g.C2) + ((int64_t)blockIdx.x * 8 + wv) * 8;
+        d[0] = (float)(__builtin_readcyclecounter() - ck0); d[2] = (float)ck2; d[5] = (float)ntiles; d[6] = 2.f; d[7] = (float)(wall_clock64() - cr0);
+      }
+#endif
+    }
+    if (loader) __builtin_amdgcn_s_barrier();   // ring free (the compute waves' last in-loop barrier): every wave is past its last tile
+  } else {
+    // two stages: tile t+1 streams in while tile t is multiplied
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < ntiles; ++t) {
+      const int cur = t & 1;
+      sbase = lds_u32(smem) + cur * STAGE_BYTES;
+      request(K0{}, 0);
+      if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
+      steps012();
+      frag_wait<0>(fr[1]);
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue.  Staging: compute wave w owns smem + w * REGION; row r of its sub-tile at r * OPITCH (SPEC: all 64 rows, plain: 32).
+  constexpr int REGION = (SPEC ? 64 : 32) * OPITCH;
+  auto stage_out = [&](int tm) {   // lane: row tm*32 + l31 (plain: l31), columns tn*32 + 16 lh + [0, 16)
+    char* dst = smem + cw * REGION + ((SPEC ? tm * 32 : 0) + l31) * OPITCH + lh * 64;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f4_t*>(dst + tn * 128 + q * 16) = f4_t{acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
+  };
+  auto finish_half = [&](int half, int j0, auto USE_RPRE) {   // rows [32 half, +32) of sub-tile `sub`; j0 = index of rpre[0]
+    const char* src = smem + sub * REGION + ((SPEC ? half * 32 : 0) + rrow) * OPITCH + ccol * 4;
+    const int mrow = sm0 + half * 32 + rrow;
+#pragma unroll
+    for (int j = 0; j < NIT_HALF; ++j) {
+      const int m = mrow + RSTEP * j;
+      if constexpr (OBF) {
+        const f4_t v0 = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH);
+        const f4_t v1 = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH + 16);
+        f32x2_t p[4] = {{v0[0] + bcol[0], v0[1] + bcol[1]}, {v0[2] + bcol[2], v0[3] + bcol[3]},
+                        {v1[0] + bcol[4], v1[1] + bcol[5]}, {v1[2] + bcol[6], v1[3] + bcol[7]}};
+        const int64_t o = ((int64_t)m * g.ldc + sn0 + ccol) * 2;
+        if constexpr (EPI == EPI_GELU) {
+          if (g.C2) *reinterpret_cast<u32x4_t*>(g.C2 + o) = u32x4_t{pack2bf(p[0][0], p[0][1]), pack2bf(p[1][0], p[1][1]), pack2bf(p[2][0], p[2][1]), pack2bf(p[3][0], p[3][1])};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[e] = gelu_sig2(p[e]);
+        }
+        *reinterpret_cast<u32x4_t*>(g.C + o) = u32x4_t{pack2bf(p[0][0], p[0][1]), pack2bf(p[1][0], p[1][1]), pack2bf(p[2][0], p[2][1]), pack2bf(p[3][0], p[3][1])};
+      } else {
+        f4_t v = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH);
+        v += f4_t{bcol[0], bcol[1], bcol[2], bcol[3]};
+        if constexpr (decltype(USE_RPRE)::value) v += rpre[j0 + j];
+        else v += *reinterpret_cast<const f4_t*>(g.resid + (int64_t)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldres + sn0 + ccol);
+        *reinterpret_cast<f4_t*>(g.C + ((int64_t)m * g.ldc + sn0 + ccol) * 4) = v;
+      }
+    }
+  };
+  if constexpr (SPEC) {
+    if (!loader) { stage_out(0); stage_out(1); }
+    __syncthreads();
+    finish_half(half0, 0, std::true_type{});
+  } else {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      stage_out(tm);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      finish_half(tm, 0, std::false_type{});
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int NLD, int EPI, int STAGES>
+int launch_lin(const LinArgs& a, hipStream_t s) {
+  constexpr int lds = STAGES * STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<NLD, EPI, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lin_kernel<NLD, EPI, STAGES>), dim3((a.M / 128) * a.tilesN), dim3(256 + 64 * NLD), lds, s, a);
+  COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
+}
+
+}  // namespace
+
+// Returns 1 when the launch does not qualify (the caller then uses gemm_kernel), otherwise the launch status (0 / < 0).
+int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
+  { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 1; }   // read per call: A/B inside one process (not on a replay path)
+  if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial) return 1;
+  if ((a->M % 128) || (a->N % 128) || (a->K % 64) || a->K < 128) return 1;
+  if ((a->lda % 8) || (a->ldb % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2) & 15)) return 1;
+  if ((int64_t)a->M * a->lda * 2 >= (int64_t)0x7fff0000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7fff0000ll) return 1;
+  if (!a->bias || ((uintptr_t)a->bias & 15)) return 1;
+  int epi;
+  if (a->out_bf16) {
+    if (a->resid || (a->ldc % 8)) return 1;
+#ifdef LIN_STAMP
+    if (a->act == COUNTR_ACT_NONE) epi = EPI_BF16;     // stamp builds: C2 carries the debug buffer
+#else
+    if (a->act == COUNTR_ACT_NONE && !a->C2) epi = EPI_BF16;
+#endif
+    else if (a->act == COUNTR_ACT_GELU) epi = EPI_GELU;
+    else return 1;
+  } else {
+#ifndef LIN_STAMP
+    if (a->C2) return 1;
+#endif
+    if (!a->resid || a->act != COUNTR_ACT_NONE || (a->ldc % 4) || (a->ldres % 4) || ((uintptr_t)a->resid & 15)) return 1;
+    epi = EPI_RES;
+  }
+  LinArgs g;
+  g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias; g.resid = a->resid;
+  g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
+  g.res_mod = a->res_mod; g.tilesN = a->N / 128;
+  const long tiles = (long)(a->M / 128) * g.tilesN;
+  static const int spec_max = [] { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); return e ? atoi(e) : 256; }();
+  const bool spec = tiles <= spec_max;
+  if (spec) {
+    int stages = 5;
+    { const char* e = getenv("COUNTR_LEAN_STAGES"); if (e) stages = atoi(e); }
+#define LIN_LAUNCH_SPEC(ST)                                            \
+    {                                                                  \
+      if (epi == EPI_BF16) return launch_lin<4, EPI_BF16, ST>(g, s);   \
+      if (epi == EPI_GELU) return launch_lin<4, EPI_GELU, ST>(g, s);   \
+      return launch_lin<4, EPI_RES, ST>(g, s);                         \
+    }
+    if (stages == 3) LIN_LAUNCH_SPEC(3)
+    if (stages == 4) LIN_LAUNCH_SPEC(4)
+    LIN_LAUNCH_SPEC(5)
+#undef LIN_LAUNCH_SPEC
+  }
+  if (epi == EPI_BF16) return launch_lin<0, EPI_BF16, 2>(g, s);
+  if (epi == EPI_GELU) return launch_lin<0, EPI_GELU, 2>(g, s);
+  return launch_lin<0, EPI_RES, 2>(g, s);
+}

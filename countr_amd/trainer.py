@@ -161,32 +161,130 @@ class _GraphStep:
         self._ring_ev[slot] = ev
 
     # ------------------------------------------------------------------ optimizer state (checkpoint 'optimizer' entry)
+    # The checkpoint's 'optimizer' entry is a torch.optim.AdamW state_dict in the REFERENCE's parameter order (util/misc.py:312-318
+    # saves optimizer.state_dict(); :400-421 loads it under --do_resume), so checkpoints move between the two code bases in both
+    # directions: timm's add_weight_decay (FSC_finetune_cross.py:234, FSC_pretrain.py:226) puts every requires_grad parameter that is
+    # 1-D or a bias into group 0 and the rest into group 1, each in named_parameters() order -- INCLUDING the encoder, whose
+    # parameters sit in the groups but never get a gradient (forward_encoder runs under no_grad) and therefore never get state.
+    FROZEN = ("pos_embed", "decoder_pos_embed")          # requires_grad=False in the reference (models_mae_cross.py:30,42)
+
+    def _torch_param_order(self):
+        from .engine import no_weight_decay
+        shapes = self.eng.layout.shapes
+        names = [n for n, _ in self.model.named_parameters() if n not in self.FROZEN]
+        nd = [n for n in names if no_weight_decay(n, shapes[n])]
+        dc = [n for n in names if not no_weight_decay(n, shapes[n])]
+        return nd, dc
+
+    def _bucket_of(self, name):
+        lay = self.eng.layout
+        o = lay.off[name] - lay.train_start
+        for (bucket, _nodecay), s0, e0 in lay.segments:
+            if s0 <= o < e0:
+                return bucket
+        raise KeyError(name)
+
+    def _group_of_bucket(self, bucket):
+        """AdamW step-counter group of a gradient bucket (engine.ADAM_GROUP_OF_BUCKET for finetuning; one group otherwise)."""
+        return 0
+
+    def _conditional_buckets(self):
+        return ()
+
     def optimizer_state(self):
-        """Flat AdamW state of the engine: first / second moments over the trainable region, the global step and the per-group step
-        counters.  (A reference checkpoint stores torch's per-tensor state dict instead; see load_optimizer_state.)"""
+        """torch.optim.AdamW.state_dict() of the equivalent reference optimizer: per-parameter {'step', 'exp_avg', 'exp_avg_sq'} for
+        every parameter that has had a gradient, two param_groups in timm's add_weight_decay order."""
         eng = self.eng
-        return {"format": "countr_amd.flat_adamw.v2", "step": eng.step_count, "group_steps": list(eng.group_steps),
-                "seen_buckets": sorted(eng.opt_seen), "exp_avg": eng.M.cpu() if eng.M is not None else None,
-                "exp_avg_sq": eng.V.cpu() if eng.V is not None else None}
+        nd, dc = self._torch_param_order()
+        index = {n: i for i, n in enumerate(nd + dc)}
+        state = {}
+        if eng.M is not None and eng.step_count > 0:
+            M, V = eng.M.cpu(), eng.V.cpu()
+            lay = eng.layout
+            import math
+            for n in lay.train_names:
+                b = self._bucket_of(n)
+                if b in self._conditional_buckets() and b not in eng.opt_seen:
+                    continue                       # never had a gradient: torch has no state for it
+                o = lay.off[n] - lay.train_start
+                k = math.prod(lay.shapes[n])
+                shp = lay.shapes[n]
+                t = eng.group_steps[self._group_of_bucket(b)]
+                state[index[n]] = {"step": torch.tensor(float(t)), "exp_avg": M[o:o + k].view(shp).clone(),
+                                   "exp_avg_sq": V[o:o + k].view(shp).clone()}
+        common = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "amsgrad": False, "maximize": False, "foreach": None,
+                  "capturable": False}
+        groups = [dict(common, weight_decay=0.0, params=list(range(len(nd)))),
+                  dict(common, weight_decay=self.wd, params=list(range(len(nd), len(nd) + len(dc))))]
+        return {"state": state, "param_groups": groups,
+                "countr_amd": {"format": "torch_adamw.v3", "step": eng.step_count, "group_steps": list(eng.group_steps),
+                               "seen_buckets": sorted(eng.opt_seen)}}
+
+    def _moments(self):
+        eng = self.eng
+        if eng.M is None:
+            eng.M = torch.zeros_like(eng.G)
+            eng.V = torch.zeros_like(eng.G)
+        return eng.M, eng.V
 
     def load_optimizer_state(self, opt):
-        """Restores optimizer_state(); returns False (and prints why) when `opt` is not ours -- e.g. the torch.optim.AdamW
-        state_dict of a reference checkpoint, whose per-tensor entries are keyed by parameter-group order and cannot be mapped
-        onto the flat buffers without the reference's parameter list."""
+        """Restores a checkpoint's 'optimizer' entry: a torch.optim.AdamW state_dict (ours or the reference's -- same layout) or the
+        flat v1 / v2 form older countr_amd checkpoints hold.  The moments are copied INTO the existing buffers (captured graphs keep
+        pointing at them).  Raises on a state that does not fit this model; returns True."""
         eng = self.eng
-        if not isinstance(opt, dict) or opt.get("exp_avg") is None:
-            print("checkpoint 'optimizer' entry is not a countr_amd flat AdamW state (torch per-tensor state?): optimizer state NOT restored")
-            return False
-        if opt["exp_avg"].numel() != eng.G.numel() or opt["exp_avg_sq"].numel() != eng.G.numel():
-            print("checkpoint optimizer state has %d elements, this model trains %d: optimizer state NOT restored"
-                  % (opt["exp_avg"].numel(), eng.G.numel()))
-            return False
-        eng.M = opt["exp_avg"].to(eng.device, torch.float32)
-        eng.V = opt["exp_avg_sq"].to(eng.device, torch.float32)
-        eng.step_count = int(opt["step"])
-        gs = opt.get("group_steps")
-        eng.group_steps = [int(x) for x in gs] if gs is not None else [eng.step_count] * 3   # v1 files: one global counter
-        eng.opt_seen = set(int(b) for b in opt.get("seen_buckets", (2, 3) if eng.step_count else ()))
+        M, V = self._moments()
+        if isinstance(opt, dict) and opt.get("exp_avg") is not None:            # flat v1 / v2
+            if opt["exp_avg"].numel() != eng.G.numel() or opt["exp_avg_sq"].numel() != eng.G.numel():
+                raise ValueError("checkpoint optimizer state has %d elements, this model trains %d" % (opt["exp_avg"].numel(), eng.G.numel()))
+            M.copy_(opt["exp_avg"].to(torch.float32))
+            V.copy_(opt["exp_avg_sq"].to(torch.float32))
+            eng.step_count = int(opt["step"])
+            gs = opt.get("group_steps")
+            eng.group_steps = [int(x) for x in gs] if gs is not None else [eng.step_count] * 3   # v1 files: one global counter
+            eng.opt_seen = set(int(b) for b in opt.get("seen_buckets", (2, 3) if eng.step_count else ()))
+            return True
+        if not isinstance(opt, dict) or "state" not in opt or "param_groups" not in opt:
+            raise ValueError("checkpoint 'optimizer' entry is neither a torch.optim.AdamW state_dict nor a countr_amd flat AdamW state")
+        nd, dc = self._torch_param_order()
+        pg = opt["param_groups"]
+        if len(pg) != 2 or len(pg[0]["params"]) != len(nd) or len(pg[1]["params"]) != len(dc):
+            raise ValueError("optimizer state_dict has groups of %s parameters, this model's add_weight_decay groups hold %s"
+                             % ([len(g_["params"]) for g_ in pg], [len(nd), len(dc)]))
+        ids = list(pg[0]["params"]) + list(pg[1]["params"])
+        name_of = dict(zip(ids, nd + dc))
+        lay = eng.layout
+        trainable = set(lay.train_names)
+        import math
+        M.zero_()
+        V.zero_()
+        steps = {}            # counter group -> step
+        seen = set()
+        for pid, st_ in opt["state"].items():
+            n = name_of.get(pid, name_of.get(int(pid)) if not isinstance(pid, int) else None)
+            if n is None:
+                raise ValueError("optimizer state for unknown parameter id %r" % (pid,))
+            if n not in trainable:
+                raise ValueError("optimizer state for %s, which this engine does not train" % n)
+            if tuple(st_["exp_avg"].shape) != tuple(lay.shapes[n]):
+                raise ValueError("optimizer state of %s has shape %s, expected %s" % (n, tuple(st_["exp_avg"].shape), tuple(lay.shapes[n])))
+            o = lay.off[n] - lay.train_start
+            k = math.prod(lay.shapes[n])
+            M[o:o + k].copy_(st_["exp_avg"].reshape(-1).to(torch.float32))
+            V[o:o + k].copy_(st_["exp_avg_sq"].reshape(-1).to(torch.float32))
+            b = self._bucket_of(n)
+            t = int(float(st_["step"]))
+            g_ = self._group_of_bucket(b)
+            if steps.setdefault(g_, t) != t:
+                raise ValueError("parameters of one AdamW counter group carry different step counts (%d vs %d at %s): "
+                                 "not a state this fused optimizer can continue" % (steps[g_], t, n))
+            if b in self._conditional_buckets():
+                seen.add(b)
+        eng.group_steps = [int(steps.get(g_, 0)) for g_ in range(3)]
+        eng.step_count = max(eng.group_steps)
+        eng.opt_seen = seen
+        extra = opt.get("countr_amd")
+        if isinstance(extra, dict):                   # our own files also carry the global counter (pinned-slot rotation only)
+            eng.step_count = int(extra.get("step", eng.step_count))
         return True
 
     def _step(self, key):
@@ -260,6 +358,13 @@ class FinetuneStep(_GraphStep):
     def _make_sync(self, process_group):
         lay = self.eng.layout   # buckets in backward-completion order: head | decoder blocks + embed | exemplar CNN | shot_token
         return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
+
+    def _group_of_bucket(self, bucket):
+        from .engine import ADAM_GROUP_OF_BUCKET
+        return ADAM_GROUP_OF_BUCKET.get(bucket, 0)
+
+    def _conditional_buckets(self):
+        return (2, 3)            # exemplar CNN (gradient only when shot_num > 0), shot_token (only when shot_num == 0)
 
     def _comm_skip(self, touched):
         """Conditional buckets without a gradient in this window (exemplar CNN when every micro-step had shot_num 0, shot_token

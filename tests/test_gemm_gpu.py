@@ -407,3 +407,69 @@ def test_splitk_finish_matches_unsplit_conv(hip, obf):
     assert torch.isfinite(out.float()).all()
     scale = ref.float().abs().max().item()
     assert (out.float() - ref.float()).abs().max().item() <= (8e-3 if obf else 2e-5) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 192), (4608, 512, 512), (1152, 768, 3072), (4608, 1536, 256)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "gelu_pre", "res", "resmod"])
+def test_lean_linear_matches_fp64_and_generic(hip, monkeypatch, M, N, K, epi):
+    """csrc/linear.hip (full-tile nn.Linear forward: 32x32x16 MFMA, staged epilogue, sigmoid-polynomial GELU) through countr_gemm:
+    every epilogue, the wave-specialised (<= 256 tiles) and the plain launch form, against torch fp64 and against gemm_kernel on the
+    same inputs (COUNTR_LEAN=0).  Operands are bf16-exact, so the only error is fp32 accumulation order + the output rounding
+    (+ <= 2.6e-5 absolute of the GELU fit)."""
+    A = _mk((M, K), torch.bfloat16, 21)
+    W = (_mk((N, K), torch.float32, 22) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 23)
+    obf = epi in ("bf16", "gelu", "gelu_pre")
+    rmod = 128 if epi == "resmod" else 0
+    resid = None if obf else _mk((rmod if rmod else M, N), torch.float32, 24)
+    z = A.double() @ W.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(z) if epi.startswith("gelu") else z
+    if resid is not None:
+        ref = ref + (resid.double().repeat(M // rmod, 1) if rmod else resid.double())
+    outs = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("COUNTR_LEAN", lean)
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if obf else torch.float32)
+        pre = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) if epi == "gelu_pre" else None
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+        a.C2 = pre.data_ptr() if pre is not None else None
+        a.bias = bias.data_ptr()
+        a.resid = resid.data_ptr() if resid is not None else None
+        a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
+        a.M, a.N, a.K = M, N, K
+        a.res_mod = rmod
+        a.act = 1 if epi.startswith("gelu") else 0
+        a.out_bf16 = int(obf)
+        a.alpha = 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+        torch.cuda.synchronize()
+        tol = 4e-3 if obf else 2e-5                      # bf16 rounding (2^-9 relative to the element, <= that of the maximum) / fp32 order
+        scale = ref.abs().max().item()
+        assert torch.isfinite(out.float()).all()
+        assert (out.double() - ref).abs().max().item() <= tol * scale + 3e-5, (lean, (out.double() - ref).abs().max().item(), scale)
+        if pre is not None:
+            assert (pre.double() - z).abs().max().item() <= 4e-3 * z.abs().max().item()
+        outs.append(out)
+    # the two kernels differ by accumulation order (and the GELU form): far below one bf16 ulp of the largest element
+    assert (outs[0].double() - outs[1].double()).abs().max().item() <= (8e-3 if obf else 2e-5) * ref.abs().max().item()
+
+
+def test_lean_linear_in_place_residual(hip):
+    """proj / fc2 write the residual stream in place (C == resid): every element is read before it is written by the same lane."""
+    M, N, K = 4608, 768, 768
+    A = _mk((M, K), torch.bfloat16, 31)
+    W = (_mk((N, K), torch.float32, 32) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 33)
+    x = _mk((M, N), torch.float32, 34)
+    ref = x.double() + A.double() @ W.double().t() + bias.double()
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C, a.resid, a.bias = A.data_ptr(), W.data_ptr(), x.data_ptr(), x.data_ptr(), bias.data_ptr()
+    a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
+    a.M, a.N, a.K = M, N, K
+    a.alpha = 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+    torch.cuda.synchronize()
+    assert (x.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
