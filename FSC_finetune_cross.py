@@ -88,9 +88,11 @@ def main(args):
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95),
                         accum_iter=args.accum_iter)
     if ckpt is not None and args.do_resume and "epoch" in ckpt:      # util/misc.py:400-421: optimizer / epoch only with --do_resume
+        # (raises when the entry fits neither this model's torch.optim.AdamW layout nor the older flat form: continuing late in the
+        # LR schedule with zeroed moments would be a silent restart of the bias correction)
+        step.load_optimizer_state(ckpt.get("optimizer"))
         args.start_epoch = ckpt["epoch"] + 1
-        if step.load_optimizer_state(ckpt.get("optimizer")):
-            print("With optim & sched!")
+        print("With optim & sched!")
     from countr_amd.data import fsc147
     loader = val_loader = None
     if args.synthetic_steps <= 0 and fsc147.available(args):

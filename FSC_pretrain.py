@@ -82,9 +82,9 @@ def main(args):
     step = PretrainStep(model, batch=args.batch_size, mask_ratio=args.mask_ratio, lr=args.lr, weight_decay=args.weight_decay,
                         betas=(0.9, 0.95), accum_iter=args.accum_iter)
     if ckpt is not None and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:352-361
-        if step.load_optimizer_state(ckpt["optimizer"]):                  # (element count checked; a torch per-tensor dict is reported)
-            args.start_epoch = ckpt["epoch"] + 1
-            print("With optim & sched!")
+        step.load_optimizer_state(ckpt["optimizer"])      # torch.optim.AdamW state_dict (ours or the reference's) or the older flat form; raises otherwise
+        args.start_epoch = ckpt["epoch"] + 1
+        print("With optim & sched!")
     from countr_amd.data import fsc147
     loader = None
     if args.synthetic_steps <= 0 and fsc147.available(args):

@@ -69,12 +69,11 @@ template <int PENDING> __device__ __forceinline__ void frag_wait(bf16x8_t (&f)[4
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(PENDING));
 }
 
-// x * Phi(x) as x * sigmoid(x (c0 + c1 x^2 + c2 x^4)), coefficients fitted (minimax over [-9, 9], tools/fit_gelu.py) and pre-multiplied
-// by -log2(e); the polynomial argument is clamped to |x| <= 8 (the fitted quartic turns around near |x| = 10).
+// packed form of common.cuh's gelu_fast (same operations on fp32 pairs: bit-identical results)
 __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
   const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -8.f, 8.f), __builtin_amdgcn_fmed3f(x[1], -8.f, 8.f)};
   const f32x2_t x2 = xc * xc;
-  const f32x2_t k0 = {-2.30112137f, -2.30112137f}, k1 = {-0.10677575f, -0.10677575f}, k2 = {1.01426498e-3f, 1.01426498e-3f};
+  const f32x2_t k0 = {COUNTR_GELU_K0, COUNTR_GELU_K0}, k1 = {COUNTR_GELU_K1, COUNTR_GELU_K1}, k2 = {COUNTR_GELU_K2, COUNTR_GELU_K2};
   f32x2_t t = __builtin_elementwise_fma(x2, k2, k1);
   t = __builtin_elementwise_fma(t, x2, k0);
   const f32x2_t u = t * xc;
@@ -85,19 +84,26 @@ __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
   return x * r;
 }
 
-template <int NLD, int EPI, int STAGES>
-__global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g) {
+// WMB = 128-row blocks per workgroup tile (1: 128x128, 4 compute waves; 2: 256x128, 8 compute waves -- 2/3 of the staged bytes per MFMA,
+// for grids that still fill the chip with half as many tiles); NLD = loader waves (0: every wave stages and multiplies).
+template <int WMB, int NLD, int EPI, int STAGES>
+__global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 * WMB + NLD) / 4) : 2) void lin_kernel(const LinArgs g) {
   constexpr bool SPEC = NLD > 0;
-  static_assert(SPEC ? (STAGES >= 3 && STAGES <= 5) : STAGES == 2, "ring depth");
+  constexpr bool TWO = SPEC && STAGES == 2;     // wave-specialised with a 2-stage ring: TWO workgroups per CU (64 KB, 128 VGPRs each)
+  static_assert(SPEC ? (STAGES >= 2 && STAGES <= 5) : (STAGES == 2 && WMB == 1), "ring depth / plain form");
+  static_assert(!TWO || (WMB == 1 && NLD == 4), "two-per-CU form");
+  constexpr int NCW = 4 * WMB;                  // compute waves, (2 WMB) x 2 sub-tiles of 64x64
   constexpr int NLW = SPEC ? NLD : 4;           // waves that stage tiles
-  constexpr int PASSES = 128 / (8 * NLW);       // 1-KiB pieces per operand per staging wave per k-tile
-  static_assert(NLW == 4, "row swizzle below assumes 32-row passes");
+  static_assert(NLW == 4, "four staging waves");
+  constexpr int BMt = 128 * WMB;
+  constexpr int A_BYTES = BMt * 128, STAGE_BYTES = A_BYTES + 16384;
+  constexpr int PA = BMt / (8 * NLW), PB = 128 / (8 * NLW);   // 1-KiB pieces per operand per staging wave per k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = SPEC && wv >= 4;
-  const int cw = wv & 3;                         // compute-wave index / loader index
+  const bool loader = SPEC && wv >= NCW;
+  const int cw = loader ? wv - NCW : wv;         // index inside its role (plain form: both)
   // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns one contiguous range of the (tile_m, tile_n) space
   int lt;
   {
@@ -105,17 +111,17 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
     lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
   const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
-  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int m0 = tile_m * BMt, n0 = tile_n * 128;
   const int ntiles = g.K >> 6;
 
-  // ---- LDS-DMA set-up (staging waves): piece (pass i, wave w) = rows [32 i + 8 w, +8) of the 128-row tile, lane -> (row, 16-byte slot)
+  // ---- LDS-DMA set-up (staging waves): piece (pass i, wave w) = rows [8 NLW i + 8 w, +8) of the operand tile, lane -> (row, 16-byte slot)
   const int drow = cw * 8 + (lane >> 3);
   const int dchunk = (lane & 7) ^ (((cw & 1) << 2) | (lane >> 4));        // = slot ^ ((row >> 1) & 7), pass-independent
   const uint32_t voffA = (uint32_t)((drow * g.lda + dchunk * 8) * 2);
   const uint32_t voffB = (uint32_t)((drow * g.ldw + dchunk * 8) * 2);
   const char* baseA = g.A + (int64_t)m0 * g.lda * 2;
   const char* baseB = g.W + (int64_t)n0 * g.ldw * 2;
-  const uint32_t passA = (uint32_t)g.lda * 64u, passB = (uint32_t)g.ldw * 64u;   // 32 rows further, bytes
+  const uint32_t passA = (uint32_t)g.lda * (16u * NLW), passB = (uint32_t)g.ldw * (16u * NLW);   // 8 NLW rows further, bytes
   auto issue = [&](int t, int slot) {
 #if LIN_ABL == 3
     if (t >= 2) return;
@@ -124,15 +130,15 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
     const char* ua = baseA + t * 128;
     const char* ub = baseB + t * 128;
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i)
-      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ua + i * passA + voffA), (lds_vptr_t)(dst + i * 4096), 16, 0, 0);
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ua + i * passA + voffA), (lds_vptr_t)(dst + i * NLW * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i)
-      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ub + i * passB + voffB), (lds_vptr_t)(dst + B_OFF + i * 4096), 16, 0, 0);
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ub + i * passB + voffB), (lds_vptr_t)(dst + A_BYTES + i * NLW * 1024), 16, 0, 0);
   };
 
   // loader waves start the ring before anything else; the memory clobber keeps the prefetch loads below BEHIND these in issue order
-  // (the first wait of the loader loop counts them: vmcnt = one tile + NPRE younger loads)
+  // (the first wait of the loader loop counts them: vmcnt = the younger tiles + NPRE younger loads)
   if constexpr (SPEC) {
     if (loader) {
 #pragma unroll
@@ -142,16 +148,17 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
     asm volatile("" ::: "memory");
   }
 
-  // ---- read-back geometry (epilogue): which rows / columns this wave's lanes finish
-  // SPEC: wave w (0..7) finishes rows [32 (w >> 2), +32) of compute wave (w & 3)'s 64x64 sub-tile; plain: its own 64 rows in two passes.
-  const int sub = cw;                                   // sub-tile whose staging region this wave reads
-  const int sm0 = m0 + (sub >> 1) * 64, sn0 = n0 + (sub & 1) * 64;
+  // ---- read-back geometry (epilogue).  A unit = 32 rows x 64 columns of one compute wave's 64x64 sub-tile.  SPEC: compute wave c
+  // finishes rows [0, 32) of its own sub-tile, loader l rows [32, 64) of sub-tiles l, l + 4 (, ...); plain: both halves of its own.
   constexpr bool OBF = EPI != EPI_RES;
+  constexpr int NUNITS = SPEC ? WMB : 1;               // read-back units of a loader wave (a compute wave has one)
+  const int sub0 = loader ? (cw & 3) : wv;             // first sub-tile this wave reads back (NCW is a multiple of 4: same column half)
+  const int sn0 = n0 + (sub0 & 1) * 64;
   // bf16 out: lane -> 8 columns (2 fp32 chunks), 8 lanes per row;  fp32 out: lane -> 4 columns, 16 lanes per row
   const int ccol = OBF ? (lane & 7) * 8 : (lane & 15) * 4;
   const int rrow = OBF ? (lane >> 3) : (lane >> 4);     // + 8 j (bf16) / 4 j (fp32)
   constexpr int RSTEP = OBF ? 8 : 4, NIT_HALF = 32 / RSTEP;     // iterations per 32 rows
-  const int half0 = SPEC ? (wv >> 2) : 0;               // SPEC: the one 32-row half this wave finishes
+  const int half0 = loader ? 1 : 0;
   float bcol[OBF ? 8 : 4];
   {
     const float4 b0 = *reinterpret_cast<const float4*>(g.bias + sn0 + ccol);
@@ -161,22 +168,26 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
       bcol[4] = b1.x; bcol[5] = b1.y; bcol[6] = b1.z; bcol[7] = b1.w;
     }
   }
-  // residual prefetch (SPEC): the 8 row segments this wave will add, fetched before the main loop
+  // residual prefetch (SPEC): the row segments this wave will add, fetched before the main loop
   typedef __attribute__((ext_vector_type(4))) float f4_t;
-  f4_t rpre[(SPEC && EPI == EPI_RES) ? 8 : 1];
-  if constexpr (SPEC && EPI == EPI_RES) {
-    const int mrow0 = sm0 + half0 * 32 + rrow;
-    if (g.res_mod > 0) {   // row modulo (pos-embed adds): one division, then steps of 4 rows with a conditional wrap
-      int mr = mrow0 % g.res_mod;
+  constexpr bool RPRE = SPEC && !TWO && EPI == EPI_RES;
+  f4_t rpre[RPRE ? 8 : 1];          // first unit only (a loader's further units fetch at use: register budget)
+  if constexpr (RPRE) {
+    {
+      constexpr int u = 0;
+      const int mrow0 = m0 + ((sub0 + 4 * u) >> 1) * 64 + half0 * 32 + rrow;
+      if (g.res_mod > 0) {   // row modulo (pos-embed adds): one division, then steps of 4 rows with a conditional wrap
+        int mr = mrow0 % g.res_mod;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        rpre[j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g.resid + (int64_t)mr * g.ldres + sn0 + ccol));
-        mr += 4; if (mr >= g.res_mod) mr -= g.res_mod;
+        for (int j = 0; j < 8; ++j) {
+          rpre[8 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g.resid + (int64_t)mr * g.ldres + sn0 + ccol));
+          mr += 4; if (mr >= g.res_mod) mr -= g.res_mod;
+        }
+      } else {
+        const float* rb = g.resid + (int64_t)mrow0 * g.ldres + sn0 + ccol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rpre[8 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(rb + (int64_t)(4 * j) * g.ldres));
       }
-    } else {
-      const float* rb = g.resid + (int64_t)mrow0 * g.ldres + sn0 + ccol;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rpre[j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(rb + (int64_t)(4 * j) * g.ldres));
     }
   }
 
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     xoff[kk] = (uint32_t)((wm * 64 + l31) * 128 + (((kk * 2 + lh) ^ swx) << 4));
-    woff[kk] = (uint32_t)(B_OFF + (wn * 64 + prow) * 128 + (((kk * 2 + lh) ^ sww) << 4));
+    woff[kk] = (uint32_t)(A_BYTES + (wn * 64 + prow) * 128 + (((kk * 2 + lh) ^ sww) << 4));
   }
   f32x16_t acc[2][2];
 #pragma unroll
@@ -199,90 +210,12 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  bf16x8_t fr[4][4];   // [set][x0, x1, w0, w1]; SPEC: set = k-step
+  bf16x8_t fr[TWO ? 2 : 4][4];   // [set][x0, x1, w0, w1]; set = k-step (two-per-CU form: alternating)
   uint32_t sbase = lds_u32(smem);
-  auto request = [&](auto KK, int set) {
-    constexpr int kk = decltype(KK)::value;
-    const uint32_t xa = sbase + xoff[kk], wa = sbase + woff[kk];
-#if LIN_ABL == 2
-    for (int q = 0; q < 4; ++q) fr[set][q] = __builtin_bit_cast(bf16x8_t, u32x4_t{xa, wa, (uint32_t)q, 1u});
-    return;
-#endif
-    fr[set][0] = ds_read128<0>(xa);
-    fr[set][1] = ds_read128<4096>(xa);
-    fr[set][2] = ds_read128<0>(wa);
-    fr[set][3] = ds_read128<4096>(wa);
-  };
-  auto mma = [&](int set) {
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#if LIN_ABL == 1
-      { const u32x4_t a_ = __builtin_bit_cast(u32x4_t, fr[set][2 + tn]), b_ = __builtin_bit_cast(u32x4_t, fr[set][tm]);
-        acc[tm][tn][0] += __uint_as_float(a_[0] ^ b_[0]); acc[tm][tn][5] += __uint_as_float(a_[1] ^ b_[1]);
-        acc[tm][tn][10] += __uint_as_float(a_[2] ^ b_[2]); acc[tm][tn][15] += __uint_as_float(a_[3] ^ b_[3]); }
-#else
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[set][2 + tn], fr[set][tm], acc[tm][tn], 0, 0, 0);
-#endif
-  };
+  uint32_t xa, wa;
+  auto addr = [&](auto KK) { constexpr int kk = decltype(KK)::value; xa = sbase + xoff[kk]; wa = sbase + woff[kk]; };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
-  // k-steps 0..2 of the tile whose step-0 fragments (set 0) are already requested; leaves step 3 (set 1) requested
-  auto steps012 = [&] {
-    request(K1{}, 1); frag_wait<4>(fr[0]); mma(0); __builtin_amdgcn_sched_barrier(0);
-    request(K2{}, 0); frag_wait<4>(fr[1]); mma(1); __builtin_amdgcn_sched_barrier(0);
-    request(K3{}, 1); frag_wait<4>(fr[0]); mma(0); __builtin_amdgcn_sched_barrier(0);
-  };
-
-  if constexpr (SPEC) {
-    if (loader) {
-      // loader waves: keep STAGES-1 tiles in flight; tile t has landed when at most (STAGES-2) tiles' worth of loads are outstanding
-      constexpr int NPRE = (OBF ? 2 : 1) + (EPI == EPI_RES ? 8 : 0);   // bias / residual loads issued after the first STAGES-1 tiles
-      int islot = STAGES - 1;
-#ifdef LIN_STAMP   // s_memtime anatomy (tools/stamp_lin.py): loaders [1] load wait [2] barrier [3] DMA issue; compute waves [2] barrier [4] the rest
-      uint64_t sk1 = 0, sk2 = 0, sk3 = 0;
-      const uint64_t sk0 = __builtin_readcyclecounter(), sr0 = wall_clock64();
-#define LSTAMP(x) const uint64_t x = __builtin_readcyclecounter()
-#else
-#define LSTAMP(x)
-#endif
-      for (int t = 0; t < ntiles; ++t) {
-        LSTAMP(ua);
-        if (t == 0 && STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 2 * PASSES + NPRE) : "memory");
-        else if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 2 * PASSES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        LSTAMP(ub);
-        __builtin_amdgcn_s_barrier();
-        LSTAMP(uc);
-        if (t + STAGES - 1 < ntiles) issue(t + STAGES - 1, islot);
-        islot = (islot + 1 == STAGES) ? 0 : islot + 1;
-#ifdef LIN_STAMP
-        { LSTAMP(ud); sk1 += ub - ua; sk2 += uc - ub; sk3 += ud - uc; }
-#endif
-      }
-#ifdef LIN_STAMP
-      if (lane == 0 && g.C2 && EPI != EPI_GELU) {
-        float* d = reinterpret_cast<float*>(g.C2) + ((int64_t)blockIdx.x * 8 + wv) * 8;
-        d[0] = (float)(__builtin_readcyclecounter() - sk0); d[1] = (float)sk1; d[2] = (float)sk2; d[3] = (float)sk3;
-        d[5] = (float)ntiles; d[6] = 1.f; d[7] = (float)(wall_clock64() - sr0);
-      }
-#endif
-    } else {
-      // compute waves.  One fragment set per k-step of a tile; the reads of k-step s+2 are issued one by one BETWEEN the MFMAs of
-      // k-step s (a ds_read_b128 issues under the 32 cycles of the MFMA in front of it; four reads in a row behind four MFMAs left the
-      // matrix pipe idle for the issue time of the last three: 740 cycles per k-tile with NO DMA traffic at all,
-      // profiles/r3_linear_ablation.txt), so a set has a full k-step (128 matrix cycles) to land.  At the tile boundary: k-step 2's
-      // MFMAs (no reads), every read of tile t landed, barrier t+1 (the loaders may now refill tile t's slot; tile t+1 is visible),
-      // then k-step 3's MFMAs carry the EIGHT reads of tile t+1's k-steps 0 and 1.
-      int slot = 0, t = 0;
-#ifdef LIN_STAMP
-      uint64_t ck2 = 0;
-      const uint64_t ck0 = __builtin_readcyclecounter(), cr0 = wall_clock64();
-#endif
-      __builtin_amdgcn_s_barrier();
-      uint32_t xa, wa;
-      auto addr = [&](auto KK) { constexpr int kk = decltype(KK)::value; xa = sbase + xoff[kk]; wa = sbase + woff[kk]; };
 #if LIN_ABL == 2
 #define LIN_RD(SET, Q, OFF, A) fr[SET][Q] = __builtin_bit_cast(bf16x8_t, u32x4_t{A, (uint32_t)(OFF), (uint32_t)(Q), 1u})
 #else
@@ -296,17 +229,84 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
 #define LIN_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[SET][2 + TN], fr[SET][TM], acc[TM][TN], 0, 0, 0)
 #endif
 #define LIN_SB __builtin_amdgcn_sched_barrier(0)
-      // MFMAs of set U with the four reads of set R (addresses xa / wa) between them
+  // MFMAs of set U with the four reads of set R (addresses xa / wa) between them
 #define LIN_STEP_RD(U, R) LIN_MM(U, 0, 0); LIN_SB; LIN_RD(R, 0, 0, xa); LIN_SB; LIN_MM(U, 0, 1); LIN_SB; LIN_RD(R, 2, 0, wa); LIN_SB; \
                           LIN_MM(U, 1, 0); LIN_SB; LIN_RD(R, 1, 4096, xa); LIN_SB; LIN_MM(U, 1, 1); LIN_SB; LIN_RD(R, 3, 4096, wa); LIN_SB
 #define LIN_STEP(U) LIN_MM(U, 0, 0); LIN_MM(U, 0, 1); LIN_MM(U, 1, 0); LIN_MM(U, 1, 1); LIN_SB
-      addr(K0{}); LIN_RD(0, 0, 0, xa); LIN_RD(0, 1, 4096, xa); LIN_RD(0, 2, 0, wa); LIN_RD(0, 3, 4096, wa);
-      addr(K1{}); LIN_RD(1, 0, 0, xa); LIN_RD(1, 1, 4096, xa); LIN_RD(1, 2, 0, wa); LIN_RD(1, 3, 4096, wa);
+#define LIN_RD4(SET) LIN_RD(SET, 0, 0, xa); LIN_RD(SET, 1, 4096, xa); LIN_RD(SET, 2, 0, wa); LIN_RD(SET, 3, 4096, wa)
+#ifdef LIN_STAMP   // s_memtime anatomy (tools/stamp_lin.py): loaders [1] load wait [2] barrier [3] DMA issue; compute waves [2] barrier
+#define LSTAMP(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define LSTAMP(x)
+#endif
+
+  if constexpr (SPEC) {
+    if (loader) {
+      // loader waves: keep STAGES-1 tiles in flight; tile t has landed when at most (STAGES-2) tiles' worth of loads are outstanding
+      constexpr int PER = PA + PB;
+      constexpr int NPRE = (OBF ? 2 : 1) + (RPRE ? 8 : 0);   // bias / residual loads issued after the first STAGES-1 tiles
+      static_assert((STAGES - 2) * PER + NPRE <= 63, "vmcnt immediate");
+      int islot = STAGES - 1;
+#ifdef LIN_STAMP
+      uint64_t sk1 = 0, sk2 = 0, sk3 = 0;
+      const uint64_t sk0 = __builtin_readcyclecounter(), sr0 = wall_clock64();
+#endif
+      for (int t = 0; t < ntiles; ++t) {
+        LSTAMP(ua);
+        if (t == 0 && STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER + NPRE) : "memory");
+        else if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LSTAMP(ub);
+        __builtin_amdgcn_s_barrier();
+        LSTAMP(uc);
+        if (t + STAGES - 1 < ntiles) issue(t + STAGES - 1, islot);
+        islot = (islot + 1 == STAGES) ? 0 : islot + 1;
+#ifdef LIN_STAMP
+        { LSTAMP(ud); sk1 += ub - ua; sk2 += uc - ub; sk3 += ud - uc; }
+#endif
+      }
+#ifdef LIN_STAMP
+      if (lane == 0 && g.C2 && EPI != EPI_GELU) {
+        float* d = reinterpret_cast<float*>(g.C2) + ((int64_t)blockIdx.x * (NCW + NLD) + wv) * 8;
+        d[0] = (float)(__builtin_readcyclecounter() - sk0); d[1] = (float)sk1; d[2] = (float)sk2; d[3] = (float)sk3;
+        d[5] = (float)ntiles; d[6] = 1.f; d[7] = (float)(wall_clock64() - sr0);
+      }
+#endif
+      __builtin_amdgcn_s_barrier();   // ring free (the compute waves' last in-loop barrier): every wave is past its last tile
+    } else {
+      // compute waves.  One fragment set per k-step of a tile; the reads of k-step s+2 are issued one by one BETWEEN the MFMAs of
+      // k-step s (a ds_read_b128 issues under the 32 cycles of the MFMA in front of it), so a set has a full k-step (128 matrix
+      // cycles) to land.  At the tile boundary: k-step 2's MFMAs (no reads), every read of tile t landed, barrier t+1 (the loaders may
+      // now refill tile t's slot; tile t+1 is visible), then k-step 3's MFMAs carry the EIGHT reads of tile t+1's k-steps 0 and 1.
+      // The loop body is the same for every tile, the last included: its barrier is the "ring free" barrier the loaders join after
+      // their loop, and its eight look-ahead reads fetch stale ring bytes that nobody uses (a peeled last tile made the register
+      // allocator copy all 64 accumulator registers once per tile).
+      int slot = 0;
+#ifdef LIN_STAMP
+      uint64_t ck2 = 0;
+      const uint64_t ck0 = __builtin_readcyclecounter(), cr0 = wall_clock64();
+#endif
+      __builtin_amdgcn_s_barrier();
+      if constexpr (TWO) {
+        // 128-VGPR budget: two fragment sets, reads one k-step ahead in a block; the other workgroup on the CU covers the bubbles
+        addr(K0{}); LIN_RD4(0); LIN_SB;
+        for (int t = 0; t < ntiles; ++t) {
+          addr(K1{}); LIN_RD4(1); frag_wait<4>(fr[0]); LIN_STEP(0);
+          addr(K2{}); LIN_RD4(0); frag_wait<4>(fr[1]); LIN_STEP(1);
+          addr(K3{}); LIN_RD4(1); frag_wait<4>(fr[0]); LIN_STEP(0);
+          frag_wait<0>(fr[1]);
+          slot ^= 1;
+          __builtin_amdgcn_s_barrier();
+          sbase = lds_u32(smem) + slot * STAGE_BYTES;
+          addr(K0{}); LIN_RD4(0); LIN_SB;
+          LIN_STEP(1);
+        }
+        frag_wait<0>(fr[0]);
+      } else {
+      addr(K0{}); LIN_RD4(0);
+      addr(K1{}); LIN_RD4(1);
       LIN_SB;
-      // (the loop body is the same for every tile, the last included: its barrier is the "ring free" barrier the loaders join after
-      // their loop, and its eight look-ahead reads fetch stale ring bytes that nobody uses -- a peeled last tile made the register
-      // allocator copy all 64 accumulator registers once per tile)
-      for (; t < ntiles; ++t) {
+      for (int t = 0; t < ntiles; ++t) {
         addr(K2{}); frag_wait<4>(fr[0]); LIN_STEP_RD(0, 2);
         addr(K3{}); frag_wait<4>(fr[1]); LIN_STEP_RD(1, 3);
         frag_wait<4>(fr[2]); LIN_STEP(2);
@@ -326,28 +326,28 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
         LIN_MM(3, 1, 1); LIN_SB; LIN_RD(1, 1, 4096, xa); LIN_RD(1, 3, 4096, wa); LIN_SB;
       }
       frag_wait<0>(fr[0]); frag_wait<0>(fr[1]);   // the stale look-ahead reads must have returned before their registers are reused
+      }
 #ifdef LIN_STAMP
       if (lane == 0 && g.C2 && EPI != EPI_GELU) {
-        float* d = reinterpret_cast<float*>(g.C2) + ((int64_t)blockIdx.x * 8 + wv) * 8;
+        float* d = reinterpret_cast<float*>(g.C2) + ((int64_t)blockIdx.x * (NCW + NLD) + wv) * 8;
         d[0] = (float)(__builtin_readcyclecounter() - ck0); d[2] = (float)ck2; d[5] = (float)ntiles; d[6] = 2.f; d[7] = (float)(wall_clock64() - cr0);
       }
 #endif
     }
-    if (loader) __builtin_amdgcn_s_barrier();   // ring free (the compute waves' last in-loop barrier): every wave is past its last tile
   } else {
-    // two stages: tile t+1 streams in while tile t is multiplied
+    // plain form, two stages: tile t+1 streams in while tile t is multiplied (two workgroups per CU cover each other's waits)
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < ntiles; ++t) {
       const int cur = t & 1;
       sbase = lds_u32(smem) + cur * STAGE_BYTES;
-      request(K0{}, 0);
+      addr(K0{}); LIN_RD4(0);
       if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
-      steps012();
-      frag_wait<0>(fr[1]);
-      mma(1);
-      __builtin_amdgcn_sched_barrier(0);
+      addr(K1{}); LIN_RD4(1); frag_wait<4>(fr[0]); LIN_STEP(0);
+      addr(K2{}); LIN_RD4(0); frag_wait<4>(fr[1]); LIN_STEP(1);
+      addr(K3{}); LIN_RD4(1); frag_wait<4>(fr[0]); LIN_STEP(0);
+      frag_wait<0>(fr[1]); LIN_STEP(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -355,17 +355,18 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
 
   // ---- epilogue.  Staging: compute wave w owns smem + w * REGION; row r of its sub-tile at r * OPITCH (SPEC: all 64 rows, plain: 32).
   constexpr int REGION = (SPEC ? 64 : 32) * OPITCH;
+  // (launch_lin sizes the dynamic LDS as max(ring, NCW * REGION): the two-per-CU form's 64-KB ring is smaller than its staging)
   auto stage_out = [&](int tm) {   // lane: row tm*32 + l31 (plain: l31), columns tn*32 + 16 lh + [0, 16)
-    char* dst = smem + cw * REGION + ((SPEC ? tm * 32 : 0) + l31) * OPITCH + lh * 64;
+    char* dst = smem + wv * REGION + ((SPEC ? tm * 32 : 0) + l31) * OPITCH + lh * 64;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f4_t*>(dst + tn * 128 + q * 16) = f4_t{acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
   };
-  auto finish_half = [&](int half, int j0, auto USE_RPRE) {   // rows [32 half, +32) of sub-tile `sub`; j0 = index of rpre[0]
+  auto finish_half = [&](int sub, int half, int j0, auto USE_RPRE) {   // rows [32 half, +32) of sub-tile `sub`; j0 = index of its rpre[0]
     const char* src = smem + sub * REGION + ((SPEC ? half * 32 : 0) + rrow) * OPITCH + ccol * 4;
-    const int mrow = sm0 + half * 32 + rrow;
+    const int mrow = m0 + (sub >> 1) * 64 + half * 32 + rrow;
 #pragma unroll
     for (int j = 0; j < NIT_HALF; ++j) {
       const int m = mrow + RSTEP * j;
@@ -393,29 +394,35 @@ __global__ __launch_bounds__(256 + 64 * NLD, 2) void lin_kernel(const LinArgs g)
   if constexpr (SPEC) {
     if (!loader) { stage_out(0); stage_out(1); }
     __syncthreads();
-    finish_half(half0, 0, std::true_type{});
+    if (!loader) finish_half(sub0, 0, 0, std::bool_constant<RPRE>{});
+    else if (cw < 4) {
+      finish_half(sub0, 1, 0, std::bool_constant<RPRE>{});
+#pragma unroll
+      for (int u = 1; u < NUNITS; ++u) finish_half(sub0 + 4 * u, 1, 0, std::false_type{});
+    }
   } else {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       stage_out(tm);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      finish_half(tm, 0, std::false_type{});
+      finish_half(sub0, tm, 0, std::false_type{});
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-template <int NLD, int EPI, int STAGES>
+template <int WMB, int NLD, int EPI, int STAGES>
 int launch_lin(const LinArgs& a, hipStream_t s) {
-  constexpr int lds = STAGES * STAGE_BYTES;
+  constexpr int ring = STAGES * (128 * WMB * 128 + 16384), staging = NLD ? 4 * WMB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
+  constexpr int lds = ring > staging ? ring : staging;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<NLD, EPI, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<NLD, EPI, STAGES>), dim3((a.M / 128) * a.tilesN), dim3(256 + 64 * NLD), lds, s, a);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES>), dim3((a.M / (128 * WMB)) * a.tilesN), dim3(256 * WMB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -451,23 +458,25 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
   g.res_mod = a->res_mod; g.tilesN = a->N / 128;
   const long tiles = (long)(a->M / 128) * g.tilesN;
-  static const int spec_max = [] { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); return e ? atoi(e) : 256; }();
-  const bool spec = tiles <= spec_max;
-  if (spec) {
-    int stages = 5;
-    { const char* e = getenv("COUNTR_LEAN_STAGES"); if (e) stages = atoi(e); }
-#define LIN_LAUNCH_SPEC(ST)                                            \
-    {                                                                  \
-      if (epi == EPI_BF16) return launch_lin<4, EPI_BF16, ST>(g, s);   \
-      if (epi == EPI_GELU) return launch_lin<4, EPI_GELU, ST>(g, s);   \
-      return launch_lin<4, EPI_RES, ST>(g, s);                         \
-    }
-    if (stages == 3) LIN_LAUNCH_SPEC(3)
-    if (stages == 4) LIN_LAUNCH_SPEC(4)
-    LIN_LAUNCH_SPEC(5)
-#undef LIN_LAUNCH_SPEC
+  int spec_max = 256, big = 0;
+  { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
+  { const char* e = getenv("COUNTR_LEAN_BIG"); if (e) big = atoi(e); }
+#define LIN_LAUNCH(WMB, NLD, ST)                                            \
+  {                                                                         \
+    if (epi == EPI_BF16) return launch_lin<WMB, NLD, EPI_BF16, ST>(g, s);   \
+    if (epi == EPI_GELU) return launch_lin<WMB, NLD, EPI_GELU, ST>(g, s);   \
+    return launch_lin<WMB, NLD, EPI_RES, ST>(g, s);                         \
   }
-  if (epi == EPI_BF16) return launch_lin<0, EPI_BF16, 2>(g, s);
-  if (epi == EPI_GELU) return launch_lin<0, EPI_GELU, 2>(g, s);
-  return launch_lin<0, EPI_RES, 2>(g, s);
+  // one workgroup per CU at most: 4 compute + 4 loader waves on a 3-stage ring.  (Measured and dropped: 4- and 5-stage rings and 8 loader
+  // waves -- the loaders are not waiting for data, their LDS-DMA instructions ISSUE at ~95 cycles each: 32 KB per k-tile at ~42 B/clk per
+  // CU is what bounds this form, profiles/r3_linear_stamps.txt)
+  if (tiles <= spec_max) LIN_LAUNCH(1, 4, 3)
+  // bigger grids.  Default: the plain form, two workgroups per CU.  Two wave-specialised alternatives are parity-tested and within 1 us
+  // of it back to back, but lose 0.06 ms per finetune step in the graph (COUNTR_LEAN_BIG=1: 256x128 tiles, 8 + 4 waves, 144 KB ring --
+  // 2/3 of the staged bytes per MFMA, 1470 cycles per k-tile for two tile-equivalents, but 324 / 432 workgroups are two rounds on 256
+  // CUs and a CU-filling workgroup shuts the exemplar side lane out; =2: 128x128, 2-stage ring, two workgroups per CU in 128 VGPRs).
+  if (big == 1 && (a->M % 256) == 0) LIN_LAUNCH(2, 4, 3)
+  if (big == 2) LIN_LAUNCH(1, 4, 2)
+  LIN_LAUNCH(1, 0, 2)
+#undef LIN_LAUNCH
 }

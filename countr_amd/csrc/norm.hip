@@ -906,7 +906,7 @@ extern "C" int countr_colsum_partials(const float* partial, float* out, int npar
 // maps (24x24: 4 splits, 48x48: 16; bwd 38 -> 21 us, 56 -> 35 us) without multiplying the partials of the big ones
 // (96x96: 32, 192x192: 64)
 static int gn_splits(int HW) {
-  static const int capa = [] { const char* e = getenv("COUNTR_GN_SPLIT_CAP"); return e ? atoi(e) : 32; }();   // 96x96 backward: 16 splits 69.5 us, 32: 60.3, 64: 65.6
+  static const int capa = [] { const char* e = getenv("COUNTR_GN_SPLIT_CAP"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : (v > 64 ? 64 : v); }();   // 96x96 backward: 16 splits 69.5 us, 32: 60.3, 64: 65.6
   const int a = HW / 144 < capa ? HW / 144 : capa, b = HW / 576 < 64 ? HW / 576 : 64;
   const int ns = a > b ? a : b;
   return ns < 1 ? 1 : ns;

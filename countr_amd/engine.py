@@ -384,7 +384,11 @@ class Engine:
         (fp32 mode's unfused bias gradients use one column-sum workspace: it stays serial).  Only for a step without a collective
         between the two lists (one rank)."""
         m = next((k for k, op in enumerate(lists.bwd_rest) if op[0] is None and op[1][0] == "tokready"), None)
-        if m is None or not self.overlap_exemplar or self.code != BF16 or os.environ.get("COUNTR_OVERLAP_TOKBWD", "1") == "0":
+        # (serial as well when the deferred reductions are off -- _conv_wgrad in bwd_tok and _linear_wgrad behind the marker would then
+        # share the 'splitk' / 'rowsum' scratch -- and with COUNTR_PARALLEL_LANES=1, whose nested fork / join inside bwd_tok would take
+        # the rest of that list off the side lane)
+        if (m is None or not self.overlap_exemplar or self.code != BF16 or not self.defer_reduce or self.parallel_lanes
+                or os.environ.get("COUNTR_OVERLAP_TOKBWD", "1") == "0"):
             self.run(lists.bwd_rest)
             self.run(lists.bwd_tok)
             return
@@ -788,7 +792,9 @@ class Engine:
         cin = [Dd, 256, 256, 256]
         hin = [dn]
         hc, hstats = [], []
-        gn_ws = self._shared("gn", B * 64 * 3 * 256 + 64 + 16 * B + B * 3 * 256)
+        # GroupNorm workspace: the C side places the per-image sums behind the per-split partials (their count follows the map size and
+        # COUNTR_GN_SPLIT_CAP), so size it from the library's own offset, the largest over the four head maps
+        gn_ws = self._shared("gn", max(int(L.countr_groupnorm_bwd_image_sums_offset(B, h * h)) for h in hs) + B * 3 * 256)
         o1 = A("o1", (B, hs[3] * hs[3]), f32)
         out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
         hact_tmp = self._shared("hact_tmp", B * hs[2] * hs[2] * 256, T)

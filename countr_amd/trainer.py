@@ -82,7 +82,7 @@ class _GraphStep:
     # unless the host runs that far ahead).  The copy stream itself waits for nothing: with a stream-side wait on the step stream's
     # "consumed" event (one slot, the natural formulation) the H2D copy of batch t+1 no longer overlapped step t on ROCm 7.2 --
     # +0.4 ms of exposed PCIe time per step (tools/host_async.py host: 5.8 ms against 5.4 with either wait removed).
-    STAGING_SLOTS = int(os.environ.get("COUNTR_STAGING_SLOTS", "3"))
+    STAGING_SLOTS = max(1, int(os.environ.get("COUNTR_STAGING_SLOTS", "3")))
 
     def _staging_consumed(self):
         if hasattr(self, "_copy_stream"):
@@ -297,6 +297,12 @@ class _GraphStep:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
             phases = self._phases(key)
+            # this step's forward overwrites the plan's activation buffers (also when it is a graph replay): a pending autograd
+            # backward of an earlier module forward with the same (batch, shot_num) must refuse (models_mae_cross._DecoderFn)
+            for _name, _fn, gkey in phases[:1]:
+                pl = eng.plans.get((self.B, gkey[0], True))
+                if pl is not None:
+                    pl.fwd_gen = getattr(pl, "fwd_gen", 0) + 1
             if self.use_graph and not self.sync.comm:
                 # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
                 # costs ~20 us of idle GPU (4 launches per step before).  The AdamW scalars are uploaded first; only phase c reads them.

@@ -409,11 +409,13 @@ def test_splitk_finish_matches_unsplit_conv(hip, obf):
     assert (out.float() - ref.float()).abs().max().item() <= (8e-3 if obf else 2e-5) * scale
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 192), (4608, 512, 512), (1152, 768, 3072), (4608, 1536, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 192), (4608, 512, 512), (1152, 768, 3072), (4608, 1536, 256), (4736, 1024, 128),
+                                   (2304, 3072, 768)])
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "gelu_pre", "res", "resmod"])
 def test_lean_linear_matches_fp64_and_generic(hip, monkeypatch, M, N, K, epi):
     """csrc/linear.hip (full-tile nn.Linear forward: 32x32x16 MFMA, staged epilogue, sigmoid-polynomial GELU) through countr_gemm:
-    every epilogue, the wave-specialised (<= 256 tiles) and the plain launch form, against torch fp64 and against gemm_kernel on the
+    every epilogue; the wave-specialised 128x128 form (<= 256 tiles), the 256x128 form (bigger grids, M % 256 == 0) and the plain
+    two-workgroups-per-CU form (M % 256 != 0), against torch fp64 and against gemm_kernel on the
     same inputs (COUNTR_LEAN=0).  Operands are bf16-exact, so the only error is fp32 accumulation order + the output rounding
     (+ <= 2.6e-5 absolute of the GELU fit)."""
     A = _mk((M, K), torch.bfloat16, 21)
@@ -454,6 +456,43 @@ def test_lean_linear_matches_fp64_and_generic(hip, monkeypatch, M, N, K, epi):
         outs.append(out)
     # the two kernels differ by accumulation order (and the GELU form): far below one bf16 ulp of the largest element
     assert (outs[0].double() - outs[1].double()).abs().max().item() <= (8e-3 if obf else 2e-5) * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("big", ["1", "2"])
+@pytest.mark.parametrize("M,N,K", [(4608, 1536, 256), (2304, 3072, 768)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu_pre", "res"])
+def test_lean_linear_alternative_big_grid_forms(hip, monkeypatch, big, M, N, K, epi):
+    """The two wave-specialised forms for grids of more than 256 tiles that are kept selectable (COUNTR_LEAN_BIG=1: 256x128 tiles with
+    8 compute + 4 loader waves; =2: 128x128 on a 2-stage ring, two workgroups per CU) against fp64."""
+    monkeypatch.setenv("COUNTR_LEAN_BIG", big)
+    A = _mk((M, K), torch.bfloat16, 41)
+    W = (_mk((N, K), torch.float32, 42) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 43)
+    obf = epi != "res"
+    resid = None if obf else _mk((M, N), torch.float32, 44)
+    z = A.double() @ W.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(z) if epi.startswith("gelu") else z
+    if resid is not None:
+        ref = ref + resid.double()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if obf else torch.float32)
+    pre = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) if epi == "gelu_pre" else None
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+    a.C2 = pre.data_ptr() if pre is not None else None
+    a.bias = bias.data_ptr()
+    a.resid = resid.data_ptr() if resid is not None else None
+    a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
+    a.M, a.N, a.K = M, N, K
+    a.act = 1 if epi.startswith("gelu") else 0
+    a.out_bf16 = int(obf)
+    a.alpha = 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+    torch.cuda.synchronize()
+    tol = 4e-3 if obf else 2e-5
+    assert (out.double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 3e-5
+    if pre is not None:
+        assert (pre.double() - z).abs().max().item() <= 4e-3 * z.abs().max().item()
 
 
 def test_lean_linear_in_place_residual(hip):

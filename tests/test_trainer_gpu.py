@@ -124,7 +124,11 @@ def test_optimizer_state_roundtrip():
                 m, _ = make("fp32")
                 m.load_state_dict(weights)
                 step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=False)
-                assert not step.load_optimizer_state({"state": {}, "param_groups": []})
+                with pytest.raises(ValueError):
+                    step.load_optimizer_state({"state": {}, "param_groups": []})        # not this model's parameter groups
+                with pytest.raises(ValueError):
+                    step.load_optimizer_state({"foo": 1})
+                assert set(state) >= {"state", "param_groups"} and len(state["param_groups"]) == 2   # torch.optim.AdamW layout
                 assert step.load_optimizer_state(state)
                 assert step.eng.group_steps == [2, 0, 2] and step.eng.opt_seen == {3}
             imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=70 + it)
@@ -134,6 +138,75 @@ def test_optimizer_state_roundtrip():
         res.append({k: p.detach().cpu().clone() for k, p in m.named_parameters()})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_optimizer_state_is_the_reference_adamw_state_dict(tmp_path):
+    """Checkpoint interchange with the reference (util/misc.py:312-318 saves optimizer.state_dict(), :400-421 loads it): the REAL
+    torch.optim.AdamW over timm's add_weight_decay groups of ALL requires_grad parameters in named_parameters() order (encoder included,
+    it just never gets a gradient) is stepped with the oracle's gradients for [3, 0, 3]; its state_dict() -- through torch.save /
+    torch.load -- is loaded into a fresh FinetuneStep, both continue with [0, 1] and stay together.  And the other way round: the
+    state FinetuneStep exports loads into a fresh torch.optim.AdamW (load_state_dict) and equals the reference optimizer's state."""
+    from countr_amd.trainer import FinetuneStep
+    from countr_amd.engine import no_weight_decay
+    m, sd = make("fp32")
+    lr, eps = 1e-3, 1e-4
+    frozen = ("pos_embed", "decoder_pos_embed")
+
+    def reference_optimizer(params):
+        names = [k for k, _ in m.named_parameters() if k not in frozen]
+        nd = [params[k] for k in names if no_weight_decay(k, params[k].shape)]
+        dc = [params[k] for k in names if not no_weight_decay(k, params[k].shape)]
+        return torch.optim.AdamW([{"params": nd, "weight_decay": 0.0}, {"params": dc, "weight_decay": 0.05}], lr=lr, betas=(0.9, 0.95), eps=eps)
+
+    P = {k: torch.nn.Parameter(torch.from_numpy(v).double()) for k, v in sd.items() if k not in frozen}
+    opt = reference_optimizer(P)
+    cur = lambda: {k: (P[k].detach().float().numpy() if k in P else v) for k, v in sd.items()}
+    sched = [3, 0, 3, 0, 1]
+    for it, S in enumerate(sched[:3]):
+        imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=40 + it)
+        _, _, rg = R.loss_and_grads(cur(), imgs, boxes, gt, mask, S, NAME)
+        for k, g_ in rg.items():
+            if g_ is not None:
+                P[k].grad = g_.double() if P[k].grad is None else P[k].grad + g_.double()
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+    path = tmp_path / "ref_opt.pth"
+    torch.save({"optimizer": opt.state_dict()}, path)
+    ref_state = torch.load(path, map_location="cpu", weights_only=False)["optimizer"]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in cur().items()})
+    step = FinetuneStep(m, batch=2, lr=lr, weight_decay=0.05, eps=eps, use_graph=False)
+    assert step.load_optimizer_state(ref_state)
+    assert step.eng.group_steps == [3, 3, 2] and step.eng.opt_seen == {2, 3}
+    for it, S in enumerate(sched[3:], start=3):
+        imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=40 + it)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+        step.step(S)
+        torch.cuda.synchronize()
+        _, _, rg = R.loss_and_grads(cur(), imgs, boxes, gt, mask, S, NAME)
+        for k in P:
+            if P[k].grad is not None:
+                P[k].grad.zero_()
+        for k, g_ in rg.items():
+            if g_ is not None:
+                P[k].grad = g_.double() if P[k].grad is None else P[k].grad + g_.double()
+        opt.step()
+        for k, p_ in m.named_parameters():
+            if k in frozen or not k.startswith(("decoder", "decode_head", "shot_token")):
+                continue
+            d = (p_.detach().cpu().double() - P[k].detach()).abs()
+            assert d.pow(2).mean().sqrt().item() <= 0.03 * lr * (it - 2), (it, k, d.pow(2).mean().sqrt().item())
+    # export -> a fresh torch optimizer accepts it, and it carries the same moments / counters as the reference optimizer's
+    mine = step.optimizer_state()
+    P2 = {k: torch.nn.Parameter(v.detach().clone()) for k, v in P.items()}
+    opt2 = reference_optimizer(P2)
+    opt2.load_state_dict({"state": mine["state"], "param_groups": mine["param_groups"]})
+    theirs = opt.state_dict()
+    assert set(mine["state"]) == set(theirs["state"])
+    for pid, st_ in theirs["state"].items():
+        assert float(mine["state"][pid]["step"]) == float(st_["step"]), pid
+        for key in ("exp_avg", "exp_avg_sq"):
+            a_, b_ = mine["state"][pid][key].double(), st_[key].double()
+            assert (a_ - b_).abs().max().item() <= 2e-2 * b_.abs().max().item() + 1e-12, (pid, key)
 
 
 def test_bf16_step_runs_and_reduces_loss():

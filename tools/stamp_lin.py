@@ -9,7 +9,8 @@ L = _lib.lib(); _lib.check(L.countr_init(0))
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def mk(*shape, dt=torch.bfloat16, s=1.0): return ((torch.rand(shape, device="cuda") - 0.5) * s).to(dt)
 M = 4608
-for name, N, K, res in (("proj", 768, 768, True), ("fc2", 768, 3072, True), ("dec fc2", 512, 2048, True), ("dec wq", 512, 512, False)):
+for name, N, K, res in (("proj", 768, 768, True), ("fc2", 768, 3072, True), ("dec fc2", 512, 2048, True), ("dec wq", 512, 512, False),
+                        ("qkv", 2304, 768, False), ("fc1 (no gelu)", 3072, 768, False)):
     A_, W_ = mk(M, K, s=2.0), mk(N, K, s=0.2); bias = mk(N, dt=torch.float32)
     out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if res else torch.bfloat16)
     resid = mk(M, N, dt=torch.float32)
@@ -20,11 +21,11 @@ for name, N, K, res in (("proj", 768, 768, True), ("fc2", 768, 3072, True), ("de
     if res: a.resid = resid.data_ptr()
     for _ in range(5): _lib.check(L.countr_gemm(C.byref(a), 1, 0, 0, st()))
     torch.cuda.synchronize()
-    nwg = (M // 128) * (N // 128)
-    d = dbg[:nwg * 64].view(nwg, 8, 8).cpu()
+    d = dbg.view(-1, 8).cpu()
+    d = d[d[:, 6] > 0]
     nt = K // 64
-    ld, cp = d[:, 4:, :], d[:, :4, :]
-    f = lambda t, i: t[:, :, i].mean().item() / nt
-    mhz = (d[:, :, 0] / (d[:, :, 7] * 1e-2)).mean().item()
-    print("%-8s %dx%dx%d k-tiles %d | loaders: loop %.0f/k-tile = load wait %.0f + barrier %.0f + DMA issue %.0f | compute: loop %.0f/k-tile, barrier %.0f | shader clock %.0f MHz"
-          % (name, M, N, K, nt, f(ld, 0), f(ld, 1), f(ld, 2), f(ld, 3), f(cp, 0), f(cp, 2), mhz), flush=True)
+    ld, cp = d[d[:, 6] == 1], d[d[:, 6] == 2]
+    f = lambda t, i: t[:, i].mean().item() / nt
+    mhz = (d[:, 0] / (d[:, 7] * 1e-2)).mean().item()
+    print("%-8s %dx%dx%d k-tiles %d waves %d+%d | loaders: loop %.0f/k-tile = load wait %.0f + barrier %.0f + DMA issue %.0f | compute: loop %.0f/k-tile, barrier %.0f | shader clock %.0f MHz"
+          % (name, M, N, K, nt, len(cp), len(ld), f(ld, 0), f(ld, 1), f(ld, 2), f(ld, 3), f(cp, 0), f(cp, 2), mhz), flush=True)

@@ -34,7 +34,7 @@ prev_end = rows[lo - 1][2]
 for name, s, e, gx, wx, gz in sel:
     key = name.replace("(anonymous namespace)::", "").replace("void ", "")
     key = key.split("(")[0]
-    if "gemm_kernel" in key:
+    if "gemm_kernel" in key or "lin_kernel" in key:
         key = "%s wgs=%d z=%d" % (key.replace("unsigned short", "bf16"), gx // max(wx, 1), gz)
     a = agg.setdefault(key, [0, 0.0])
     a[0] += 1
