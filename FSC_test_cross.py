@@ -2,7 +2,8 @@
 """Few-/zero-shot evaluation CLI with the reference's flags (FSC_test_cross(few-shot).py:26-78), running the MI355X engine.
 
 `--box_bound 0` = zero-shot.  With the FSC147 files present (--data_path/--anno_file/--data_split_file/--im_dir) images are
-loaded with PIL exactly as TestData does (:134-190: height 384, width 16*int(W/H*384/16), exemplar crops resized to 64x64).
+loaded as TestData does (countr_amd/data/fsc147.py::test_item, pinned against the reference class in tests/golden/data_test.npz;
+`--external`: the split's own exemplar crops, cut to --box_bound, serve every image -- :96-129).
 Without a dataset (none is available offline) `--synthetic N` evaluates N synthetic wide images through the same
 sliding-window / stitching / normalisation code (countr_amd/inference.py)."""
 import argparse
@@ -51,28 +52,6 @@ def get_args_parser():
     return p
 
 
-def load_fsc147_item(args, annotations, im_id):
-    """TestData.__getitem__ (FSC_test_cross(few-shot).py:134-190) with PIL only."""
-    from PIL import Image
-    anno = annotations[im_id]
-    bboxes = anno["box_examples_coordinates"] if args.box_bound < 0 else anno["box_examples_coordinates"][:args.box_bound]
-    dots = np.array(anno["points"])
-    image = Image.open(os.path.join(args.data_path, args.im_dir, im_id)).convert("RGB")
-    W, H = image.size
-    new_H, new_W = 384, 16 * int((W / H * 384) / 16)
-    sh, sw = new_H / H, new_W / W
-    image = image.resize((new_W, new_H), Image.BILINEAR)
-    img = torch.from_numpy(np.asarray(image, dtype=np.float32) / 255.0).permute(2, 0, 1)
-    boxes, pos = [], []
-    for bbox in bboxes:
-        x1, y1, x2, y2 = int(bbox[0][0] * sw), int(bbox[0][1] * sh), int(bbox[2][0] * sw), int(bbox[2][1] * sh)
-        crop = img[:, y1:y2 + 1, x1:x2 + 1].unsqueeze(0)
-        boxes.append(torch.nn.functional.interpolate(crop, size=(64, 64), mode="bilinear", align_corners=False)[0])
-        pos.append((y1, x1, y2, x2))
-    boxes = torch.stack(boxes) if boxes else torch.zeros(0)
-    return img, boxes, pos, dots.shape[0]
-
-
 def main(args):
     misc.init_distributed_mode(args)
     torch.manual_seed(args.seed)
@@ -92,11 +71,19 @@ def main(args):
             pos = [(10 * j, 10 * j, 10 * j + 40, 10 * j + 40) for j in range(k)]
             items.append(("synthetic_%d" % i, img, boxes, pos, int(rs.randint(5, 200))))
     else:
+        from countr_amd.data import fsc147
         annotations = json.load(open(os.path.join(args.data_path, args.anno_file)))
         split = json.load(open(os.path.join(args.data_path, args.data_split_file)))[args.split]
+        im_dir = os.path.join(args.data_path, args.im_dir)
+        ext = None
+        if args.external:     # FSC_test_cross(few-shot).py:96-129: the split's own exemplar crops, cut to --box_bound, for every image
+            ext = fsc147.external_exemplars(annotations, split, im_dir, args.box_bound)
+            if ext.shape[0] > 8:
+                raise SystemExit("--external with %d exemplars: the cross-attention kernel holds at most 8 exemplar tokens (use --box_bound <= 8)"
+                                 % ext.shape[0])
         for im_id in split:
-            img, boxes, pos, gt = load_fsc147_item(args, annotations, im_id)
-            items.append((im_id, img, boxes, pos, gt))
+            img, dots, boxes, pos, _gt_map = fsc147.test_item(annotations, im_dir, im_id, args.box_bound, ext)
+            items.append((im_id, img, boxes, [tuple(r) for r in pos], dots.shape[0]))
     from countr_amd.parallel import shard_batch
     lo, hi = shard_batch(len(items), misc.get_rank(), misc.get_world_size())   # replicas only: images sharded, no collective
     mae = rmse = nae = 0.0

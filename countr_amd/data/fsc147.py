@@ -372,6 +372,70 @@ def transform_pretrain(image, rng=random):
     return to_tensor(image)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# test-time loader: TestData of FSC_test_cross(few-shot).py:82-190 (pinned by tests/golden/data_test.npz, generated by exec'ing that class)
+# ---------------------------------------------------------------------------------------------------------------
+def _test_resize(image):
+    """height 384, width 16 * int(W / H * 384 / 16) (:147-154) -> (tensor CHW in [0, 1], scale_h, scale_w, new_h, new_w)"""
+    from PIL import Image
+    W, H = image.size
+    new_h, new_w = 384, 16 * int((W / H * 384) / 16)
+    sw, sh = float(new_w) / W, float(new_h) / H
+    return to_tensor(image.resize((new_w, new_h), Image.BILINEAR)), sh, sw, new_h, new_w
+
+
+def _test_crops(img_t, bboxes, sh, sw):
+    """:160-174 -- corner 0 / corner 2 of every box scaled with int() truncation, inclusive crop, 64x64 bilinear"""
+    rects = [[int(b[0][1] * sh), int(b[0][0] * sw), int(b[2][1] * sh), int(b[2][0] * sw)] for b in bboxes]
+    return [resize_box(img_t[:, y1:y2 + 1, x1:x2 + 1]) for y1, x1, y2, x2 in rects], rects
+
+
+def external_exemplars(annotations, split_ids, im_dir, box_bound=-1):
+    """TestData.__init__ with external=True (:96-129): the exemplar crops of EVERY image of the split, in annotation-file order, as one
+    list -- cut to the first `box_bound` crops when box_bound >= 0 -- used as the exemplars of every test image."""
+    ids = set(split_ids)
+    crops = []
+    for im_id in annotations:
+        if im_id not in ids:
+            continue
+        bboxes = annotations[im_id]["box_examples_coordinates"]
+        if bboxes:
+            img_t, sh, sw, _, _ = _test_resize(_open_rgba_only(os.path.join(im_dir, im_id)))
+            crops += _test_crops(img_t, bboxes, sh, sw)[0]
+    if box_bound >= 0:
+        crops = crops[:box_bound]
+    return torch.stack(crops) if crops else torch.zeros(0)
+
+
+def _open_rgba_only(path):
+    """Image.open + the reference's mode rule (:98-100, :142-144): only RGBA is converted"""
+    from PIL import Image
+    image = Image.open(path)
+    if image.mode == "RGBA":
+        image = image.convert("RGB")
+    image.load()
+    return image
+
+
+def test_item(annotations, im_dir, im_id, box_bound=-1, external_boxes=None):
+    """TestData.__getitem__ (:134-190) -> (image [3, 384, W'], dots [n, 2], boxes [k, 3, 64, 64] (or empty), pos [(y1, x1, y2, x2)],
+    gt_map [384, W']).  With external exemplars pos is empty (no 3x3 path, no test-time normalisation: there is no box in THIS image)."""
+    from scipy import ndimage
+    anno = annotations[im_id]
+    bboxes = anno["box_examples_coordinates"] if box_bound < 0 else anno["box_examples_coordinates"][:box_bound]
+    dots = np.array(anno["points"])
+    img_t, sh, sw, new_h, new_w = _test_resize(_open_rgba_only(os.path.join(im_dir, im_id)))
+    if external_boxes is not None:
+        boxes, pos = external_boxes, []
+    else:
+        crops, pos = _test_crops(img_t, bboxes, sh, sw)
+        boxes = torch.stack(crops) if crops else torch.zeros(0)
+    if box_bound >= 0:
+        assert len(boxes) <= box_bound
+    gt = ndimage.gaussian_filter(dot_map(dots, new_h, new_w, sh, sw), sigma=(1, 1), order=0)
+    return img_t, dots, boxes, pos, torch.from_numpy(gt) * 60
+
+
 def _paths(args):
     j = lambda p: p if os.path.isabs(p) else os.path.join(args.data_path, p)
     return j(args.anno_file), j(args.data_split_file), j(args.im_dir)

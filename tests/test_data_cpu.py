@@ -209,3 +209,41 @@ def test_augmented_dataset_end_to_end(tmp_path):
     with pytest.raises(FileNotFoundError):
         D.TrainData(types.SimpleNamespace(data_path=str(tmp_path), anno_file=anno_f, data_split_file=split_f, im_dir=im_dir,
                                           class_file="missing.txt"), split="train", do_aug=True)
+
+
+def test_test_time_loader_matches_reference_testdata(tmp_path):
+    """countr_amd/data/fsc147.py::test_item / external_exemplars against the reference's own TestData class
+    (FSC_test_cross(few-shot).py:82-190, exec'd unchanged by tools/oracle/make_golden_data.py on the same six-image dataset):
+    image, exemplar crops, box positions, gaussian ground-truth map; few-shot, --box_bound 2 / 0 and the --external branch."""
+    from countr_amd.data import fsc147 as D
+    from oracle import weights as W
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_test.npz"))
+    anno_f, _split_f, _class_f, im_dir, ids = W.write_aug_dataset(str(tmp_path))
+    annotations = json.load(open(anno_f))
+    splits = {0: ids, 1: ids[:3]}
+    ext_cache = {}
+    full_boxes = {}
+    assert int(g["ncases"]) == 30
+    for n in range(int(g["ncases"])):
+        external, bound, k, ndots, npos, split_id = (int(v) for v in g["t%d_meta" % n])
+        ext = None
+        if external:
+            key = (bound, split_id)
+            if key not in ext_cache:
+                ext_cache[key] = D.external_exemplars(annotations, splits[split_id], im_dir, bound)
+            ext = ext_cache[key]
+        img, dots, boxes, pos, gt = D.test_item(annotations, im_dir, ids[k], bound, ext)
+        assert dots.shape[0] == ndots and len(pos) == npos
+        ref_img = g["t%d_image" % n]
+        assert img.shape[1] == 384 and img.shape[2] % 16 == 0 and -(-img.shape[2] // 4) == ref_img.shape[2]
+        assert np.abs(img.numpy()[:, ::4, ::4] - ref_img).max() <= 1e-6
+        assert np.abs(img.double().sum(dim=(1, 2)).numpy() - g["t%d_image_sum" % n]).max() <= 1e-6 * img[0].numel()
+        assert np.array_equal(np.asarray(pos, np.int64).reshape(-1, 4), g["t%d_pos" % n])
+        bsum = boxes.reshape(boxes.shape[0], -1).double().sum(1).numpy() if boxes.numel() else np.zeros(0)
+        assert bsum.shape == g["t%d_boxes_sum" % n].shape and np.abs(bsum - g["t%d_boxes_sum" % n]).max(initial=0.0) <= 1e-3
+        if "t%d_boxes" % n in g.files:
+            assert np.abs(boxes.numpy() - g["t%d_boxes" % n]).max() <= 1e-6
+        assert abs(gt.double().sum().item() - float(g["t%d_gt_sum" % n])) <= 1e-3
+        assert np.abs(gt.numpy()[::4, ::4] - g["t%d_gt" % n]).max() <= 1e-5
+        if external:
+            assert pos == [] and boxes.shape[0] == (bound if bound >= 0 else sum(len(annotations[i]["box_examples_coordinates"]) for i in splits[split_id]))

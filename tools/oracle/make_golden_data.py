@@ -197,5 +197,62 @@ def main():
         print(k, np.asarray(v).shape, float(np.asarray(v, np.float64).sum()))
 
 
+def main_test_loader():
+    """tests/golden/data_test.npz: the reference's TEST-TIME loader.  `class TestData` (FSC_test_cross(few-shot).py:82-190, its
+    external-exemplar branch :96-129 included) is read from /root/reference at run time and exec'd UNCHANGED against the module globals
+    it expects (annotations, data_split, im_dir; torchvision's Resize / ToTensor / Compose are the stand-ins documented above,
+    misc.measure_time a no-op context manager) on the six-image on-disk dataset of the augmentation fixtures."""
+    import contextlib
+    import json
+    import tempfile
+    from PIL import Image
+    from scipy import ndimage
+    from torch.utils.data import Dataset
+    from oracle import weights as W
+    root = tempfile.mkdtemp()
+    anno_f, split_f, _class_f, im_dir, ids = W.write_aug_dataset(root)
+    src = open(os.path.join(REF, "FSC_test_cross(few-shot).py")).read().split("\n")
+    first = next(i for i, l in enumerate(src) if l.startswith("class TestData"))
+    last = next(i for i in range(first + 1, len(src)) if src[i].startswith("def main"))
+    tr = sys.modules["torchvision.transforms"]
+
+    class _MT:
+        duration = 0.0
+
+    @contextlib.contextmanager
+    def measure_time():
+        yield _MT()
+    ns = {"Dataset": Dataset, "Image": Image, "transforms": tr, "np": np, "torch": torch, "ndimage": ndimage,
+          "misc": types.SimpleNamespace(measure_time=measure_time), "annotations": json.load(open(anno_f)),
+          "data_split": {"test": ids, "val": ids[:3]}, "im_dir": im_dir}
+    exec(compile("\n".join(src[first:last]), "TestData", "exec"), ns)
+    out = {}
+    n = 0
+    for external, bound, split in ((False, -1, "test"), (False, 2, "test"), (False, 0, "test"), (True, 3, "val"), (True, -1, "val"), (True, 2, "test")):
+        ds = ns["TestData"](external=external, box_bound=bound, split=split)
+        for idx in range(len(ds)):
+            image, dots, boxes, pos, gt_map, name, _dur = ds[idx]
+            out["t%d_meta" % n] = np.array([int(external), bound, ids.index(name), dots.shape[0], len(pos), 0 if split == "test" else 1])
+            out["t%d_image" % n] = image.numpy()[:, ::4, ::4].copy()
+            out["t%d_image_sum" % n] = image.double().sum(dim=(1, 2)).numpy()
+            bx = np.asarray(boxes.numpy() if isinstance(boxes, torch.Tensor) else boxes, np.float32)
+            # full crops once per distinct exemplar set (bound 2 / 0 are prefixes of bound -1; the external list is the same for every
+            # image of a configuration); a float64 checksum per box everywhere
+            if (not external and bound == -1) or (external and idx == 0):
+                out["t%d_boxes" % n] = bx
+            out["t%d_boxes_sum" % n] = bx.reshape(bx.shape[0], -1).astype(np.float64).sum(1) if bx.size else np.zeros(0)
+            out["t%d_pos" % n] = np.asarray(pos, np.int64).reshape(-1, 4)
+            out["t%d_gt_sum" % n] = np.float64(gt_map.double().sum().item())
+            out["t%d_gt" % n] = gt_map.numpy()[::4, ::4].copy()
+            n += 1
+    out["ncases"] = np.int64(n)
+    np.savez_compressed(os.path.join(OUT, "data_test.npz"), **out)
+    print("data_test.npz: %d cases" % n, {k: np.asarray(v).shape for k, v in out.items() if k.startswith("t0_") or k.startswith("t%d_" % (n - 1))})
+
+
 if __name__ == "__main__":
-    main()
+    if "--test-loader-only" not in sys.argv:
+        main()
+    else:
+        install_stand_ins()
+    main_test_loader()
