@@ -88,6 +88,16 @@ def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
     assert r.returncode != 0 and "at most 8" in r.stderr
 
 
+def test_finetune_cli_default_batch_size(tmp_path):
+    """No --batch_size: the reference's default of 26 images per GPU (FSC_finetune_cross.py:29), bf16, two synthetic iterations."""
+    out = str(tmp_path / "ft26")
+    log = run(["FSC_finetune_cross.py", "--data_path", "/nonexistent", "--synthetic_steps", "2", "--epochs", "1", "--warmup_epochs", "0",
+               "--output_dir", out, "--resume", "", "--log_every", "1"])
+    assert "effective batch size: 26" in log
+    lines = [json.loads(l) for l in log.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(np.isfinite(l["loss"]) and l["loss"] > 0 for l in lines)
+
+
 def test_finetune_cli_with_augmentation(tmp_path):
     """The reference's default: --do_aug on (noise, colour jitter, blur, affine, flip, mosaic through countr_amd/data/fsc147.py) with
     the class file the cross-image mosaic needs; two DataLoader workers, as a user would run it."""

@@ -42,6 +42,46 @@ def test_samples_are_independent_and_runs_are_deterministic(model, batch8):
         assert full.shape == (8, 384, 384) and torch.isfinite(full).all()
 
 
+def test_default_batch_26_is_deterministic_and_sample_independent(model):
+    """The CLI's default --batch_size 26 (FSC_finetune_cross.py:29) on the full model in bf16: M = 14976 rows = 117 tiles of 128 (odd:
+    no 256-row pairing, 936 / 1404 / 2808-tile GEMM grids, 312 (batch x head) attention groups): two runs agree bit for bit, two fused
+    steps from the same state end in the same parameters, and sample i matches the same sample run alone / inside a batch of 8 to bf16
+    noise.  (Bit-exact independence is a property of B <= 8 only -- test above: the split-K factors of the exemplar-CNN and head
+    convolutions follow the tile count, i.e. the fp32 summation order follows the batch size: tools/diag_batch_indep.py, 'ytok' first.)"""
+    from countr_amd.trainer import FinetuneStep
+    imgs, boxes, gt, mask = (torch.from_numpy(a).cuda() for a in W.make_inputs(batch=26, shots=3, seed=6))
+    model.eval()
+    with torch.no_grad():
+        full = model(imgs, boxes, 3).clone()
+        assert torch.equal(full, model(imgs, boxes, 3))
+        assert full.shape == (26, 384, 384) and torch.isfinite(full).all()
+        close = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+        for i in (0, 13, 25):
+            assert close(model(imgs[i:i + 1], boxes[i:i + 1], 3)[0], full[i]) < 3e-2, i
+        assert close(model(imgs[8:16], boxes[8:16], 3), full[8:16]) < 3e-2
+    model.train()
+    keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ends = []
+    for _ in range(2):
+        model.load_state_dict(keep)
+        step = FinetuneStep(model, batch=26, lr=1e-5, use_graph=True)
+        eng = step.eng                      # the AdamW state lives in the engine: start both runs from a fresh optimizer
+        if eng.M is not None:
+            eng.M.zero_(); eng.V.zero_()
+        eng.step_count, eng.group_steps, eng.opt_seen = 0, [0, 0, 0], set()
+        losses = []
+        for S in (3, 0, 3):
+            step.load(imgs, boxes, gt, mask, S)
+            losses.append(step.step(S)[0].item())
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(torch.tensor(losses)))
+        ends.append({k: p.detach().clone() for k, p in model.named_parameters()})
+    for k in ends[0]:
+        assert torch.equal(ends[0][k], ends[1][k]), k
+    model.load_state_dict(keep)
+    model.eval()
+
+
 def test_backward_is_exactly_linear_in_dout_and_deterministic(model, batch8):
     """Every backward kernel is linear in its incoming gradient and scaling by a power of two is exact in fp32 and bf16, so
     grads(4 * dout) == 4 * grads(dout) bit for bit; two identical backward passes agree bit for bit."""

@@ -109,6 +109,41 @@ def test_finetune_steps_match_torch_adamw(use_graph):
             assert torch.equal(p.detach().cpu(), torch.from_numpy(sd[k])), k
 
 
+@pytest.mark.parametrize("B,shots", [(3, [3, 0]), (5, [0, 2]), (26, [3])])
+def test_finetune_step_at_odd_batch_sizes_matches_oracle(B, shots):
+    """Batch sizes a user actually passes (the reference's and this CLI's default is --batch_size 26; 3 and 5 give row counts that are
+    not multiples of any GEMM tile): M = 576 B takes the ragged-tile paths of gemm_kernel, other split-K factors, GroupNorm splits and
+    the attention kernel's non-multiple-of-8 (batch x head) mapping.  Loss, counts, gradient norm and the stepped parameters against the
+    oracle + the real torch.optim.AdamW, fp32 parity mode, eager and graph replay of the same step."""
+    from countr_amd.trainer import FinetuneStep
+    lr = 1e-3
+    for use_graph in (False, True):
+        m, sd = make("fp32")
+        step = FinetuneStep(m, batch=B, lr=lr, weight_decay=0.05, eps=1e-4, use_graph=use_graph)
+        ref = TorchAdamW(sd, lr, 1e-4)
+        for it, S in enumerate(shots):
+            imgs, boxes, gt, mask = W.make_inputs(batch=B, shots=3, seed=90 + it)
+            step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+            sums = step.step(S).clone()
+            gn = step.grad_norm().item()
+            torch.cuda.synchronize()
+            if use_graph:            # the graph-replayed run is compared with the eager one (bit-identical), not with the oracle again
+                continue
+            torch.set_num_threads(min(__import__("os").cpu_count(), 32))
+            out, rloss, rg = R.loss_and_grads(ref.state_dict_f32(sd), imgs, boxes, gt, mask, S, NAME)
+            assert abs(sums[0].item() - rloss.item()) <= 2e-3 * abs(rloss.item()), (B, it, S)
+            assert np.abs(sums[1:1 + B].cpu().numpy() - R.counts(out).numpy()).max() < 0.5
+            ref.accumulate(rg)
+            assert abs(gn - ref.grad_norm().item()) <= 2e-3 * ref.grad_norm().item(), (B, it, gn, ref.grad_norm().item())
+            ref.step()
+            check_params(m, ref, lr, it, "B=%d" % B)
+        params = {k: p.detach().cpu().clone() for k, p in m.named_parameters()}
+        if use_graph:
+            for k in params:
+                assert torch.equal(params[k], eager[k]), (B, k)
+        eager = params
+
+
 def test_optimizer_state_roundtrip():
     """optimizer_state() -> load_optimizer_state() on a fresh step continues bit-identically (moments, global and per-group
     step counters, the set of conditional buckets that already had a gradient); foreign dicts are refused."""
