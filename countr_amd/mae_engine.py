@@ -8,7 +8,7 @@ pre-allocated buffers, hipGraph-replayable), different graph: the whole model tr
   forward_decoder  models_mae_noct.py:159-179   unshuffle = one row gather with mask_token as default row (+ pos embed)
   forward_loss     models_mae_noct.py:181-198   countr_patch_mse (all-patch MSE, optional norm_pix)
   backward         autograd of the above        encoder + decoder ViT blocks (flash attention backward in bf16 mode)
-Gradient buckets: 0 = decoder side (final first), 1..3 = encoder thirds from the top (mae_bucket_fn).
+Gradient buckets: 0 = decoder side (final first), 1..6 = encoder block groups from the top (mae_bucket_fn, mae_enc_parts).
 """
 import torch
 
@@ -22,27 +22,34 @@ def mae_trainable(name):
     return name not in ("pos_embed", "decoder_pos_embed")
 
 
-def mae_bucket_fn(depth):
-    """Gradient buckets in backward-completion order: 0 = decoder side + mask_token, then the encoder in thirds from the top:
-    1 = norm + upper blocks, 2 = middle blocks, 3 = lower blocks + patch_embed (each all-reduce overlaps the next phase)."""
-    lo, hi = depth // 3, depth - depth // 3
+def mae_enc_parts(depth):
+    """Encoder gradient buckets.  Every all-reduce overlaps the backward phase behind it, so only the LAST bucket is exposed: six parts
+    (two ViT-B blocks = 57 MB of fp32 gradient each, + the 2.4-MB patch embedding in the last) instead of round 2's thirds (115 MB)."""
+    import os
+    return max(1, min(depth, int(os.environ.get("COUNTR_MAE_BUCKETS", "6"))))
+
+
+def mae_bucket_fn(depth, parts=None):
+    """Gradient buckets in backward-completion order: 0 = decoder side + mask_token, then the encoder in `parts` groups of blocks from
+    the top: 1 = norm + the uppermost blocks, ..., parts = the lowest blocks + patch_embed (each all-reduce overlaps the next phase)."""
+    parts = mae_enc_parts(depth) if parts is None else parts
 
     def bucket(name):
         if name.startswith(("decoder_", "mask_token")):
             return 0
         if name.startswith("blocks."):
             i = int(name.split(".")[1])
-            return 1 if i >= hi else (2 if i >= lo else 3)
-        return 1 if name.startswith("norm.") else 3   # patch_embed
+            return 1 + (depth - 1 - i) * parts // depth
+        return 1 if name.startswith("norm.") else parts   # patch_embed
 
     return bucket
 
 
 class MaePlan(Plan):
-    def __init__(self):
+    def __init__(self, parts=3):
         super().__init__()
         self.bwd_dec = self.bwd_head
-        self.bwd_enc = [self.bwd_rest, self.bwd_tok, []]   # encoder backward in three phases (buckets 1, 2, 3)
+        self.bwd_enc = [[] for _ in range(parts)]   # encoder backward, one launch list per gradient bucket 1 .. parts
 
 
 class MaeEngine(Engine):
@@ -129,7 +136,7 @@ class MaeEngine(Engine):
     def _build(self, B, K, train):
         """K = len_keep tokens per image seen by the encoder (models_mae_noct.py:117)."""
         L = self.L
-        p = MaePlan()
+        p = MaePlan(mae_enc_parts(self.depth))
         T, f32, i32 = self.tdt, torch.float32, torch.int32
         N, D, Dd, H, Hd = self.N, self.D, self.Dd, self.H, self.Hd
         code = self.code
@@ -188,7 +195,7 @@ class MaeEngine(Engine):
         if not train:
             return p
 
-        p.acc = MaePlan()            # the same lists with parameter gradients accumulated (gradient accumulation, micro-steps 2..)
+        p.acc = MaePlan(mae_enc_parts(self.depth))            # the same lists with parameter gradients accumulated (gradient accumulation, micro-steps 2..)
         for acc, lists in ((0, p), (1, p.acc)):
             self._acc = acc
             # =========================== backward ===========================
@@ -219,7 +226,7 @@ class MaeEngine(Engine):
             for i in reversed(range(self.depth)):
                 ops = lists.bwd_enc[bucket("blocks.%d.norm1.weight" % i) - 1]
                 g_t = self._block_bwd(ops, "blocks.%d" % i, enc[i], se, B, K, D, H, g_t)
-            ops = lists.bwd_enc[2]
+            ops = lists.bwd_enc[-1]
             self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
             self._flush_reductions(p)
         self._acc = 0

@@ -42,6 +42,8 @@ class GradSync:
         self.comm = self.world > 1 or (os.environ.get("COUNTR_FORCE_COMM", "0") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = None
         self._started = set()
+        self.profile = False        # bench.py: event pair around the join of every finish() -> exposed_us()
+        self._exposed = []
         if self.comm and flat_grad.is_cuda:
             self.stream = torch.cuda.Stream(device=flat_grad.device)
 
@@ -80,10 +82,31 @@ class GradSync:
                 runs[-1][1] = e
             else:
                 runs.append([s, e])
+        main = torch.cuda.current_stream(self.g.device) if self.g.is_cuda else None
+        if self.profile and main is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(main)
         for s, e in runs:
             dist.all_reduce(self.g[s:e], group=self.group)
         if self.stream is not None:
-            torch.cuda.current_stream(self.g.device).wait_stream(self.stream)
+            main.wait_stream(self.stream)
+        if self.profile and main is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(main)
+            self._exposed.append((e0, e1))
+
+    def exposed_us(self):
+        """Median time the step's stream spent between reaching finish() and having every bucket reduced (the collectives issued there
+        + the wait for the ones still running on the side stream): the communication that did NOT hide under backward.  Call after a
+        synchronize; needs profile = True."""
+        if not self._exposed:
+            return None
+        v = sorted(a.elapsed_time(b) * 1e3 for a, b in self._exposed)
+        self._exposed = []
+        return v[len(v) // 2]
+
+    def bucket_bytes(self):
+        return [4 * max(0, e - s) for s, e in self.buckets]
 
     @property
     def grad_scale(self):

@@ -467,13 +467,15 @@ class PretrainStep(_GraphStep):
         eng.run(self._lists(p, acc).bwd_dec)
 
     def _make_sync(self, process_group):
-        lay = self.eng.layout   # decoder side | encoder thirds from the top (mae_engine.mae_bucket_fn)
-        return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(4)])
+        from .mae_engine import mae_enc_parts
+        lay = self.eng.layout   # decoder side | encoder block groups from the top (mae_engine.mae_bucket_fn)
+        self.parts = mae_enc_parts(self.eng.depth)
+        return GradSync(self.eng.G, None, None, process_group, buckets=[lay.bucket_range(b) for b in range(self.parts + 1)])
 
     def _phases(self, K):
         acc = int(self._micro > 0)
         enc = lambda j: (lambda key: self.eng.run(self._lists(self.eng.plan(self.B, key[0], True), key[1]).bwd_enc[j]))
-        return [("a", self._phase_a, (K, acc)), ("b", enc(0), (K, acc)), ("b2", enc(1), (K, acc)), ("b3", enc(2), (K, acc))]
+        return [("a", self._phase_a, (K, acc))] + [("b%d" % j, enc(j), (K, acc)) for j in range(self.parts)]
 
     def load(self, imgs, ids_shuffle=None):
         cur = torch.cuda.current_stream(self.eng.device)

@@ -53,6 +53,24 @@ def run_finetune(rank, world, per_rank, use_graph=True):
     return m, losses
 
 
+def run_finetune_real(rank, world, per_rank=8, use_graph=True):
+    """BASELINE config 3's per-GPU work: ViT-B/16, bf16, 8 images per rank, hipGraph replay, shot schedule with every bucket case."""
+    import models_mae_cross as mm
+    from countr_amd.trainer import FinetuneStep
+    m = mm.__dict__["mae_vit_base_patch16"](precision="bf16")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict("mae_vit_base_patch16", seed=0).items()}, strict=True)
+    m.to("cuda").train()
+    step = FinetuneStep(m, batch=per_rank, lr=1e-4, weight_decay=0.05, use_graph=use_graph)
+    losses = []
+    for it, S in enumerate(SHOTS + [3, 3]):
+        imgs, boxes, gt, mask = W.make_inputs(batch=per_rank * world, shots=3, seed=60 + it)
+        sl = slice(rank * per_rank, (rank + 1) * per_rank)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs[sl], boxes[sl], gt[sl], mask)), S)
+        losses.append(step.step(S)[0].item())
+    torch.cuda.synchronize()
+    return m, losses
+
+
 def run_pretrain(rank, world, per_rank, use_graph=True):
     from countr_amd.trainer import PretrainStep
     m = pretrain_model()
@@ -75,8 +93,13 @@ if __name__ == "__main__":
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group(backend, rank=rank, world_size=world)
-    m, losses = (run_finetune if what == "finetune" else run_pretrain)(rank, world, 2 if world > 1 else 4)
-    torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters()}, "losses": losses},
+    if what == "finetune_real":
+        m, losses = run_finetune_real(rank, world)
+        keep = lambda k: k.startswith(("decoder", "decode_head", "shot_token"))
+    else:
+        m, losses = (run_finetune if what == "finetune" else run_pretrain)(rank, world, 2 if world > 1 else 4)
+        keep = lambda k: True
+    torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters() if keep(k)}, "losses": losses},
                os.path.join(outdir, "%s_rank%d.pt" % (what, rank)))
     dist.barrier()
     dist.destroy_process_group()
