@@ -474,9 +474,9 @@ __global__ __launch_bounds__(64) void masked_mse_finish_kernel(const float* __re
 // gradient (torch 1.13 optimizer.zero_grad() keeps zero tensors, so a parameter that had a gradient once is stepped ever after).
 struct AdamRanges {
   int n;
-  int64_t start[8], end[8];
-  float wd[8];
-  int grp[8], zero[8];
+  int64_t start[16], end[16];
+  float wd[16];
+  int grp[16], zero[16];
 };
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              bf16_t* __restrict__ shadow, AdamRanges R, float lr, float b1, float b2, float eps, float bc1s,
@@ -660,7 +660,7 @@ extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, v
                                  const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
                                  const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                                  const float* hyper_dev, float* gnorm_ws, void* stream) {
-  if (!p || !g || !m || !v || nranges < 1 || nranges > 8 || (step < 1 && !hyper_dev)) { countr_set_error("countr_adamw_step: bad args (1..8 ranges, step >= 1)"); return -1; }
+  if (!p || !g || !m || !v || nranges < 1 || nranges > 16 || (step < 1 && !hyper_dev)) { countr_set_error("countr_adamw_step: bad args (1..16 ranges, step >= 1)"); return -1; }
   AdamRanges R;
   R.n = nranges;
   int64_t total = 0;

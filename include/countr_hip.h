@@ -207,7 +207,7 @@ int countr_conv_shadows(int n, const float* const* src, void* const* wf, void* c
 int countr_masked_mse_workspace_floats(int B);
 int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
                       float* workspace, int B, int HW, float grad_scale, void* stream);
-/* fused AdamW over flat fp32 buffers (torch.optim.AdamW at FSC_finetune_cross.py:235); up to 8 [start,end) ranges each with
+/* fused AdamW over flat fp32 buffers (torch.optim.AdamW at FSC_finetune_cross.py:235); up to 16 [start,end) ranges each with
  * its weight decay, its bias-correction counter group (groups[i] in {0,1,2}, NULL = all 0: torch keeps a step counter per
  * parameter, util/misc.py:266-280 steps only parameters that have a gradient) and a zero-gradient flag (zero_grad[i] != 0: the
  * range is stepped with g = 0, which is what torch 1.13's zero_grad() -- zero tensors, not None -- makes of a parameter that is

@@ -47,22 +47,28 @@ def test_mae_layout_buckets_cover_all_trainable_parameters():
     from countr_amd.engine import ParamLayout, no_weight_decay
     from countr_amd.mae_engine import mae_bucket_fn, mae_trainable
     shapes = [(n, s) for n, s, _ in W.schema_mae()]
+    from countr_amd.mae_engine import mae_enc_parts
+    assert mae_enc_parts(12) == 6 and mae_enc_parts(2) == 2
+    old = mae_bucket_fn(12, parts=3)                       # round 2's thirds, still selectable (COUNTR_MAE_BUCKETS=3)
+    assert [old("blocks.%d.attn.qkv.weight" % i) for i in range(12)] == [3] * 4 + [2] * 4 + [1] * 4 and old("patch_embed.proj.weight") == 3
     mae_bucket = mae_bucket_fn(12)
+    NB = 7                                                  # decoder side + six encoder groups of two blocks
     lay = ParamLayout(shapes, trainable=mae_trainable, bucket=mae_bucket)
     assert lay.frozen_names == ["pos_embed", "decoder_pos_embed"]
-    rng = [lay.bucket_range(b) for b in range(4)]
-    assert rng[0][0] == 0 and rng[3][1] == lay.n_train and all(rng[b][1] == rng[b + 1][0] for b in range(3))   # contiguous RCCL buckets
+    rng = [lay.bucket_range(b) for b in range(NB)]
+    assert rng[0][0] == 0 and rng[-1][1] == lay.n_train and all(rng[b][1] == rng[b + 1][0] for b in range(NB - 1))   # contiguous RCCL buckets
     assert mae_bucket("decoder_pred.weight") == 0 and mae_bucket("mask_token") == 0 and mae_bucket("norm.weight") == 1
-    assert [mae_bucket("blocks.%d.attn.qkv.weight" % i) for i in range(12)] == [3] * 4 + [2] * 4 + [1] * 4   # backward order
-    assert mae_bucket("patch_embed.proj.weight") == 3
+    assert [mae_bucket("blocks.%d.attn.qkv.weight" % i) for i in range(12)] == [6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1]   # backward order
+    assert mae_bucket("patch_embed.proj.weight") == 6
+    assert max(4 * (e - s) for s, e in rng[1:]) < 60e6     # the exposed (last) encoder bucket: 57 MB of fp32 gradient, was 115
     for n in lay.train_names:
         o = lay.off[n] - lay.train_start
         lo, hi = rng[mae_bucket(n)]
         assert lo <= o and o + int(np.prod(lay.shapes[n])) <= hi, n
         assert lay.off[n] % 64 == 0
-    # segments alternate (bucket, no-decay first); every trainable element is in exactly one AdamW range (<= 8 ranges)
+    # segments alternate (bucket, no-decay first); every trainable element is in exactly one AdamW range
     keys = [tuple(k) for k, _, _ in lay.segments]
-    assert keys == [(b, nd) for b in range(4) for nd in (True, False)]
+    assert keys == [(b, nd) for b in range(NB) for nd in (True, False)]
     covered = sum(e - s for _, s, e in lay.segments)
     assert covered == lay.n_train
     for (bk, nodecay), s, e in lay.segments:
