@@ -1298,6 +1298,7 @@ extern "C" int countr_reduce_table(const long long* table, int n, int total_bloc
 }
 
 int countr_lean_linear(const countr_gemm_args* a, hipStream_t s);   // linear.hip: 1 = does not qualify
+int countr_lean_conv(const countr_gemm_args* a, hipStream_t s);
 
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
@@ -1315,6 +1316,10 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_ROW && modeB == COUNTR_OP_ROW && a->act <= COUNTR_ACT_GELU) {
     const int rc = countr_lean_linear(a, s);   // full-tile nn.Linear forward shapes: the lean kernel of linear.hip
+    if (rc != 1) return rc;
+  }
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_IM2ROW && modeB == COUNTR_OP_ROW) {
+    const int rc = countr_lean_conv(a, s);     // 3x3 convolution forward / dgrad on the big maps: same kernel, im2row LDS-DMA addressing
     if (rc != 1) return rc;
   }
   if (dtype == COUNTR_BF16) return dispatch<bf16_t>(*a, modeA, modeB, s);

@@ -48,6 +48,7 @@ struct LinArgs {
   int M, N, K;
   int lda, ldw, ldc, ldres;   // elements
   int res_mod, tilesN;
+  int H, Wd, Cin;      // CONV (3x3, pad 1, NHWC): A is the map [B, H, Wd, Cin], row m = pixel, k = tap * Cin + c
 };
 
 constexpr int STAGE_BYTES = 32768, B_OFF = 16384;
@@ -86,18 +87,21 @@ __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
 
 // WMB = 128-row blocks per workgroup tile (1: 128x128, 4 compute waves; 2: 256x128, 8 compute waves -- 2/3 of the staged bytes per MFMA,
 // for grids that still fill the chip with half as many tiles); NLD = loader waves (0: every wave stages and multiplies).
-template <int WMB, int NLD, int EPI, int STAGES>
-__global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 * WMB + NLD) / 4) : 2) void lin_kernel(const LinArgs g) {
+// CONV: the A operand is the 3x3 im2row view of an NHWC map (implicit GEMM, forward and -- with dgrad-form weights -- dgrad of the
+// density-head / exemplar convolutions): only the LDS-DMA source addresses differ, the tile in LDS and everything behind it is the same.
+template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1>
+__global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 * WMB * WNB + NLD) / 4) : 2) void lin_kernel(const LinArgs g) {
   constexpr bool SPEC = NLD > 0;
   constexpr bool TWO = SPEC && STAGES == 2;     // wave-specialised with a 2-stage ring: TWO workgroups per CU (64 KB, 128 VGPRs each)
   static_assert(SPEC ? (STAGES >= 2 && STAGES <= 5) : (STAGES == 2 && WMB == 1), "ring depth / plain form");
-  static_assert(!TWO || (WMB == 1 && NLD == 4), "two-per-CU form");
-  constexpr int NCW = 4 * WMB;                  // compute waves, (2 WMB) x 2 sub-tiles of 64x64
+  static_assert(!TWO || (WMB == 1 && WNB == 1 && NLD == 4), "two-per-CU form");
+  static_assert(WMB * WNB <= 2 && (SPEC || WMB * WNB == 1), "tile = 128x128, 256x128 or 128x256");
+  constexpr int NCW = 4 * WMB * WNB;            // compute waves, (2 WMB) x (2 WNB) sub-tiles of 64x64
   constexpr int NLW = SPEC ? NLD : 4;           // waves that stage tiles
   static_assert(NLW == 4, "four staging waves");
-  constexpr int BMt = 128 * WMB;
-  constexpr int A_BYTES = BMt * 128, STAGE_BYTES = A_BYTES + 16384;
-  constexpr int PA = BMt / (8 * NLW), PB = 128 / (8 * NLW);   // 1-KiB pieces per operand per staging wave per k-tile
+  constexpr int BMt = 128 * WMB, BNt = 128 * WNB, SUBN = 2 * WNB;   // SUBN = 64-column sub-tiles per row of sub-tiles
+  constexpr int A_BYTES = BMt * 128, STAGE_BYTES = A_BYTES + BNt * 128;
+  constexpr int PA = BMt / (8 * NLW), PB = BNt / (8 * NLW);   // 1-KiB pieces per operand per staging wave per k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,30 +115,71 @@ __global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 *
     lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
   const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
-  const int m0 = tile_m * BMt, n0 = tile_n * 128;
+  const int m0 = tile_m * BMt, n0 = tile_n * BNt;
   const int ntiles = g.K >> 6;
 
   // ---- LDS-DMA set-up (staging waves): piece (pass i, wave w) = rows [8 NLW i + 8 w, +8) of the operand tile, lane -> (row, 16-byte slot)
   const int drow = cw * 8 + (lane >> 3);
   const int dchunk = (lane & 7) ^ (((cw & 1) << 2) | (lane >> 4));        // = slot ^ ((row >> 1) & 7), pass-independent
-  const uint32_t voffA = (uint32_t)((drow * g.lda + dchunk * 8) * 2);
+  const uint32_t voffA = CONV ? (uint32_t)(((m0 + drow) * g.Cin + dchunk * 8) * 2) : (uint32_t)((drow * g.lda + dchunk * 8) * 2);
   const uint32_t voffB = (uint32_t)((drow * g.ldw + dchunk * 8) * 2);
-  const char* baseA = g.A + (int64_t)m0 * g.lda * 2;
-  const char* baseB = g.W + (int64_t)n0 * g.ldw * 2;
-  const uint32_t passA = (uint32_t)g.lda * (16u * NLW), passB = (uint32_t)g.ldw * (16u * NLW);   // 8 NLW rows further, bytes
+  // CONV: bit t of vmask[i] <=> tap t of this lane's pixel in pass i lies inside the image (zero padding otherwise); the pixel of pass
+  // i + 1 is 8 NLW pixels further in raster order
+  uint32_t vmask[CONV ? PA : 1];
+  if constexpr (CONV) {
+    if (!SPEC || loader) {
+      const int m = m0 + drow;
+      int x = m % g.Wd, y = (m / g.Wd) % g.H;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        uint32_t vm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if ((unsigned)(y + t / 3 - 1) < (unsigned)g.H && (unsigned)(x + t % 3 - 1) < (unsigned)g.Wd) vm |= 1u << t;
+        vmask[i] = vm;
+        x += 8 * NLW;
+        while (x >= g.Wd) { x -= g.Wd; y = (y + 1 == g.H) ? 0 : y + 1; }
+      }
+    }
+  }
+  // The staging loads are MUBUF LDS-DMA (buffer_load_dwordx4 ... offen lds): address = descriptor base + 32-bit lane offset (loop
+  // invariant) + scalar offset (k-tile and pass advance, SALU only) -- no vector address arithmetic per piece -- and a lane whose
+  // offset lies beyond the descriptor's size gets ZEROS (the convolution's padding taps) instead of needing a second source pointer.
+  // (The 64-bit-address form, global_load_lds with a VGPR pair per lane, issued at ~95 cycles per piece and wave and was what bounded
+  // the wave-specialised loop: profiles/r3_linear_stamps.txt.)
+  // CONV: the descriptor base sits (Wd + 1) pixels in front of the map so that every tap shift is a non-negative scalar offset.
+  const int64_t cshift = CONV ? (int64_t)(g.Wd + 1) * g.Cin * 2 : 0;
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(CONV ? g.A - cshift : g.A + (int64_t)m0 * g.lda * 2), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (int64_t)n0 * g.ldw * 2), 0, 0x7ffffff0, 0x00020000);
+  const uint32_t passA = (uint32_t)(CONV ? g.Cin : g.lda) * (16u * NLW), passB = (uint32_t)g.ldw * (16u * NLW);   // 8 NLW rows further, bytes
   auto issue = [&](int t, int slot) {
 #if LIN_ABL == 3
     if (t >= 2) return;
 #endif
     char* dst = smem + slot * STAGE_BYTES + cw * 1024;
-    const char* ua = baseA + t * 128;
-    const char* ub = baseB + t * 128;
+    if constexpr (CONV) {
+      // k-tile t = 64 channels of one tap (64 | Cin): scalar offset = tap shift + channel block, per-lane pixel offset, and one bit
+      // test per piece for the zero padding (offset 2^31 is out of the descriptor's range: the DMA writes zeros)
+      const int k0 = t * 64, tap = k0 / g.Cin, cb = k0 - tap * g.Cin;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const uint32_t so = (uint32_t)(cshift + ((int64_t)(dy * g.Wd + dx) * g.Cin + cb) * 2);
+      const uint32_t bit = 1u << tap;
 #pragma unroll
-    for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ua + i * passA + voffA), (lds_vptr_t)(dst + i * NLW * 1024), 16, 0, 0);
+      for (int i = 0; i < PA; ++i) {
+        // (named variable on purpose: with the conditional expression written as the builtin's argument the HOST pass of hipcc 7.2
+        // silently drops the kernel's stub -- undefined symbol at load time, no diagnostic)
+        const uint32_t vo = (vmask[i] & bit) ? voffA : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * NLW * 1024), 16, vo, so + i * passA, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * NLW * 1024), 16, voffA, t * 128 + i * passA, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_global_load_lds((glb_vptr_t)(ub + i * passB + voffB), (lds_vptr_t)(dst + A_BYTES + i * NLW * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + A_BYTES + i * NLW * 1024), 16, voffB, t * 128 + i * passB, 0, 0);
   };
 
   // loader waves start the ring before anything else; the memory clobber keeps the prefetch loads below BEHIND these in issue order
@@ -151,9 +196,9 @@ __global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 *
   // ---- read-back geometry (epilogue).  A unit = 32 rows x 64 columns of one compute wave's 64x64 sub-tile.  SPEC: compute wave c
   // finishes rows [0, 32) of its own sub-tile, loader l rows [32, 64) of sub-tiles l, l + 4 (, ...); plain: both halves of its own.
   constexpr bool OBF = EPI != EPI_RES;
-  constexpr int NUNITS = SPEC ? WMB : 1;               // read-back units of a loader wave (a compute wave has one)
+  constexpr int NUNITS = SPEC ? NCW / 4 : 1;           // read-back units of a loader wave (a compute wave has one)
   const int sub0 = loader ? (cw & 3) : wv;             // first sub-tile this wave reads back (NCW is a multiple of 4: same column half)
-  const int sn0 = n0 + (sub0 & 1) * 64;
+  const int sn0 = n0 + (sub0 % SUBN) * 64;             // (sub0 + 4 u shares the column block: SUBN divides 4)
   // bf16 out: lane -> 8 columns (2 fp32 chunks), 8 lanes per row;  fp32 out: lane -> 4 columns, 16 lanes per row
   const int ccol = OBF ? (lane & 7) * 8 : (lane & 15) * 4;
   const int rrow = OBF ? (lane >> 3) : (lane >> 4);     // + 8 j (bf16) / 4 j (fp32)
@@ -175,7 +220,7 @@ __global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 *
   if constexpr (RPRE) {
     {
       constexpr int u = 0;
-      const int mrow0 = m0 + ((sub0 + 4 * u) >> 1) * 64 + half0 * 32 + rrow;
+      const int mrow0 = m0 + ((sub0 + 4 * u) / SUBN) * 64 + half0 * 32 + rrow;
       if (g.res_mod > 0) {   // row modulo (pos-embed adds): one division, then steps of 4 rows with a conditional wrap
         int mr = mrow0 % g.res_mod;
 #pragma unroll
@@ -192,7 +237,7 @@ __global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 *
   }
 
   // ---- fragment addresses (compute waves): byte offsets inside a stage for k-step kk; tile tm / tn = +4096 in the offset field
-  const int wm = cw >> 1, wn = cw & 1;
+  const int wm = cw / SUBN, wn = cw % SUBN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int prow = ((l31 >> 2) & 1) * 16 + ((l31 >> 3) & 3) * 4 + (l31 & 3);            // W row permutation p(l31)
   const int swx = (l31 >> 1) & 7, sww = (prow >> 1) & 7;
@@ -366,7 +411,7 @@ __global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 *
   };
   auto finish_half = [&](int sub, int half, int j0, auto USE_RPRE) {   // rows [32 half, +32) of sub-tile `sub`; j0 = index of its rpre[0]
     const char* src = smem + sub * REGION + ((SPEC ? half * 32 : 0) + rrow) * OPITCH + ccol * 4;
-    const int mrow = m0 + (sub >> 1) * 64 + half * 32 + rrow;
+    const int mrow = m0 + (sub / SUBN) * 64 + half * 32 + rrow;
 #pragma unroll
     for (int j = 0; j < NIT_HALF; ++j) {
       const int m = mrow + RSTEP * j;
@@ -413,16 +458,16 @@ __global__ __launch_bounds__(256 * WMB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 *
   }
 }
 
-template <int WMB, int NLD, int EPI, int STAGES>
+template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1>
 int launch_lin(const LinArgs& a, hipStream_t s) {
-  constexpr int ring = STAGES * (128 * WMB * 128 + 16384), staging = NLD ? 4 * WMB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
+  constexpr int ring = STAGES * (128 * WMB + 128 * WNB) * 128, staging = NLD ? 4 * WMB * WNB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
   constexpr int lds = ring > staging ? ring : staging;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES>), dim3((a.M / (128 * WMB)) * a.tilesN), dim3(256 * WMB + 64 * NLD), lds, s, a);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), dim3((a.M / (128 * WMB)) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -434,7 +479,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial) return 1;
   if ((a->M % 128) || (a->N % 128) || (a->K % 64) || a->K < 128) return 1;
   if ((a->lda % 8) || (a->ldb % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2) & 15)) return 1;
-  if ((int64_t)a->M * a->lda * 2 >= (int64_t)0x7fff0000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7fff0000ll) return 1;
+  if ((int64_t)128 * a->lda * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll || (int64_t)256 * a->ldb * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll) return 1;   // per-tile descriptor offsets
   if (!a->bias || ((uintptr_t)a->bias & 15)) return 1;
   int epi;
   if (a->out_bf16) {
@@ -458,7 +503,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
   g.res_mod = a->res_mod; g.tilesN = a->N / 128;
   const long tiles = (long)(a->M / 128) * g.tilesN;
-  int spec_max = 256, big = 0;
+  int spec_max = 256, big = 1;
   { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
   { const char* e = getenv("COUNTR_LEAN_BIG"); if (e) big = atoi(e); }
 #define LIN_LAUNCH(WMB, NLD, ST)                                            \
@@ -471,12 +516,47 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   // waves -- the loaders are not waiting for data, their LDS-DMA instructions ISSUE at ~95 cycles each: 32 KB per k-tile at ~42 B/clk per
   // CU is what bounds this form, profiles/r3_linear_stamps.txt)
   if (tiles <= spec_max) LIN_LAUNCH(1, 4, 3)
-  // bigger grids.  Default: the plain form, two workgroups per CU.  Two wave-specialised alternatives are parity-tested and within 1 us
-  // of it back to back, but lose 0.06 ms per finetune step in the graph (COUNTR_LEAN_BIG=1: 256x128 tiles, 8 + 4 waves, 144 KB ring --
-  // 2/3 of the staged bytes per MFMA, 1470 cycles per k-tile for two tile-equivalents, but 324 / 432 workgroups are two rounds on 256
-  // CUs and a CU-filling workgroup shuts the exemplar side lane out; =2: 128x128, 2-stage ring, two workgroups per CU in 128 VGPRs).
+  // bigger grids.  Default (COUNTR_LEAN_BIG=1): 256x128 tiles, 8 compute + 4 loader waves, 144-KB ring -- 2/3 of the staged bytes per
+  // MFMA; =2: 128x128 wave-specialised on a 2-stage ring, two workgroups per CU in 128 VGPRs; =0 (and M % 256 != 0): the plain form,
+  // two workgroups per CU, every wave stages and multiplies.  Finetune step on one box: 5.03 / 4.99 / 5.01 ms for 0 / 1 / 2 (with the
+  // 64-bit-address DMA form of the first version the order was the other way round: the big tile was DMA-issue bound).
   if (big == 1 && (a->M % 256) == 0) LIN_LAUNCH(2, 4, 3)
   if (big == 2) LIN_LAUNCH(1, 4, 2)
   LIN_LAUNCH(1, 0, 2)
 #undef LIN_LAUNCH
+}
+
+// 3x3 convolution forward / dgrad as implicit GEMM (A = IM2ROW view of an NHWC bf16 map, B = [Cout][9 Cin] weights): 256 x 128 tiles,
+// 8 compute + 4 loader waves.  Returns 1 when the launch does not qualify (gemm_kernel then runs it).
+int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
+  { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 1; }
+  { const char* e = getenv("COUNTR_LEAN_CONV"); if (e && atoi(e) == 0) return 1; }
+#ifndef LIN_STAMP
+  if (a->C2) return 1;
+#endif
+  if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial || a->resid || a->act != COUNTR_ACT_NONE || !a->out_bf16) return 1;
+  if ((a->M % 128) || (a->N % 128) || (a->Cin % 64) || a->K != 9 * a->Cin || a->H < 2 || a->W < 2) return 1;
+  if ((a->ldb % 8) || (a->ldc % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15)) return 1;
+  if ((int64_t)(a->M + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll || a->N > 4096) return 1;
+  if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
+  const long tiles = (long)(a->M / 128) * (a->N / 128);
+  if (tiles <= 256) return 1;     // small maps: the generic kernel's split-K / wave-specialised 128x128 forms
+  static float* zero_bias = nullptr;
+  if (!a->bias && !zero_bias) {
+    if (hipMalloc(&zero_bias, 4096 * sizeof(float)) != hipSuccess || hipMemset(zero_bias, 0, 4096 * sizeof(float)) != hipSuccess) { zero_bias = nullptr; return 1; }
+  }
+  LinArgs g;
+  g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = nullptr; g.bias = a->bias ? a->bias : zero_bias; g.resid = nullptr;
+#ifdef LIN_STAMP
+  g.C2 = (char*)a->C2;   // stamp builds: the debug buffer
+#endif
+  g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = 0;
+  g.res_mod = 0; g.tilesN = a->N / 128; g.H = a->H; g.Wd = a->W; g.Cin = a->Cin;
+  // 128 x 256 tiles when the width allows (the density head's 256 output channels in ONE workgroup: the im2row operand -- nine taps of
+  // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128
+  int form = (a->N % 256) == 0 ? 2 : 1;
+  { const char* e = getenv("COUNTR_LEAN_CONV_FORM"); if (e) form = atoi(e); }
+  if (form == 2 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 3, true, 2>(g, s); }
+  if (a->M % 256) return 1;
+  return launch_lin<2, 4, EPI_BF16, 3, true>(g, s);
 }

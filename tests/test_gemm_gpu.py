@@ -512,3 +512,39 @@ def test_lean_linear_in_place_residual(hip):
     _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
     torch.cuda.synchronize()
     assert (x.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout,use_bias", [(2, 96, 96, 256, 256, True), (8, 48, 48, 512, 256, True), (4, 48, 96, 256, 256, False),
+                                                   (32, 24, 24, 64, 256, True), (2, 96, 96, 256, 512, False)])
+def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin, Cout, use_bias):
+    """The density-head / exemplar 3x3 convolutions on the big maps (forward, and dgrad through the dgrad-form weights) run the lean
+    kernel of linear.hip with im2row LDS-DMA addressing (256x128 tiles, 8 compute + 4 loader waves): against torch conv2d in fp64 and
+    against gemm_kernel (COUNTR_LEAN_CONV=0) on the same bf16 inputs -- zero padding at every image border, tiles that span image
+    boundaries (H x W not a multiple of 256), rows narrower than a 32-pixel staging pass (W = 24), Cin = 64 (one k-tile per tap) and
+    512, with and without bias (dgrad)."""
+    x = _mk((Bsz, H, W, Cin), torch.bfloat16, 51)                 # NHWC
+    w = (_mk((Cout, 3, 3, Cin), torch.float32, 52) * 0.1).to(torch.bfloat16)   # OHWI = [Cout][tap][Cin]
+    bias = _mk((Cout,), torch.float32, 53) if use_bias else None
+    M, K = Bsz * H * W, 9 * Cin
+    assert M % 256 == 0 and (M // 128) * (Cout // 128) > 256
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double() if use_bias else None, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    outs = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("COUNTR_LEAN_CONV", lean)
+        out = torch.full((M, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+        a.bias = bias.data_ptr() if use_bias else None
+        a.ldb, a.ldc = K, Cout
+        a.M, a.N, a.K = M, Cout, K
+        a.H, a.W, a.Cin = H, W, Cin
+        a.out_bf16 = 1
+        a.alpha = 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 2, 0, _stream()), "conv")
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert (out.double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item(), lean
+        outs.append(out)
+    assert (outs[0].double() - outs[1].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()

@@ -29,3 +29,21 @@ for name, N, K, res in (("proj", 768, 768, True), ("fc2", 768, 3072, True), ("de
     mhz = (d[:, 0] / (d[:, 7] * 1e-2)).mean().item()
     print("%-8s %dx%dx%d k-tiles %d waves %d+%d | loaders: loop %.0f/k-tile = load wait %.0f + barrier %.0f + DMA issue %.0f | compute: loop %.0f/k-tile, barrier %.0f | shader clock %.0f MHz"
           % (name, M, N, K, nt, len(cp), len(ld), f(ld, 0), f(ld, 1), f(ld, 2), f(ld, 3), f(cp, 0), f(cp, 2), mhz), flush=True)
+
+# 3x3 convolution forward (im2row A operand), 128x256 tiles
+for Hs, Cin in ((192, 256), (96, 256)):
+    B = 8
+    xx = mk(B, Hs, Hs, Cin); w = mk(256, 9 * Cin, s=0.2); y = torch.empty((B * Hs * Hs, 256), device="cuda", dtype=torch.bfloat16)
+    bias = mk(256, dt=torch.float32)
+    dbg = torch.zeros(1 << 22, device="cuda")
+    a = _lib.GemmArgs(); a.alpha = 1.0; a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    a.A, a.B, a.C, a.C2 = xx.data_ptr(), w.data_ptr(), y.data_ptr(), dbg.data_ptr(); a.ldb, a.ldc = 9 * Cin, 256; a.bias = bias.data_ptr()
+    a.M, a.N, a.K = B * Hs * Hs, 256, 9 * Cin; a.H = a.W = Hs; a.Cin = Cin; a.out_bf16 = 1
+    for _ in range(3): _lib.check(L.countr_gemm(C.byref(a), 1, 2, 0, st()))
+    torch.cuda.synchronize()
+    d = dbg.view(-1, 8).cpu(); d = d[d[:, 6] > 0]
+    nt = 9 * Cin // 64
+    ld, cp = d[d[:, 6] == 1], d[d[:, 6] == 2]
+    f = lambda t, i: t[:, i].mean().item() / nt
+    print("conv %dx%d Cin%d k-tiles %d waves %d+%d | loaders: loop %.0f/k-tile = load wait %.0f + barrier %.0f + DMA issue %.0f | compute: loop %.0f/k-tile, barrier %.0f | shader clock %.0f MHz"
+          % (Hs, Hs, Cin, nt, len(cp), len(ld), f(ld, 0), f(ld, 1), f(ld, 2), f(ld, 3), f(cp, 0), f(cp, 2), (d[:, 0] / (d[:, 7] * 1e-2)).mean().item()), flush=True)
