@@ -42,8 +42,6 @@ typedef __attribute__((address_space(3))) void* lds_vptr_t;
 typedef const __attribute__((address_space(1))) void* glb_vptr_t;
 typedef __attribute__((address_space(3))) const char* lds_cptr_t;
 
-__device__ uint4 g_fa_zero_page[1] = {};   // source of the DMA lanes whose key row does not exist (ragged last tile)
-
 template <typename F, int... I>
 __device__ __forceinline__ void fa_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F> __device__ __forceinline__ void fa_static_for(F&& f) { fa_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
@@ -97,7 +95,8 @@ template <int PENDING> __device__ __forceinline__ void fa_vm_wait() { asm volati
 
 // ABL (timing experiments only, selected by COUNTR_FA_ABL; 1-6 give wrong results): 1 = K/V staged in the prologue only (no loads,
 // LDS stores or barriers in the steps), 2 = 1 + no v_exp, 3 = 1 + no MFMA, 4 = staging and barriers only, 5 = empty kernel,
-// 6 = one tile only (prologue + epilogue), 7 = correct output + s_memtime stamps of wave 0 written to lse (tools/stamp_attn.py)
+// 6 = one tile only (prologue + epilogue), 7 = correct output + s_memtime stamps of wave 0 written to lse (tools/stamp_attn.py),
+// 8 = no fragment reads in the steps (MFMAs on stale registers)
 // PRE: q already carries scale * log2(e) (the frozen encoder's q projection is pre-scaled at weight-packing time, engine.py): the
 // scores come out of the MFMA in the exp2 domain, and because the QK^T accumulators start at -m_ref instead of 0 the softmax
 // needs no subtract / scale FMA at all (one VALU instruction per score less: 32 of ~135 per tile and wave).
@@ -113,7 +112,11 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   constexpr int RPP = 256 / CPR;     // rows staged per pass of the 256 threads (register path)
   constexpr int PASSES = 64 / RPP;
   constexpr int NQK = 2 * KS;        // MFMA slots of QK^T
-  constexpr bool STAGING = !(ABL >= 1 && ABL <= 3);
+#ifndef COUNTR_FA_LA
+#define COUNTR_FA_LA 5
+#endif
+  constexpr int LA = DMA ? COUNTR_FA_LA : 2;   // fragment look-ahead in MFMA slots (register-staged dh = 32 path: compiler-scheduled reads)
+  constexpr bool STAGING = !((ABL >= 1 && ABL <= 3) || ABL == 9 || ABL == 10);   // 9 = 1 + no VALU at all in the steps, 10 = 1 + no row max / rescale
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hh = lane >> 5;
@@ -175,28 +178,36 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   auto Vslot = [&](int slot) { return smem + slot * C::STAGE + C::KT; };
   // DMA path: wave w streams the 1-KiB pieces 2w, 2w+1 (8 rows each) of the K tile and of the V tile of a stage.  Lane L of piece
   // p lands in row R = 8p + (L >> 3), 16-byte slot L & 7, and fetches the chunk that slot holds under the swizzle.
-  int koff[2], voff[2], srowd[2];
+  // The pieces are MUBUF LDS-DMA loads (buffer_load_dwordx4 ... offen lds): descriptor base = this (batch, head)'s K or V, a loop-
+  // invariant 32-bit lane offset, the tile advance as a scalar offset -- no vector address arithmetic per piece -- and key rows beyond N
+  // (ragged last tile) get an offset outside the descriptor, for which the DMA writes zeros.  (Round 2 used global_load_lds with a
+  // 64-bit address pair per lane: ~95 issue cycles per piece and wave, four pieces per step in every wave's instruction stream.)
+  uint32_t koff[2], voff[2];
+  int srowd[2];
   if (DMA) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int R = 8 * (2 * wave + p) + (lane >> 3), cs = lane & 7;
       srowd[p] = R;
-      koff[p] = R * (int)rs + ((cs ^ ((R >> 1) & 7)) << 3);
-      voff[p] = R * (int)rs + ((cs ^ (((R >> 1) & 1) << 2)) << 3);
+      koff[p] = (uint32_t)(R * (int)rs + ((cs ^ ((R >> 1) & 7)) << 3)) * 2u;
+      voff[p] = (uint32_t)(R * (int)rs + ((cs ^ (((R >> 1) & 1) << 2)) << 3)) * 2u;
     }
   }
-  auto dma_tile = [&](const bf16_t* base, int tile, const int (&off)[2], char* dst) {
+  const __amdgpu_buffer_rsrc_t srdK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, 0x7ffffff0, 0x00020000);
+  auto dma_tile = [&](const __amdgpu_buffer_rsrc_t srd, int tile, const uint32_t (&off)[2], char* dst) {
+    const uint32_t so = (uint32_t)tile * 64u * (uint32_t)rs * 2u;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const bf16_t* g = base + (int64_t)tile * 64 * rs + off[p];
-      if (RAGGED && tile * 64 + srowd[p] >= N) g = reinterpret_cast<const bf16_t*>(g_fa_zero_page);
-      __builtin_amdgcn_global_load_lds((glb_vptr_t)g, (lds_vptr_t)(dst + (2 * wave + p) * 1024), 16, 0, 0);
+      uint32_t vo = off[p];
+      if (RAGGED && tile * 64 + srowd[p] >= N) vo = 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_vptr_t)(dst + (2 * wave + p) * 1024), 16, vo, so, 0, 0);
     }
   };
   // stage j = {K(j+1), V(j)} -> ring slot j & 3
   auto dma_stage = [&](int j) {
-    if (j + 1 < T) dma_tile(kp, j + 1, koff, Kslot(j & 3));
-    dma_tile(vp, j, voff, Vslot(j & 3));
+    if (j + 1 < T) dma_tile(srdK, j + 1, koff, Kslot(j & 3));
+    dma_tile(srdV, j, voff, Vslot(j & 3));
   };
   auto stage_count = [&](int j) { return j < T ? (j + 1 < T ? 4 : 2) : 0; };   // DMA instructions of stage j per wave
   auto vm_wait_pending = [&](int pending) {   // all but the newest `pending` DMA instructions of this wave have landed
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   // registers: K(0) -> K area of slot 1, {K(1), V(0)} -> slot 0 (all loads issued before the first wait).
   const char* K0;
   if (DMA) {
-    dma_tile(kp, 0, koff, Kslot(3));
+    dma_tile(srdK, 0, koff, Kslot(3));
     dma_stage(0);
     if (1 < T) dma_stage(1);
     // K(0) first: S(0) and its row max are computed while stages 0 and 1 are still landing
@@ -378,9 +389,15 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
 #pragma unroll
         for (int d = 0; d < DB; ++d) va[d] = sb + vbase[d];
       }
-      bf16x8_t fr[SC::NS];   // operand A of slot j (lives two slots)
+      bf16x8_t fr[SC::NS];   // operand A of slot j (lives LA slots)
+      // Fragment look-ahead.  Round 2 requested a fragment two MFMA slots ahead of its use: with eight waves reading the CU's LDS a
+      // ds_read_b128 / transposing pair comes back after 130-300 cycles, two slots are 64-100 cycles of issue, so most slots began
+      // with a wait and the matrix pipe idled (the loop ran 1740 cycles per step against ~1000 for the same 16 MFMA + 108 VALU per
+      // wave WITHOUT LDS reads: tools/ubench_pingpong.hip mode 0).  LA slots ahead costs 4 VGPRs per slot of the 50 this kernel has spare.
+      constexpr auto lds_after = [](int j) { int n = 0; for (int k = 1; k <= LA; ++k) if (j + k < SC::NS) n += (j + k < NQK) ? 1 : 2; return n; };
       auto issue = [&](auto J) {   // fragment read(s) of MFMA slot j
         constexpr int j = J;
+        if constexpr (ABL == 8) { fr[j] = qf[j & (KS - 1)]; return; }     // timing experiment: no fragment reads
         if constexpr (j < NQK) {
           if constexpr (DMA) fr[j] = fa_read_b128<(j & 1) * 4096>(ka[j >> 1]);
           else fr[j] = kfrag(K, j & 1, j >> 1);
@@ -390,18 +407,20 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
           else fr[j] = vfrag(V, blk, s, d);
         }
       };
-      issue(std::integral_constant<int, 0>{});
-      issue(std::integral_constant<int, 1>{});
+      fa_static_for<LA>([&](auto J) { issue(J); });
       float mx = 0.f;
+      if (ABL != 9) {
 #pragma unroll
-      for (int u = 0; u < SC::PRE; ++u) exp_unit(Sc, u);
+        for (int u = 0; u < SC::PRE; ++u) exp_unit(Sc, u);
+      }
       __builtin_amdgcn_sched_barrier(0);
       fa_static_for<SC::NS>([&](auto J) {
         constexpr int j = J;
-        if constexpr (j + 2 < SC::NS) issue(std::integral_constant<int, j + 2>{});
-        if constexpr (DMA) {   // LDS instructions issued after the reads of slot j: those of slots j+1, j+2
-          constexpr int c1 = (j + 1 < SC::NS) ? (j + 1 < NQK ? 1 : 2) : 0, c2 = (j + 2 < SC::NS) ? (j + 2 < NQK ? 1 : 2) : 0;
-          fa_lds_wait<c1 + c2>(fr[j]);
+        if constexpr (j + LA < SC::NS) issue(std::integral_constant<int, j + LA>{});
+        if constexpr (DMA) {   // LDS instructions issued after the reads of slot j: those of slots j+1 .. j+LA
+          constexpr int pend = lds_after(j);
+          static_assert(pend <= 15, "lgkmcnt is a 4-bit counter");
+          fa_lds_wait<pend>(fr[j]);
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (j < NQK) {
@@ -422,9 +441,11 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
           else o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], pfrag(blk, s), o[d], 0, 0, 0);
         }
         constexpr int u0 = (j == 0) ? SC::PRE : SC::unit_end[j == 0 ? 0 : j - 1], u1 = SC::unit_end[j];
+        if constexpr (ABL != 9) {
 #pragma unroll
-        for (int u = u0; u < u1; ++u) exp_unit(Sc, u);
-        if constexpr (j >= SC::MAX0) {   // row max of S(t+1), a share per slot
+          for (int u = u0; u < u1; ++u) exp_unit(Sc, u);
+        }
+        if constexpr (j >= SC::MAX0 && ABL != 9 && ABL != 10) {   // row max of S(t+1), a share per slot
           constexpr int PER = 16 / (SC::NS - SC::MAX0), r0 = (j - SC::MAX0) * PER;
           if (RAGGED && j == SC::MAX0 && t + 2 == T) mask_tail(Sn, t + 1);
 #pragma unroll
@@ -432,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      rescale_for(xor32_max(mx), Sn);
+      if (ABL != 9 && ABL != 10) rescale_for(xor32_max(mx), Sn);
     }
     if (ABL == 7) tb = __builtin_readcyclecounter();
     if (STAGING) {
@@ -547,7 +568,7 @@ int launch_fa_fwd_pipe(const void* qkv, void* out, float* lse, int B, int N, int
   if (DH == 64 && abl && N % 64 == 0) {
     constexpr int lds64 = FaCfg<64, true>::LDS;
 #define COUNTR_FA_ABL_CASE(A) case A: hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, A>), grid, block, lds64, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c); break;
-    switch (abl) { COUNTR_FA_ABL_CASE(1) COUNTR_FA_ABL_CASE(2) COUNTR_FA_ABL_CASE(3) COUNTR_FA_ABL_CASE(4) COUNTR_FA_ABL_CASE(5) COUNTR_FA_ABL_CASE(6) COUNTR_FA_ABL_CASE(7) default: break; }
+    switch (abl) { COUNTR_FA_ABL_CASE(1) COUNTR_FA_ABL_CASE(2) COUNTR_FA_ABL_CASE(3) COUNTR_FA_ABL_CASE(4) COUNTR_FA_ABL_CASE(5) COUNTR_FA_ABL_CASE(6) COUNTR_FA_ABL_CASE(7) COUNTR_FA_ABL_CASE(8) COUNTR_FA_ABL_CASE(9) COUNTR_FA_ABL_CASE(10) default: break; }
 #undef COUNTR_FA_ABL_CASE
     COUNTR_LAUNCH_CHECK("countr_attn_fwd (ablation)");
   }
