@@ -123,8 +123,12 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
   const int dchunk = (lane & 7) ^ (((cw & 1) << 2) | (lane >> 4));        // = slot ^ ((row >> 1) & 7), pass-independent
   const uint32_t voffA = CONV ? (uint32_t)(((m0 + drow) * g.Cin + dchunk * 8) * 2) : (uint32_t)((drow * g.lda + dchunk * 8) * 2);
   const uint32_t voffB = (uint32_t)((drow * g.ldw + dchunk * 8) * 2);
-  // CONV: bit t of vmask[i] <=> tap t of this lane's pixel in pass i lies inside the image (zero padding otherwise); the pixel of pass
-  // i + 1 is 8 NLW pixels further in raster order
+  // Ragged M (M % tile rows != 0): bit i of rowmask <=> this lane's row of pass i exists; the other lanes stage zeros (an offset outside
+  // the descriptor) and the epilogue skips their rows.  CONV: bit t of vmask[i] <=> tap t of this lane's pixel in pass i lies inside
+  // the image (zero padding otherwise); the pixel of pass i + 1 is 8 NLW pixels further in raster order
+  uint32_t rowmask = 0;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) rowmask |= (m0 + drow + 8 * NLW * i < g.M) ? (1u << i) : 0u;
   uint32_t vmask[CONV ? PA : 1];
   if constexpr (CONV) {
     if (!SPEC || loader) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
         uint32_t vm = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-          if ((unsigned)(y + t / 3 - 1) < (unsigned)g.H && (unsigned)(x + t % 3 - 1) < (unsigned)g.Wd) vm |= 1u << t;
+          if ((rowmask >> i & 1u) && (unsigned)(y + t / 3 - 1) < (unsigned)g.H && (unsigned)(x + t % 3 - 1) < (unsigned)g.Wd) vm |= 1u << t;
         vmask[i] = vm;
         x += 8 * NLW;
         while (x >= g.Wd) { x -= g.Wd; y = (y + 1 == g.H) ? 0 : y + 1; }
@@ -174,8 +178,10 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * NLW * 1024), 16, voffA, t * 128 + i * passA, 0, 0);
+      for (int i = 0; i < PA; ++i) {
+        const uint32_t vo = (rowmask >> i & 1u) ? voffA : 0x80000000u;     // (a named variable: see the note in the CONV branch)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * NLW * 1024), 16, vo, t * 128 + i * passA, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i)
@@ -229,9 +235,9 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
           mr += 4; if (mr >= g.res_mod) mr -= g.res_mod;
         }
       } else {
-        const float* rb = g.resid + (int64_t)mrow0 * g.ldres + sn0 + ccol;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rpre[8 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(rb + (int64_t)(4 * j) * g.ldres));
+        for (int j = 0; j < 8; ++j)   // (rows beyond a ragged M are clamped: fetched, never stored)
+          rpre[8 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g.resid + (int64_t)min(mrow0 + 4 * j, g.M - 1) * g.ldres + sn0 + ccol));
       }
     }
   }
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
 #pragma unroll
     for (int j = 0; j < NIT_HALF; ++j) {
       const int m = mrow + RSTEP * j;
+      if (m >= g.M) continue;            // ragged last tile
       if constexpr (OBF) {
         const f4_t v0 = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH);
         const f4_t v1 = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH + 16);
@@ -467,7 +474,7 @@ int launch_lin(const LinArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), dim3((a.M / (128 * WMB)) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), dim3(((a.M + 128 * WMB - 1) / (128 * WMB)) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -477,7 +484,7 @@ int launch_lin(const LinArgs& a, hipStream_t s) {
 int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 1; }   // read per call: A/B inside one process (not on a replay path)
   if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial) return 1;
-  if ((a->M % 128) || (a->N % 128) || (a->K % 64) || a->K < 128) return 1;
+  if (a->M < 1 || (a->N % 128) || (a->K % 64) || a->K < 128) return 1;      // any M: rows beyond it stage zeros and are not stored
   if ((a->lda % 8) || (a->ldb % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2) & 15)) return 1;
   if ((int64_t)128 * a->lda * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll || (int64_t)256 * a->ldb * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll) return 1;   // per-tile descriptor offsets
   if (!a->bias || ((uintptr_t)a->bias & 15)) return 1;
@@ -502,7 +509,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias; g.resid = a->resid;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
   g.res_mod = a->res_mod; g.tilesN = a->N / 128;
-  const long tiles = (long)(a->M / 128) * g.tilesN;
+  const long tiles = (long)((a->M + 127) / 128) * g.tilesN;
   int spec_max = 256, big = 1;
   { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
   { const char* e = getenv("COUNTR_LEAN_BIG"); if (e) big = atoi(e); }
@@ -520,7 +527,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   // MFMA; =2: 128x128 wave-specialised on a 2-stage ring, two workgroups per CU in 128 VGPRs; =0 (and M % 256 != 0): the plain form,
   // two workgroups per CU, every wave stages and multiplies.  Finetune step on one box: 5.03 / 4.99 / 5.01 ms for 0 / 1 / 2 (with the
   // 64-bit-address DMA form of the first version the order was the other way round: the big tile was DMA-issue bound).
-  if (big == 1 && (a->M % 256) == 0) LIN_LAUNCH(2, 4, 3)
+  if (big == 1) LIN_LAUNCH(2, 4, 3)
   if (big == 2) LIN_LAUNCH(1, 4, 2)
   LIN_LAUNCH(1, 0, 2)
 #undef LIN_LAUNCH
@@ -535,11 +542,11 @@ int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
   if (a->C2) return 1;
 #endif
   if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial || a->resid || a->act != COUNTR_ACT_NONE || !a->out_bf16) return 1;
-  if ((a->M % 128) || (a->N % 128) || (a->Cin % 64) || a->K != 9 * a->Cin || a->H < 2 || a->W < 2) return 1;
+  if (a->M < 1 || (a->N % 128) || (a->Cin % 64) || a->K != 9 * a->Cin || a->H < 2 || a->W < 2) return 1;
   if ((a->ldb % 8) || (a->ldc % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15)) return 1;
   if ((int64_t)(a->M + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll || a->N > 4096) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
-  const long tiles = (long)(a->M / 128) * (a->N / 128);
+  const long tiles = (long)((a->M + 127) / 128) * (a->N / 128);
   if (tiles <= 256) return 1;     // small maps: the generic kernel's split-K / wave-specialised 128x128 forms
   static float* zero_bias = nullptr;
   if (!a->bias && !zero_bias) {
@@ -557,6 +564,5 @@ int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
   int form = (a->N % 256) == 0 ? 2 : 1;
   { const char* e = getenv("COUNTR_LEAN_CONV_FORM"); if (e) form = atoi(e); }
   if (form == 2 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 3, true, 2>(g, s); }
-  if (a->M % 256) return 1;
   return launch_lin<2, 4, EPI_BF16, 3, true>(g, s);
 }
