@@ -30,6 +30,8 @@ class GemmArgs(C.Structure):
         ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
         ("alpha", C.c_float),
         ("rowsum_partial", C.c_void_p),
+        ("ln_xcopy", C.c_void_p), ("ln_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 

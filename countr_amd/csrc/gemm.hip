@@ -1322,6 +1322,10 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
     const int rc = countr_lean_conv(a, s);     // 3x3 convolution forward / dgrad on the big maps: same kernel, im2row LDS-DMA addressing
     if (rc != 1) return rc;
   }
+  if (a->ln_xcopy || a->ln_stats_out || a->ln_stats || a->ln_colsum) {
+    countr_set_error("countr_gemm: the LayerNorm-folding fields need the lean bf16 (ROW, ROW) kernel (N % 128 == 0, K % 64 == 0, aligned operands, bias)");
+    return -1;
+  }
   if (dtype == COUNTR_BF16) return dispatch<bf16_t>(*a, modeA, modeB, s);
   if (dtype == COUNTR_F32) return dispatch<float>(*a, modeA, modeB, s);
   countr_set_error("countr_gemm: bad dtype");

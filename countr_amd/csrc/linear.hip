@@ -49,6 +49,15 @@ struct LinArgs {
   int lda, ldw, ldc, ldres;   // elements
   int res_mod, tilesN;
   int H, Wd, Cin;      // CONV (3x3, pad 1, NHWC): A is the map [B, H, Wd, Cin], row m = pixel, k = tap * Cin + c
+  // LayerNorm folding (LN template flag).  Producer (EPI_RES): xcopy = bf16 copy of the fp32 output, stats_out[m][N/64][2] = {sum, sum of
+  // squares} of the fp32 output row over each 64-column block.  Consumer (EPI_BF16 / EPI_GELU): A is that bf16 copy of the UN-normalised
+  // rows, W carries gamma, stats_in[m][K/64][2] the producer's partials, colsum[n] = sum_k W[n][k]:
+  //   out = rstd_m (acc - mean_m colsum_n) + bias_n  ==  LayerNorm(x)_m W0^T + b0   (W = gamma o W0, bias = b0 + W0 beta).
+  char* xcopy;
+  float* stats_out;
+  const float* stats_in;
+  const float* colsum;
+  float ln_eps;
 };
 
 constexpr int STAGE_BYTES = 32768, B_OFF = 16384;
@@ -89,7 +98,7 @@ __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
 // for grids that still fill the chip with half as many tiles); NLD = loader waves (0: every wave stages and multiplies).
 // CONV: the A operand is the 3x3 im2row view of an NHWC map (implicit GEMM, forward and -- with dgrad-form weights -- dgrad of the
 // density-head / exemplar convolutions): only the LDS-DMA source addresses differ, the tile in LDS and everything behind it is the same.
-template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1>
+template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false>
 __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 * WMB * WNB + NLD) / 4) : 2) void lin_kernel(const LinArgs g) {
   constexpr bool SPEC = NLD > 0;
   constexpr bool TWO = SPEC && STAGES == 2;     // wave-specialised with a 2-stage ring: TWO workgroups per CU (64 KB, 128 VGPRs each)
@@ -202,6 +211,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
   // ---- read-back geometry (epilogue).  A unit = 32 rows x 64 columns of one compute wave's 64x64 sub-tile.  SPEC: compute wave c
   // finishes rows [0, 32) of its own sub-tile, loader l rows [32, 64) of sub-tiles l, l + 4 (, ...); plain: both halves of its own.
   constexpr bool OBF = EPI != EPI_RES;
+  constexpr int RING = STAGES * STAGE_BYTES, STG = SPEC ? NCW * 64 * OPITCH : 0, LNST_OFF = RING > STG ? RING : STG;   // row statistics behind ring / staging
   constexpr int NUNITS = SPEC ? NCW / 4 : 1;           // read-back units of a loader wave (a compute wave has one)
   const int sub0 = loader ? (cw & 3) : wv;             // first sub-tile this wave reads back (NCW is a multiple of 4: same column half)
   const int sn0 = n0 + (sub0 % SUBN) * 64;             // (sub0 + 4 u shares the column block: SUBN divides 4)
@@ -217,6 +227,34 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
     if constexpr (OBF) {
       const float4 b1 = *reinterpret_cast<const float4*>(g.bias + sn0 + ccol + 4);
       bcol[4] = b1.x; bcol[5] = b1.y; bcol[6] = b1.z; bcol[7] = b1.w;
+    }
+  }
+  constexpr bool LNIN = LN && OBF, LNOUT = LN && !OBF;
+  float ccs[LNIN ? 8 : 1];
+  if constexpr (LNIN) {
+    const float4 c0 = *reinterpret_cast<const float4*>(g.colsum + sn0 + ccol), c1 = *reinterpret_cast<const float4*>(g.colsum + sn0 + ccol + 4);
+    ccs[0] = c0.x; ccs[1] = c0.y; ccs[2] = c0.z; ccs[3] = c0.w; ccs[4] = c1.x; ccs[5] = c1.y; ccs[6] = c1.z; ccs[7] = c1.w;
+    // mean / rstd of the tile's rows from the producer's 64-column partials -> LDS behind the ring (read by the epilogue).  The compute
+    // waves do it (they wait for the first k-tile anyway and issue no DMA of their own in the wave-specialised forms)
+    if (!loader && tid < BMt) {
+      const int m = m0 + tid;
+      float s1 = 0.f, s2 = 0.f;
+      if (m < g.M) {
+        const int nblk = g.K >> 6;
+        const float4* sp = reinterpret_cast<const float4*>(g.stats_in + (int64_t)m * nblk * 2);
+        if (nblk == 12) {   // K = 768 (ViT-B): all six loads in flight at once (the runtime-bound loop below waits for each in turn: +4 us)
+          float4 v[6];
+#pragma unroll
+          for (int b2 = 0; b2 < 6; ++b2) v[b2] = sp[b2];
+#pragma unroll
+          for (int b2 = 0; b2 < 6; ++b2) { s1 += v[b2].x + v[b2].z; s2 += v[b2].y + v[b2].w; }
+        } else {
+          for (int b2 = 0; b2 < nblk / 2; ++b2) { const float4 v = sp[b2]; s1 += v.x + v.z; s2 += v.y + v.w; }
+          if (nblk & 1) { const float2 v = *reinterpret_cast<const float2*>(g.stats_in + ((int64_t)m * nblk + nblk - 1) * 2); s1 += v.x; s2 += v.y; }
+        }
+      }
+      const float inv = 1.f / (float)g.K, mean = s1 * inv, var = fmaxf(s2 * inv - mean * mean, 0.f);
+      *reinterpret_cast<float2*>(smem + LNST_OFF + tid * 8) = make_float2(mean, rsqrtf(var + g.ln_eps));
     }
   }
   // residual prefetch (SPEC): the row segments this wave will add, fetched before the main loop
@@ -295,7 +333,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
     if (loader) {
       // loader waves: keep STAGES-1 tiles in flight; tile t has landed when at most (STAGES-2) tiles' worth of loads are outstanding
       constexpr int PER = PA + PB;
-      constexpr int NPRE = (OBF ? 2 : 1) + (RPRE ? 8 : 0);   // bias / residual loads issued after the first STAGES-1 tiles
+      constexpr int NPRE = (OBF ? 2 : 1) + (RPRE ? 8 : 0) + (LNIN ? 2 : 0);   // bias / residual loads issued after the first STAGES-1 tiles
       static_assert((STAGES - 2) * PER + NPRE <= 63, "vmcnt immediate");
       int islot = STAGES - 1;
 #ifdef LIN_STAMP
@@ -425,8 +463,19 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
       if constexpr (OBF) {
         const f4_t v0 = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH);
         const f4_t v1 = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH + 16);
-        f32x2_t p[4] = {{v0[0] + bcol[0], v0[1] + bcol[1]}, {v0[2] + bcol[2], v0[3] + bcol[3]},
-                        {v1[0] + bcol[4], v1[1] + bcol[5]}, {v1[2] + bcol[6], v1[3] + bcol[7]}};
+        f32x2_t p[4];
+        if constexpr (LNIN) {   // rstd (acc - mean colsum) + bias
+          const float2 st = *reinterpret_cast<const float2*>(smem + LNST_OFF + (m - m0) * 8);
+          const float rs = st.y, t = -st.x * st.y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p[e][0] = __builtin_fmaf(e < 2 ? v0[2 * e] : v1[2 * e - 4], rs, __builtin_fmaf(t, ccs[2 * e], bcol[2 * e]));
+            p[e][1] = __builtin_fmaf(e < 2 ? v0[2 * e + 1] : v1[2 * e - 3], rs, __builtin_fmaf(t, ccs[2 * e + 1], bcol[2 * e + 1]));
+          }
+        } else {
+          p[0] = f32x2_t{v0[0] + bcol[0], v0[1] + bcol[1]}; p[1] = f32x2_t{v0[2] + bcol[2], v0[3] + bcol[3]};
+          p[2] = f32x2_t{v1[0] + bcol[4], v1[1] + bcol[5]}; p[3] = f32x2_t{v1[2] + bcol[6], v1[3] + bcol[7]};
+        }
         const int64_t o = ((int64_t)m * g.ldc + sn0 + ccol) * 2;
         if constexpr (EPI == EPI_GELU) {
           if (g.C2) *reinterpret_cast<u32x4_t*>(g.C2 + o) = u32x4_t{pack2bf(p[0][0], p[0][1]), pack2bf(p[1][0], p[1][1]), pack2bf(p[2][0], p[2][1]), pack2bf(p[3][0], p[3][1])};
@@ -440,6 +489,12 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
         if constexpr (decltype(USE_RPRE)::value) v += rpre[j0 + j];
         else v += *reinterpret_cast<const f4_t*>(g.resid + (int64_t)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldres + sn0 + ccol);
         *reinterpret_cast<f4_t*>(g.C + ((int64_t)m * g.ldc + sn0 + ccol) * 4) = v;
+        if constexpr (LNOUT) {   // bf16 copy for the next GEMM's A operand + this 64-column block's row partials (16 lanes = one row)
+          *reinterpret_cast<uint2*>(g.xcopy + ((int64_t)m * g.ldc + sn0 + ccol) * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+          const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+          if ((lane & 15) == 0) *reinterpret_cast<float2*>(g.stats_out + ((int64_t)m * (g.N >> 6) + (sn0 >> 6)) * 2) = make_float2(s1, s2);
+        }
       }
     }
   };
@@ -465,16 +520,16 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
   }
 }
 
-template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1>
+template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false>
 int launch_lin(const LinArgs& a, hipStream_t s) {
   constexpr int ring = STAGES * (128 * WMB + 128 * WNB) * 128, staging = NLD ? 4 * WMB * WNB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
-  constexpr int lds = ring > staging ? ring : staging;
+  constexpr int lds = (ring > staging ? ring : staging) + ((LN && EPI != EPI_RES) ? 128 * WMB * 8 : 0);   // + the consumer's row statistics
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB>), dim3(((a.M + 128 * WMB - 1) / (128 * WMB)) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN>), dim3(((a.M + 128 * WMB - 1) / (128 * WMB)) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -505,19 +560,28 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
     if (!a->resid || a->act != COUNTR_ACT_NONE || (a->ldc % 4) || (a->ldres % 4) || ((uintptr_t)a->resid & 15)) return 1;
     epi = EPI_RES;
   }
+  const bool ln_out = a->ln_xcopy != nullptr || a->ln_stats_out != nullptr, ln_in = a->ln_stats != nullptr || a->ln_colsum != nullptr;
+  if (ln_out && (epi != EPI_RES || !a->ln_xcopy || !a->ln_stats_out || ((uintptr_t)a->ln_xcopy & 15) || ((uintptr_t)a->ln_stats_out & 7))) return 1;
+  if (ln_in && (epi == EPI_RES || !a->ln_stats || !a->ln_colsum || (((uintptr_t)a->ln_stats | (uintptr_t)a->ln_colsum) & 15) || a->ln_nblk != a->K / 64)) return 1;
   LinArgs g;
+  g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias; g.resid = a->resid;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
-  g.res_mod = a->res_mod; g.tilesN = a->N / 128;
+  g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.H = g.Wd = g.Cin = 0;
   const long tiles = (long)((a->M + 127) / 128) * g.tilesN;
   int spec_max = 256, big = 1;
   { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
   { const char* e = getenv("COUNTR_LEAN_BIG"); if (e) big = atoi(e); }
-#define LIN_LAUNCH(WMB, NLD, ST)                                            \
-  {                                                                         \
-    if (epi == EPI_BF16) return launch_lin<WMB, NLD, EPI_BF16, ST>(g, s);   \
-    if (epi == EPI_GELU) return launch_lin<WMB, NLD, EPI_GELU, ST>(g, s);   \
-    return launch_lin<WMB, NLD, EPI_RES, ST>(g, s);                         \
+#define LIN_LAUNCH(WMB, NLD, ST)                                                                    \
+  {                                                                                                 \
+    if (ln_in || ln_out) {                                                                          \
+      if (epi == EPI_BF16) return launch_lin<WMB, NLD, EPI_BF16, ST, false, 1, true>(g, s);         \
+      if (epi == EPI_GELU) return launch_lin<WMB, NLD, EPI_GELU, ST, false, 1, true>(g, s);         \
+      return launch_lin<WMB, NLD, EPI_RES, ST, false, 1, true>(g, s);                               \
+    }                                                                                               \
+    if (epi == EPI_BF16) return launch_lin<WMB, NLD, EPI_BF16, ST>(g, s);                           \
+    if (epi == EPI_GELU) return launch_lin<WMB, NLD, EPI_GELU, ST>(g, s);                           \
+    return launch_lin<WMB, NLD, EPI_RES, ST>(g, s);                                                 \
   }
   // one workgroup per CU at most: 4 compute + 4 loader waves on a 3-stage ring.  (Measured and dropped: 4- and 5-stage rings and 8 loader
   // waves -- the loaders are not waiting for data, their LDS-DMA instructions ISSUE at ~95 cycles each: 32 KB per k-tile at ~42 B/clk per
@@ -528,7 +592,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   // two workgroups per CU, every wave stages and multiplies.  Finetune step on one box: 5.03 / 4.99 / 5.01 ms for 0 / 1 / 2 (with the
   // 64-bit-address DMA form of the first version the order was the other way round: the big tile was DMA-issue bound).
   if (big == 1) LIN_LAUNCH(2, 4, 3)
-  if (big == 2) LIN_LAUNCH(1, 4, 2)
+  if (big == 2 && !ln_in && !ln_out) LIN_LAUNCH(1, 4, 2)
   LIN_LAUNCH(1, 0, 2)
 #undef LIN_LAUNCH
 }
@@ -559,6 +623,7 @@ int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
 #endif
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = 0;
   g.res_mod = 0; g.tilesN = a->N / 128; g.H = a->H; g.Wd = a->W; g.Cin = a->Cin;
+  g.xcopy = nullptr; g.stats_out = nullptr; g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f;
   // 128 x 256 tiles when the width allows (the density head's 256 output channels in ONE workgroup: the im2row operand -- nine taps of
   // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128
   int form = (a->N % 256) == 0 ? 2 : 1;

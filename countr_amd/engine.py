@@ -199,6 +199,12 @@ class Engine:
         self.prescale_q = (self.FROZEN_ENCODER and precision == "bf16" and attention != "unfused" and self.D // self.H == 64
                            and self.N % 64 == 0 and os.environ.get("COUNTR_PRESCALE_Q", "1") != "0")
         self.qkv_bias_pre = None
+        # frozen encoder, bf16: norm1 / norm2 are folded into the qkv / fc1 layers (gamma into the packed weights, beta into the bias;
+        # the proj / fc2 / patch-embed epilogues emit the bf16 operand + 64-column row partials, the qkv / fc1 epilogues apply mean and
+        # rstd -- _pack_prescaled_q, _build): 24 LayerNorm launches and their 0.5 GB of traffic per step gone.  COUNTR_LN_FOLD=0 disables.
+        self.ln_fold = (self.FROZEN_ENCODER and precision == "bf16" and self.D % 128 == 0 and os.environ.get("COUNTR_LN_FOLD", "1") != "0"
+                        and os.environ.get("COUNTR_LEAN", "1") != "0")
+        self.fc1_bias_pre = self.ln_c_qkv = self.ln_c_fc1 = None
         self._ws = {}
         self._need = {}
         self._sizing = False
@@ -250,24 +256,48 @@ class Engine:
             lo = lay.train_start if trainable_only else 0
             _lib.check(L.countr_cast_permute(self.P.data_ptr() + 4 * lo, self.Wt.data_ptr() + 2 * lo, lay.total - lo, 0, 0, 0, 0,
                                              BF16, st), "cast")
-            if self.prescale_q and not trainable_only and stream is None:
+            if (self.prescale_q or self.ln_fold) and not trainable_only and stream is None:
                 self._pack_prescaled_q()
         self._refresh_conv_shadows()
 
     def _pack_prescaled_q(self):
-        """Frozen encoder, bf16 mode: the q rows of every blocks.i.attn.qkv shadow (and a copy of its bias) carry the factor
-        dh^-0.5 * log2(e), rounded ONCE from the fp32 master -- q = x W_q^T + b_q is linear, so the attention kernel receives
-        scores in the exp2 domain (countr_attn_fwd with scale <= 0) and does no per-score scale / subtract.  Weight-packing
-        time only (load_state_dict / .to()), a few torch elementwise ops on the engine's stream."""
-        D, lay = self.D, self.layout
-        c = (D // self.H) ** -0.5 * 1.4426950408889634
+        """Frozen encoder, bf16 mode, weight-packing time only (load_state_dict / .to()): a few torch ops on the engine's stream.
+        (1) pre-scaled q: the q rows of every blocks.i.attn.qkv shadow (and a copy of its bias) carry the factor dh^-0.5 * log2(e),
+        rounded ONCE from the fp32 master -- q = x W_q^T + b_q is linear, so the attention kernel receives scores in the exp2 domain
+        (countr_attn_fwd with scale <= 0) and does no per-score scale / subtract.
+        (2) LayerNorm folding (ln_fold): LN(x) W^T + b = rstd (x (gamma o W)^T - mean c) + (b + W beta), c_n = sum_k (gamma o W)_nk: the
+        qkv / fc1 shadows carry gamma of norm1 / norm2, the bias copies carry W beta, and c is summed from the ROUNDED bf16 shadow (the
+        values the GEMM multiplies), so that a constant row still maps to exactly the bias."""
+        D, lay, P = self.D, self.layout, self.P
+        c = (D // self.H) ** -0.5 * 1.4426950408889634 if self.prescale_q else 1.0
         if self.qkv_bias_pre is None:
             self.qkv_bias_pre = torch.zeros((self.depth, 3 * D), device=self.device, dtype=torch.float32)
+            if self.ln_fold:
+                self.fc1_bias_pre = torch.zeros((self.depth, 4 * D), device=self.device, dtype=torch.float32)
+                self.ln_c_qkv = torch.zeros((self.depth, 3 * D), device=self.device, dtype=torch.float32)
+                self.ln_c_fc1 = torch.zeros((self.depth, 4 * D), device=self.device, dtype=torch.float32)
+        view = lambda name, *shape: P[lay.off[name]:lay.off[name] + math.prod(shape)].view(*shape)
         for i in range(self.depth):
-            ow, ob = lay.off["blocks.%d.attn.qkv.weight" % i], lay.off["blocks.%d.attn.qkv.bias" % i]
-            self.Wt[ow:ow + D * D].copy_((self.P[ow:ow + D * D] * c).to(torch.bfloat16))
-            self.qkv_bias_pre[i].copy_(self.P[ob:ob + 3 * D])
-            self.qkv_bias_pre[i, :D].mul_(c)
+            b = "blocks.%d." % i
+            W, bias = view(b + "attn.qkv.weight", 3 * D, D), view(b + "attn.qkv.bias", 3 * D)
+            ow = lay.off[b + "attn.qkv.weight"]
+            if self.ln_fold:
+                g1, be1 = view(b + "norm1.weight", D), view(b + "norm1.bias", D)
+                Wf, bf = W * g1[None, :], bias + W @ be1
+            else:
+                Wf, bf = W.clone(), bias.clone()
+            Wf[:D] *= c
+            bf[:D] *= c
+            self.Wt[ow:ow + 3 * D * D].copy_(Wf.reshape(-1).to(torch.bfloat16))
+            self.qkv_bias_pre[i].copy_(bf)
+            if self.ln_fold:
+                self.ln_c_qkv[i].copy_(self.Wt[ow:ow + 3 * D * D].view(3 * D, D).float().sum(1))
+                W1, b1 = view(b + "mlp.fc1.weight", 4 * D, D), view(b + "mlp.fc1.bias", 4 * D)
+                g2, be2 = view(b + "norm2.weight", D), view(b + "norm2.bias", D)
+                o1 = lay.off[b + "mlp.fc1.weight"]
+                self.Wt[o1:o1 + 4 * D * D].copy_((W1 * g2[None, :]).reshape(-1).to(torch.bfloat16))
+                self.fc1_bias_pre[i].copy_(b1 + W1 @ be2)
+                self.ln_c_fc1[i].copy_(self.Wt[o1:o1 + 4 * D * D].view(4 * D, D).float().sum(1))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -443,9 +473,11 @@ class Engine:
             self._flush_list(key)
 
     # linear forward: out = act(x W^T + b) (+ resid)
-    def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True, bias_ptr=None):
+    def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True, bias_ptr=None, **ln):
+        """**ln: the LayerNorm-folding fields of countr_gemm_args (ln_xcopy / ln_stats_out for a producer, ln_stats / ln_colsum /
+        ln_nblk / ln_eps for a consumer)."""
         out_bf16 = (out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
-        self._gemm(ops, self.code, OP_ROW, OP_ROW, A=x.data_ptr(), B=self._wp(wname), C=out.data_ptr(),
+        self._gemm(ops, self.code, OP_ROW, OP_ROW, A=x.data_ptr(), B=self._wp(wname), C=out.data_ptr(), **ln,
                    C2=(pre.data_ptr() if pre is not None else None),
                    bias=(bias_ptr if bias_ptr is not None else (self._pp(wname[:-6] + "bias") if bias else None)),
                    resid=(resid if isinstance(resid, int) else (resid.data_ptr() if resid is not None else None)),
@@ -682,22 +714,30 @@ class Engine:
         latent = A("latent", (rows, D), T)
         self._op(ops, L.countr_im2patch, img.data_ptr(), patches.data_ptr(), B, self.img, self.img, self.patch, code)
         Kp = 3 * self.patch * self.patch
+        pre_q, fold = self.prescale_q, self.ln_fold
+        if (pre_q or fold) and self.qkv_bias_pre is None:
+            self._pack_prescaled_q()
+        # LayerNorm folding: every producer of the residual stream x (patch embed, proj, fc2) also leaves its bf16 copy in xn and the
+        # row partials in lnst; the consumers (qkv, fc1) read xn and normalise in their epilogue
+        lnst = A("lnstats", (rows, D // 64, 2), f32) if fold else None
+        prod = dict(ln_xcopy=xn.data_ptr(), ln_stats_out=lnst.data_ptr()) if fold else {}
+        cons = (lambda cvec: dict(ln_stats=lnst.data_ptr(), ln_colsum=cvec.data_ptr(), ln_nblk=D // 64, ln_eps=self.ln_eps)) if fold else (lambda cvec: {})
         self._gemm(ops, code, OP_ROW, OP_ROW, A=patches.data_ptr(), B=self._wp("patch_embed.proj.weight"), C=x.data_ptr(),
                    bias=self._pp("patch_embed.proj.bias"), resid=self._pp("pos_embed"), lda=Kp, ldb=Kp, ldc=D, ldres=D,
-                   M=rows, N=D, K=Kp, res_mod=N, out_bf16=0)
+                   M=rows, N=D, K=Kp, res_mod=N, out_bf16=0, **prod)
         for i in range(self.depth):
             b = "blocks.%d" % i
-            self._layernorm(ops, x, b + ".norm1", xn, rows, D)
-            pre_q = self.prescale_q
-            if pre_q and self.qkv_bias_pre is None:
-                self._pack_prescaled_q()
+            if not fold:
+                self._layernorm(ops, x, b + ".norm1", xn, rows, D)
             self._linear(ops, xn, b + ".attn.qkv.weight", qkv, rows, 3 * D, D,
-                         bias_ptr=self.qkv_bias_pre[i].data_ptr() if pre_q else None)
+                         bias_ptr=self.qkv_bias_pre[i].data_ptr() if (pre_q or fold) else None, **cons(self.ln_c_qkv[i] if fold else None))
             self._attention_fwd(ops, p, qkv, att, B, H, D, prescaled=pre_q)
-            self._linear(ops, att, b + ".attn.proj.weight", x, rows, D, D, resid=x)
-            self._layernorm(ops, x, b + ".norm2", xn, rows, D)
-            self._linear(ops, xn, b + ".mlp.fc1.weight", hid, rows, 4 * D, D, act=ACT_GELU)
-            self._linear(ops, hid, b + ".mlp.fc2.weight", x, rows, D, 4 * D, resid=x)
+            self._linear(ops, att, b + ".attn.proj.weight", x, rows, D, D, resid=x, **prod)
+            if not fold:
+                self._layernorm(ops, x, b + ".norm2", xn, rows, D)
+            self._linear(ops, xn, b + ".mlp.fc1.weight", hid, rows, 4 * D, D, act=ACT_GELU,
+                         bias_ptr=self.fc1_bias_pre[i].data_ptr() if fold else None, **cons(self.ln_c_fc1[i] if fold else None))
+            self._linear(ops, hid, b + ".mlp.fc2.weight", x, rows, D, 4 * D, resid=x, **({} if i + 1 == self.depth else prod))
         self._layernorm(ops, x, "norm", latent, rows, D)
         p.enc_ops = len(ops)
 

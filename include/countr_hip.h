@@ -78,6 +78,18 @@ typedef struct countr_gemm_args {
   float alpha;
   float* rowsum_partial; /* optional (bf16 split-K only): fp32 [max(splitk,1)][M] receives sum_k A(m,k) per
                             K split -- the bias gradient of a wgrad GEMM, fused as one extra MFMA per tile    */
+  /* LayerNorm folded into the surrounding nn.Linear layers (frozen encoder, bf16, (ROW, ROW), N % 128 == 0, K % 64 == 0; timm Block:
+   * x = x + proj(attn(norm1(x))); x = x + fc2(gelu(fc1(norm2(x)))) -- models_mae_cross.py:144-146).
+   * Producer (fp32 output with residual): ln_xcopy receives a bf16 copy of C, ln_stats_out[m][N/64][2] the {sum, sum of squares} of
+   * every 64-column block of the fp32 output row.  Consumer (bf16 output): A is that copy, B = gamma o W, bias = b + W beta,
+   * ln_stats the producer's partials (ln_nblk = K / 64 blocks per row), ln_colsum[n] = sum_k B[n][k]; the epilogue applies
+   * rstd_m (acc - mean_m ln_colsum[n]) + bias[n] with mean / rstd over the K features of row m (biased variance, ln_eps). */
+  void* ln_xcopy;
+  float* ln_stats_out;
+  const float* ln_stats;
+  const float* ln_colsum;
+  int32_t ln_nblk;
+  float ln_eps;
 } countr_gemm_args;
 
 int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream);

@@ -549,3 +549,81 @@ def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin,
         assert (out.double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item(), lean
         outs.append(out)
     assert (outs[0].double() - outs[1].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M", [4608, 576, 14976])
+@pytest.mark.parametrize("act", [0, 1])
+def test_lean_linear_layernorm_folding(hip, M, act):
+    """LayerNorm folded into the Linear layers around it (frozen encoder): a producer GEMM (bias + fp32 residual) also emits the bf16
+    copy of its output and the {sum, sum of squares} of every 64-column block of each output row; a consumer GEMM on that copy with
+    gamma folded into its weights applies rstd (acc - mean colsum) + (b + W beta).  Reference: torch fp64
+    LayerNorm(x) W^T + b (+ GELU) with x = the producer's fp32 output.  What the fold changes numerically: the GEMM operand is the
+    rounded RAW row instead of the rounded normalised row, so its rounding error relative to sigma grows by sqrt(1 + (mean / sigma)^2).
+    Rows with mean ~ 0 (the transformer's case: per-token means of the residual stream are a fraction of sigma) must match the unfolded
+    path's error; every 7th row here has |mean| = 12 sigma and is held to that factor (documented limit, COUNTR_LN_FOLD=0 is the way out)."""
+    D, N2 = 768, 1536
+    eps = 1e-6
+    A0 = _mk((M, D), torch.bfloat16, 61)
+    W0 = (_mk((D, D), torch.float32, 62) * 0.05).to(torch.bfloat16)
+    b0 = _mk((D,), torch.float32, 63)
+    x_in = _mk((M, D), torch.float32, 64) * 2
+    x_in[::7] += 15.0                                             # rows with mean >> sigma
+    x = x_in.clone()
+    xb = torch.full((M, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    st = torch.full((M, D // 64, 2), float("nan"), device="cuda", dtype=torch.float32)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C, a.resid, a.bias = A0.data_ptr(), W0.data_ptr(), x.data_ptr(), x.data_ptr(), b0.data_ptr()
+    a.lda, a.ldb, a.ldc, a.ldres = D, D, D, D
+    a.M, a.N, a.K = M, D, D
+    a.alpha = 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    a.ln_xcopy, a.ln_stats_out = xb.data_ptr(), st.data_ptr()
+    _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "producer")
+    torch.cuda.synchronize()
+    xr = x_in.double() + A0.double() @ W0.double().t() + b0.double()
+    assert (x.double() - xr).abs().max().item() <= 2e-5 * xr.abs().max().item()
+    assert torch.equal(xb, x.to(torch.bfloat16))                                            # the copy is the rounded fp32 output
+    blocks = x.double().view(M, D // 64, 64)
+    assert (st[..., 0].double() - blocks.sum(-1)).abs().max().item() <= 1e-4 * blocks.sum(-1).abs().max().item()
+    assert (st[..., 1].double() - (blocks ** 2).sum(-1)).abs().max().item() <= 1e-5 * (blocks ** 2).sum(-1).abs().max().item()
+    # consumer
+    gamma = _mk((D,), torch.float32, 65) * 0.5 + 1.0
+    beta = _mk((D,), torch.float32, 66) * 0.2
+    W1 = _mk((N2, D), torch.float32, 67) * 0.05
+    b1 = _mk((N2,), torch.float32, 68)
+    Wf = (W1 * gamma[None, :]).to(torch.bfloat16)
+    colsum = Wf.float().sum(1).contiguous()
+    bf = (b1 + W1 @ beta).contiguous()
+    out = torch.full((M, N2), float("nan"), device="cuda", dtype=torch.bfloat16)
+    c = _lib.GemmArgs()
+    c.A, c.B, c.C, c.bias = xb.data_ptr(), Wf.data_ptr(), out.data_ptr(), bf.data_ptr()
+    c.lda, c.ldb, c.ldc = D, D, N2
+    c.M, c.N, c.K = M, N2, D
+    c.act = act
+    c.out_bf16 = 1
+    c.alpha = 1.0
+    c.nbatch = 1; c.nb1 = 1; c.splitk = 1
+    c.ln_stats, c.ln_colsum, c.ln_nblk, c.ln_eps = st.data_ptr(), colsum.data_ptr(), D // 64, eps
+    _lib.check(hip.countr_gemm(C.byref(c), 1, 0, 0, _stream()), "consumer")
+    torch.cuda.synchronize()
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), eps)
+    ref = ln @ W1.double().t() + b1.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    err = (out.double() - ref).abs()
+    # what the unfolded path costs: LN output rounded to bf16, weights rounded to bf16, bf16 output
+    base = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), eps).to(torch.bfloat16).double() @ W1.to(torch.bfloat16).double().t() + b1.double()
+    if act:
+        base = torch.nn.functional.gelu(base)
+    base_err = (base.to(torch.bfloat16).double() - ref).abs()
+    assert torch.isfinite(out.float()).all()
+    kappa = torch.sqrt(1 + (x.double().mean(1) / x.double().std(1, unbiased=False)) ** 2)          # per-row amplification of the operand rounding
+    plain = kappa < 1.5
+    assert plain.float().mean().item() > 0.8 and kappa.max().item() > 8
+    bmax, brms = base_err.max().item(), base_err.pow(2).mean().sqrt().item()
+    assert err[plain].max().item() <= 2.5 * bmax, (err[plain].max().item(), bmax)
+    assert err[plain].pow(2).mean().sqrt().item() <= 1.5 * brms + 1e-4, (err[plain].pow(2).mean().sqrt().item(), brms)
+    assert (err.max(1).values / kappa).max().item() <= 2.5 * bmax, ((err.max(1).values / kappa).max().item(), bmax)
+    # the generic kernel refuses the fields loudly (no silent un-normalised result)
+    c.N = 1536 + 4
+    assert hip.countr_gemm(C.byref(c), 1, 0, 0, _stream()) != 0
