@@ -116,13 +116,16 @@ def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=Tr
     return {"bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
             "frac": achieved / MFMA_BF16_PEAK, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": 28311552 * batch // 8,
             "north_star_target_frac": 0.9,
-            "measured_ceiling_frac": 0.47,
-            "ceiling_note": "0.9 of 2.5 PF is not reachable for N = 576, dh = 64 on this chip: (1) with all 256 CUs issuing MFMAs the clock "
-                            "settles at 1.92 GHz = 2.0 PF sustained (tools/ubench_clock.hip, profiles/r3_clock_microbench.txt); (2) per 64-key tile a "
-                            "wave needs 512 matrix cycles and ~470 VALU cycles (32 v_exp_f32 at 8.3 cycles each), and a 32-cycle MFMA hides only "
-                            "~12 cycles of VALU of the SIMD's two waves (profiles/r2_issue_microbench.txt): 59 % of the matrix pipe in steady state "
-                            "= 0.47 of 2.5 PF; (3) at B = 8 every workgroup is resident at once, so ~5 us of launch ramp + first-touch prologue + "
-                            "tail per launch are not amortised.",
+            "measured_ceiling_frac": 0.67,
+            "ceiling_note": "0.9 of 2.5 PF is not reachable for N = 576 on this chip whatever the kernel does: (1) with all 256 CUs issuing "
+                            "MFMAs the clock settles at 1.92 GHz = 2.02 PF sustained = 0.81 (tools/ubench_clock.hip, profiles/r3_clock_microbench.txt); "
+                            "(2) 576 query rows are 18 waves of 32 rows per (batch, head), 1728 waves on 2048 wave slots: 0.84 of that = 0.67.  This "
+                            "kernel's distance from 0.67: at B = 8 every workgroup is resident at once, so prologue (4.5 k cycles) + tail / epilogue "
+                            "(~5 k) of a 24 k-cycle workgroup are not amortised; in the loop the two waves of a SIMD reach 63 % of the matrix pipe "
+                            "(1617 cycles per 2 x 16 MFMAs; profiles/r3_attention_anatomy.txt: MFMA-only steps 14 us, VALU-only 24 us, together 31 us "
+                            "at B = 32).  Round 2 read that as a VALU-issue bound; a two-wave microbenchmark with the same instruction mix and no "
+                            "memory (tools/ubench_pingpong.hip, mode 0) runs AT the matrix-pipe bound, so the loss is in how this kernel's stream "
+                            "interleaves, not in the hardware -- open (DESIGN.md section 5).",
             "kernel": "fa_fwd_pipe_kernel<64>: encoder attention core (QK^T, softmax, PV), one launch per layer",
             "us_per_launch": us,
             "timing": "in-step, HIP events on the launch stream, %d encoder launches x %d eager forward passes: median of [attention + next launch] "
