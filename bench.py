@@ -121,11 +121,11 @@ def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=Tr
                             "MFMAs the clock settles at 1.92 GHz = 2.02 PF sustained = 0.81 (tools/ubench_clock.hip, profiles/r3_clock_microbench.txt); "
                             "(2) 576 query rows are 18 waves of 32 rows per (batch, head), 1728 waves on 2048 wave slots: 0.84 of that = 0.67.  This "
                             "kernel's distance from 0.67: at B = 8 every workgroup is resident at once, so prologue (4.5 k cycles) + tail / epilogue "
-                            "(~5 k) of a 24 k-cycle workgroup are not amortised; in the loop the two waves of a SIMD reach 63 % of the matrix pipe "
-                            "(1617 cycles per 2 x 16 MFMAs; profiles/r3_attention_anatomy.txt: MFMA-only steps 14 us, VALU-only 24 us, together 31 us "
-                            "at B = 32).  Round 2 read that as a VALU-issue bound; a two-wave microbenchmark with the same instruction mix and no "
-                            "memory (tools/ubench_pingpong.hip, mode 0) runs AT the matrix-pipe bound, so the loss is in how this kernel's stream "
-                            "interleaves, not in the hardware -- open (DESIGN.md section 5).",
+                            "(~5 k) of a 24 k-cycle workgroup are not amortised; in the loop the two waves of a SIMD need 1617 cycles per step for "
+                            "2 x 16 MFMAs = 63 % of the matrix pipe, and that is the cost of the instruction stream itself: a replica of the step's "
+                            "compute without any memory traffic (tools/ubench_fa_step.hip, profiles/r3_fa_step_microbench.txt) gives the younger "
+                            "wave 1611 cycles -- 1024 matrix + ~590 cycles of exp / row-sum / pack / max VALU that two waves cannot hide under "
+                            "their MFMAs on this SIMD (v_exp_f32 alone: 210).",
             "kernel": "fa_fwd_pipe_kernel<64>: encoder attention core (QK^T, softmax, PV), one launch per layer",
             "us_per_launch": us,
             "timing": "in-step, HIP events on the launch stream, %d encoder launches x %d eager forward passes: median of [attention + next launch] "

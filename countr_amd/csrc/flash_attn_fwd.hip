@@ -115,6 +115,10 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
 #ifndef COUNTR_FA_LA
 #define COUNTR_FA_LA 5
 #endif
+#ifndef COUNTR_FA_SPLIT
+#define COUNTR_FA_SPLIT 0
+#endif
+  constexpr bool SPLIT = DMA && COUNTR_FA_SPLIT;
   constexpr int LA = DMA ? COUNTR_FA_LA : 2;   // fragment look-ahead in MFMA slots (register-staged dh = 32 path: compiler-scheduled reads)
   constexpr bool STAGING = !((ABL >= 1 && ABL <= 3) || ABL == 9 || ABL == 10);   // 9 = 1 + no VALU at all in the steps, 10 = 1 + no row max / rescale
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,6 +297,21 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
     l1 += p1;
     P[blk][w] = pack2bf(p0, p1);
   };
+  // split form (COUNTR_FA_SPLIT): the two v_exp_f32 of unit u are issued in one MFMA slot, the instructions that consume them (row
+  // sums, bf16 pack) in the next, so that an in-order wave never waits for a transcendental result
+  float pe[16][2];
+  auto exp_only = [&](const f32x16_t (&S)[2], int u) {
+    const int blk = u >> 3, w = u & 7;
+    float p0 = PRE ? S[blk][2 * w] : __builtin_fmaf(S[blk][2 * w], c, -mref);
+    float p1 = PRE ? S[blk][2 * w + 1] : __builtin_fmaf(S[blk][2 * w + 1], c, -mref);
+    pe[u][0] = __builtin_amdgcn_exp2f(p0); pe[u][1] = __builtin_amdgcn_exp2f(p1);
+  };
+  auto exp_finish = [&](int u) {
+    const int blk = u >> 3, w = u & 7;
+    l0 += pe[u][0];
+    l1 += pe[u][1];
+    P[blk][w] = pack2bf(pe[u][0], pe[u][1]);
+  };
   auto pfrag = [&](int blk, int s) {
     const u32x4_t v = {P[blk][4 * s], P[blk][4 * s + 1], P[blk][4 * s + 2], P[blk][4 * s + 3]};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
       float mx = 0.f;
       if (ABL != 9) {
 #pragma unroll
-        for (int u = 0; u < SC::PRE; ++u) exp_unit(Sc, u);
+        for (int u = 0; u < SC::PRE; ++u) { if (SPLIT) exp_only(Sc, u); else exp_unit(Sc, u); }
       }
       __builtin_amdgcn_sched_barrier(0);
       fa_static_for<SC::NS>([&](auto J) {
@@ -442,8 +461,20 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
         }
         constexpr int u0 = (j == 0) ? SC::PRE : SC::unit_end[j == 0 ? 0 : j - 1], u1 = SC::unit_end[j];
         if constexpr (ABL != 9) {
+          if constexpr (SPLIT) {   // exponentials of this slot's units first, then the consumers of the previous slot's
+            constexpr int f0 = (j == 0) ? 0 : ((j == 1) ? SC::PRE : SC::unit_end[j - 2]);
 #pragma unroll
-          for (int u = u0; u < u1; ++u) exp_unit(Sc, u);
+            for (int u = u0; u < u1; ++u) exp_only(Sc, u);
+#pragma unroll
+            for (int u = f0; u < u0; ++u) exp_finish(u);
+            if constexpr (j + 1 == SC::NS) {
+#pragma unroll
+              for (int u = u0; u < 16; ++u) exp_finish(u);
+            }
+          } else {
+#pragma unroll
+            for (int u = u0; u < u1; ++u) exp_unit(Sc, u);
+          }
         }
         if constexpr (j >= SC::MAX0 && ABL != 9 && ABL != 10) {   // row max of S(t+1), a share per slot
           constexpr int PER = 16 / (SC::NS - SC::MAX0), r0 = (j - SC::MAX0) * PER;
