@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("rowsum_partial", C.c_void_p),
         ("ln_xcopy", C.c_void_p), ("ln_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
+        ("rowsum_slabs", C.c_int32),
     ]
 
 
@@ -57,6 +58,8 @@ def _declare(L):
     L.countr_init.argtypes = [i32]
     L.countr_version.argtypes = []
     L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
+    L.countr_gemm_rowsum_slabs.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
+    L.countr_gemm_tiles.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
     L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.countr_reduce_table.argtypes = [vp, i32, i32, vp]
     for name, sig in _SIGS.items():

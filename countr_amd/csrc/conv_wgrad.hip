@@ -1,0 +1,299 @@
+// Lean weight gradient of a 3x3 convolution (NHWC, pad 1) for gfx950: dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci], the
+// (COL, IM2COL) split-K launches of countr_gemm() whose shapes qualify (bf16, Cout % 128 == 0, Cin % 128 == 0, pixels % 64 == 0).
+// Autograd's convolution_backward weight/bias outputs for models_mae_cross.py:85-100 (density head) and :47-67 (exemplar CNN).
+//
+// Both operands are K-major here -- the contraction index is the PIXEL, the slow dimension of both NHWC maps -- so a k-tile is 64
+// pixels x 128 channels of each map:
+//   * staged by MUBUF LDS-DMA (buffer_load_dwordx4 ... lds) exactly as it lies in memory, 256-byte pixel rows, 16-byte chunk c of pixel
+//     row k stored at slot c ^ ((k & 3) << 2); the padding taps of the im2col operand are lanes whose offset is pushed outside the
+//     descriptor (the DMA writes zeros), decided by ONE comparison pair per (lane, pass) from incrementally updated pixel coordinates
+//     (the generic kernel's im2col loader spends ~16 VALU instructions and a 64-bit address per 1-KiB piece: 1303 issue cycles per
+//     k-tile against 512 matrix cycles, profiles/r2_gemm_kernel_timeline.txt);
+//   * read back with ds_read_b64_tr_b16: a 16-lane group transposes a [4 pixels][16 channels] block, two reads = one 32x32x16 MFMA
+//     operand (8 consecutive pixels of one channel per lane).  With the XOR above the 32 lanes of a half-wave touch 32 distinct 8-byte
+//     bank pairs: conflict-free.
+// Workgroup = 4 WNB compute waves (64x64 sub-tiles, 2x2 MFMA tiles) + 4 loader waves, 3-stage ring, tile 128 (Cout) x 128 WNB (Cin
+// of one tap); grid = tiles x splitk, an XCD owning one or two k-ranges.  Output: raw fp32 partial[z][Cout][9 Cin] (countr_reduce_table
+// / countr_splitk_reduce finish and permute to OIHW).
+// Fused bias gradient (rowsum_partial): sum_p dy[p][co] = the same dy fragments times a matrix of ones.  One extra MFMA per k-step
+// would cost a wave 25 %, so the k-tiles of a (z, 32-row block) are dealt round-robin to the NC = tilesN * WNB waves that hold that
+// block's fragments anyway (+1.4 % each); every one writes its own slab: rowsum_partial[z * NC + i][Cout]
+// (countr_gemm_rowsum_slabs() tells the caller how many slabs a launch writes).
+#include "common.cuh"
+#include "../../include/countr_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef __attribute__((address_space(3))) const char* lds_cptr_t;
+
+struct CwgArgs {
+  const char* dy;      // [P, Cout] bf16 (NHWC output gradient)
+  const char* x;       // [P, Cin] bf16 (NHWC input map)
+  float* part;         // [Z][Cout][9 Cin]
+  float* rowsum;       // [Z * NC][Cout] or null
+  int Cout, Cin, H, Wd;
+  int N;               // 9 Cin
+  int tiles, tilesN;   // tiles = (Cout / 128) * tilesN
+  int nkt, per, Z;     // k-tiles (P / 64), k-tiles per z, slabs
+};
+
+__device__ __forceinline__ uint32_t lds_u32(const char* p) { return (uint32_t)(uintptr_t)(lds_cptr_t)p; }
+
+template <int OFF> __device__ __forceinline__ s16x4_t ds_tr(uint32_t a) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+
+struct Frag { s16x4_t lo, hi; };   // k = 8 lh + [0, 4), + [4, 8)
+__device__ __forceinline__ bf16x8_t frag_bits(const Frag& f) {
+  return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// wait until at most PENDING LDS instructions are outstanding; the set's fragments are threaded through so their MFMAs stay behind it
+template <int PENDING> __device__ __forceinline__ void frag_wait(Frag (&f)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi)
+               : "n"(PENDING));
+}
+
+template <int WNB>
+__global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel(const CwgArgs g) {
+  constexpr int STAGES = 3, NCW = 4 * WNB, NLW = 4, SUBN = 2 * WNB;
+  constexpr int A_BYTES = 64 * 256, STAGE_BYTES = A_BYTES * (1 + WNB);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= NCW;
+  const int cw = loader ? wv - NCW : wv;
+  // joint (z, tile) order, one contiguous range per XCD (workgroup b runs on XCD b % 8)
+  int z, lt;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xc = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int v = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + j;
+    z = v / g.tiles; lt = v - z * g.tiles;
+  }
+  const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
+  const int m0 = tile_m * 128, n0 = tile_n * (128 * WNB);
+  const int tap = n0 / g.Cin, ci0 = n0 - tap * g.Cin;
+  const int dyt = tap / 3 - 1, dxt = tap - (tap / 3) * 3 - 1;
+  const int kt0 = min(z * g.per, g.nkt), kt1 = min(kt0 + g.per, g.nkt);
+  const int ntiles = kt1 - kt0;
+
+  // ---- staging (loader waves).  Piece (pass i, wave w) = pixel rows [16 i + 4 w, +4) of a 128-channel operand tile; lane -> (row, slot)
+  const int krow = lane >> 4, c8 = (lane & 15) ^ (krow << 2);
+  const uint32_t voffA = (uint32_t)(((cw * 4 + krow) * g.Cout + c8 * 8) * 2);
+  const uint32_t voffB = (uint32_t)(((cw * 4 + krow) * g.Cin + c8 * 8) * 2);
+  const int64_t cshift = (int64_t)(g.Wd + 1) * g.Cin * 2;     // descriptor base (Wd + 1) pixels in front of the map: every tap shift >= 0
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g.dy + ((int64_t)kt0 * 64 * g.Cout + m0) * 2), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g.x + ((int64_t)kt0 * 64 * g.Cin + ci0) * 2 - cshift), 0, 0x7ffffff0, 0x00020000);
+  const uint32_t tapoff = (uint32_t)(cshift + (int64_t)(dyt * g.Wd + dxt) * g.Cin * 2);
+  const uint32_t passA = (uint32_t)g.Cout * 32u, passB = (uint32_t)g.Cin * 32u;       // 16 pixel rows further, bytes
+  const uint32_t tileA = (uint32_t)g.Cout * 128u, tileB = (uint32_t)g.Cin * 128u;     // 64 pixel rows further
+  int px[4], py[4];   // pixel coordinates of this lane's row in pass i of the NEXT tile to be issued
+  if (loader) {
+    const int p = kt0 * 64 + cw * 4 + krow;
+    int xx = p % g.Wd, yy = (p / g.Wd) % g.H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      px[i] = xx; py[i] = yy;
+      xx += 16;
+      while (xx >= g.Wd) { xx -= g.Wd; yy = (yy + 1 == g.H) ? 0 : yy + 1; }
+    }
+  }
+  auto issue = [&](int t, int slot_) {   // called with t = 0, 1, 2, ... in order (the coordinates advance by one tile per call)
+    char* dst = smem + slot_ * STAGE_BYTES + cw * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * 4096), 16, voffA, t * tileA + i * passA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = (unsigned)(py[i] + dyt) < (unsigned)g.H && (unsigned)(px[i] + dxt) < (unsigned)g.Wd;
+      const uint32_t vo = ok ? voffB : 0x80000000u;   // (a named variable: hipcc 7.2 drops the kernel stub for a conditional written as the argument)
+#pragma unroll
+      for (int j = 0; j < WNB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + A_BYTES + j * A_BYTES + i * 4096), 16, vo,
+                                                 tapoff + t * tileB + i * passB + j * 256, 0, 0);
+      px[i] += 64;
+      while (px[i] >= g.Wd) { px[i] -= g.Wd; py[i] = (py[i] + 1 == g.H) ? 0 : py[i] + 1; }
+    }
+  };
+  if (loader) {
+#pragma unroll
+    for (int s_ = 0; s_ < STAGES - 1; ++s_)
+      if (s_ < ntiles) issue(s_, s_);
+  }
+
+  // ---- fragment addresses (compute waves)
+  const int wm = cw / SUBN, wn = cw % SUBN;
+  const int l15 = lane & 15, q16 = (lane >> 4) & 1, lh = lane >> 5, rr = l15 >> 2, bb = l15 & 3;
+  uint32_t offA[2], offB[2];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int ca = wm * 8 + t2 * 4 + q16 * 2 + (bb >> 1), cb = (wn & 1) * 8 + t2 * 4 + q16 * 2 + (bb >> 1);
+    offA[t2] = (uint32_t)((lh * 8 + rr) * 256 + ((ca ^ (rr << 2)) << 4) + (bb & 1) * 8);
+    offB[t2] = (uint32_t)(A_BYTES + (wn >> 1) * A_BYTES + (lh * 8 + rr) * 256 + ((cb ^ (rr << 2)) << 4) + (bb & 1) * 8);
+  }
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  // bias-gradient turn: contributor i = (tile_n * SUBN + wn) >> 1 of the NC that hold rows [32 tmr, +32) of this 64-row block
+  const int rid = tile_n * SUBN + wn, tmr = rid & 1, ridx = rid >> 1, NC = (g.tilesN * SUBN) >> 1;
+  const bool want_rs = g.rowsum != nullptr;
+  f32x16_t accb;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+
+  Frag fr[4][4];   // [set = k-step][a0, a1, b0, b1]
+  uint32_t a0, a1, b0, b1;
+  auto addr = [&](uint32_t sbase) { a0 = sbase + offA[0]; a1 = sbase + offA[1]; b0 = sbase + offB[0]; b1 = sbase + offB[1]; };
+#define CWG_RD(SET, Q, KK, A) { fr[SET][Q].lo = ds_tr<(KK) * 4096>(A); fr[SET][Q].hi = ds_tr<(KK) * 4096 + 1024>(A); }
+#define CWG_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(fr[SET][TM]), frag_bits(fr[SET][2 + TN]), acc[TM][TN], 0, 0, 0)
+#define CWG_SB __builtin_amdgcn_sched_barrier(0)
+#define CWG_BIAS(SET) if (mine) { accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(tmr ? fr[SET][1] : fr[SET][0]), ones, accb, 0, 0, 0); CWG_SB; }
+  // MFMAs of set U with the reads of set R = k-step KK of the stage at a0 / a1 / b0 / b1 between them
+#define CWG_STEP_RD(U, R, KK) CWG_MM(U, 0, 0); CWG_SB; CWG_RD(R, 0, KK, a0); CWG_SB; CWG_MM(U, 0, 1); CWG_SB; CWG_RD(R, 2, KK, b0); CWG_SB; \
+                              CWG_MM(U, 1, 0); CWG_SB; CWG_RD(R, 1, KK, a1); CWG_SB; CWG_MM(U, 1, 1); CWG_SB; CWG_RD(R, 3, KK, b1); CWG_SB; CWG_BIAS(U)
+#define CWG_STEP(U) CWG_MM(U, 0, 0); CWG_MM(U, 0, 1); CWG_MM(U, 1, 0); CWG_MM(U, 1, 1); CWG_SB; CWG_BIAS(U)
+#define CWG_RD4(SET, KK) CWG_RD(SET, 0, KK, a0); CWG_RD(SET, 1, KK, a1); CWG_RD(SET, 2, KK, b0); CWG_RD(SET, 3, KK, b1)
+
+  if (loader) {
+    // keep STAGES-1 tiles in flight; tile t has landed when at most (STAGES-2) tiles' worth of loads are outstanding
+    constexpr int PER = 4 + 4 * WNB;
+    int islot = STAGES - 1;
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + STAGES - 1 < ntiles) issue(t + STAGES - 1, islot);
+      islot = (islot + 1 == STAGES) ? 0 : islot + 1;
+    }
+    __builtin_amdgcn_s_barrier();   // the compute waves' last in-loop barrier
+    return;
+  }
+
+  // compute waves: one fragment set per k-step; the reads of k-step s+2 go between the MFMAs of k-step s; at the tile boundary k-step 2
+  // runs bare, every read of the tile has landed, barrier (the loaders may refill the slot, the next tile is visible), and k-step 3's
+  // MFMAs carry the reads of the next tile's k-steps 0 and 1.  Same body for every tile: the last one's look-ahead reads fetch stale
+  // ring bytes nobody uses (linear.hip has the history of this loop).
+  int slot = 0, tmod = 0;
+  __builtin_amdgcn_s_barrier();
+  addr(lds_u32(smem));
+  CWG_RD4(0, 0);
+  CWG_RD4(1, 1);
+  CWG_SB;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool mine = want_rs && tmod == ridx;
+    tmod = (tmod + 1 == NC) ? 0 : tmod + 1;
+    frag_wait<8>(fr[0]); CWG_STEP_RD(0, 2, 2);
+    frag_wait<8>(fr[1]); CWG_STEP_RD(1, 3, 3);
+    frag_wait<8>(fr[2]); CWG_STEP(2);
+    frag_wait<0>(fr[3]);
+    slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+    __builtin_amdgcn_s_barrier();
+    addr(lds_u32(smem) + slot * STAGE_BYTES);
+    CWG_MM(3, 0, 0); CWG_SB; CWG_RD(0, 0, 0, a0); CWG_RD(0, 2, 0, b0); CWG_SB;
+    CWG_MM(3, 0, 1); CWG_SB; CWG_RD(0, 1, 0, a1); CWG_RD(0, 3, 0, b1); CWG_SB;
+    CWG_MM(3, 1, 0); CWG_SB; CWG_RD(1, 0, 1, a0); CWG_RD(1, 2, 1, b0); CWG_SB;
+    CWG_MM(3, 1, 1); CWG_SB; CWG_RD(1, 1, 1, a1); CWG_RD(1, 3, 1, b1); CWG_SB;
+    CWG_BIAS(3)
+  }
+  frag_wait<0>(fr[0]); frag_wait<0>(fr[1]);   // the stale look-ahead reads must be back before their registers are reused
+
+  // ---- raw fp32 partial sums: accumulator register e of lane (l31, lh) = row (e & 3) + 8 (e >> 2) + 4 lh, column l31 of its 32x32 tile
+  const int l31 = lane & 31;
+  float* out = g.part + (int64_t)z * g.Cout * g.N + (int64_t)(m0 + wm * 64 + 4 * lh) * g.N + n0 + wn * 64 + l31;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        out[(int64_t)(tm * 32 + (e & 3) + 8 * (e >> 2)) * g.N + tn * 32] = acc[tm][tn][e];
+  if (want_rs && l31 == 0) {
+    float* rs = g.rowsum + (int64_t)(z * NC + ridx) * g.Cout + m0 + wm * 64 + tmr * 32 + 4 * lh;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rs[(e & 3) + 8 * (e >> 2)] = accb[e];
+  }
+}
+
+template <int WNB>
+int launch_cwg(const CwgArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * 64 * 256 * (1 + WNB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg_kernel<WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((cwg_kernel<WNB>), dim3(a.tiles * a.Z), dim3(256 * WNB + 256), lds, s, a);
+  COUNTR_LAUNCH_CHECK("countr_gemm(lean conv wgrad)");
+}
+
+// form: 0 = does not qualify, 1 = 128x128 tiles, 2 = 128x256 tiles
+int cwg_form(const countr_gemm_args* a) {
+  { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 0; }
+  { const char* e = getenv("COUNTR_LEAN_WGRAD"); if (e && atoi(e) == 0) return 0; }
+  if (!a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->bias || a->resid || a->C2 || a->act != COUNTR_ACT_NONE) return 0;
+  if (a->ln_xcopy || a->ln_stats_out || a->ln_stats || a->ln_colsum) return 0;
+  if ((a->M % 128) || (a->Cin % 128) || a->N != 9 * a->Cin || (a->K % 64) || a->K < 64 || a->H < 2 || a->W < 2) return 0;
+  if (a->lda != a->M || a->ldc != a->N) return 0;
+  if ((((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->partial) & 15)) return 0;
+  if (a->rowsum_partial && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1) * (a->N / 128)) return 0;   // caller sized the legacy layout
+  if ((int64_t)(a->K + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->K * a->M * 2 >= (int64_t)0x7f000000ll) return 0;
+  // 128 x 256 tiles (a whole tap of a 256-channel map per workgroup: 48 KB staged per 32 MFMAs instead of 32 KB per 16) when the map
+  // has the channels for it -- 192x192: 316 vs 391 us with the slab count that fills the chip in either form
+  // (countr_gemm_wgrad_tiles() is what a caller divides 256 by), profiles/r3_conv_wgrad_microbench.txt
+  int form = (a->Cin % 256) == 0 ? 2 : 1;
+  { const char* e = getenv("COUNTR_LEAN_WGRAD_FORM"); if (e) form = atoi(e); }
+  if (form == 2 && (a->Cin % 256)) form = 1;
+  return form == 2 ? 2 : 1;
+}
+
+}  // namespace
+
+// Slabs of rowsum_partial a (COL, IM2COL) bf16 split-K launch writes ([slabs][M]): splitk on the generic kernel, splitk x NC here.
+int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a) {
+  countr_gemm_args b = *a;
+  b.rowsum_slabs = (a->splitk > 1 ? a->splitk : 1) * (a->N / 128);
+  if (!b.partial) b.partial = reinterpret_cast<float*>(16);   // (a sizing call may come before the workspace exists)
+  const int form = cwg_form(&b);
+  const int sk = a->splitk > 1 ? a->splitk : 1;
+  if (!form) return sk;
+  return sk * (a->N / 128);     // NC = tilesN * SUBN / 2 = (N / (128 WNB)) * WNB
+}
+
+// Output tiles (workgroups per split-K slab) of a (COL, IM2COL) bf16 launch: what the caller divides the CU count by to pick splitk.
+int countr_lean_wgrad_tiles(const countr_gemm_args* a) {
+  countr_gemm_args b = *a;
+  b.rowsum_partial = nullptr;
+  if (!b.partial) b.partial = reinterpret_cast<float*>(16);
+  const int form = cwg_form(&b);
+  if (!form) return ((a->M + 127) / 128) * ((a->N + 127) / 128);
+  return (a->M / 128) * (a->N / (128 * form));
+}
+
+// Returns 1 when the launch does not qualify (gemm_kernel then runs it), otherwise the launch status.
+int countr_lean_wgrad(const countr_gemm_args* a, hipStream_t s) {
+  const int form = cwg_form(a);
+  if (!form) return 1;
+  CwgArgs g;
+  g.dy = (const char*)a->A; g.x = (const char*)a->B; g.part = a->partial; g.rowsum = a->rowsum_partial;
+  g.Cout = a->M; g.Cin = a->Cin; g.H = a->H; g.Wd = a->W; g.N = a->N;
+  g.tilesN = a->N / (128 * form); g.tiles = (a->M / 128) * g.tilesN;
+  g.nkt = a->K / 64; g.Z = a->splitk > 1 ? a->splitk : 1;
+  g.per = (g.nkt + g.Z - 1) / g.Z;
+  return form == 2 ? launch_cwg<2>(g, s) : launch_cwg<1>(g, s);
+}

@@ -505,10 +505,28 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
   // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed; speed only).  Give every XCD one contiguous range
   // of the (tile_m, tile_n) space so the tiles sharing an A row-panel / B panel sit behind the same L2 instead of being
   // re-fetched over the fabric by all 8 XCDs (fc2 4608x768x3072: ~208 MB -> ~66 MB per launch).  Bijective for any count.
-  int lt;
+  // With a z dimension (split-K slabs, batched GEMMs) the dispatch order is x fastest, then z: the XCD of a workgroup is
+  // (blockIdx.x + gridDim.x * blockIdx.z) % 8, and the remap runs over the joint (z, tile) space -- an XCD then holds ~1/8 of the
+  // (z, tile) pairs in z-major order, i.e. the tiles of ONE or two k-ranges (one or two batches) instead of a few tiles of every one:
+  // the operand panels of a k-range are fetched by one L2, not by all eight.
+  int lt, zz;
   {
-    const int nt_ = gridDim.x, q = nt_ >> 3, r = nt_ & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+#ifndef COUNTR_ZMAP
+#define COUNTR_ZMAP 1
+#endif
+    const int nx = gridDim.x;
+#if COUNTR_ZMAP
+    const int lin = blockIdx.x + nx * blockIdx.z, nt_ = nx * gridDim.z;
+#else
+    const int lin = blockIdx.x, nt_ = nx;
+#endif
+    const int q = nt_ >> 3, r = nt_ & 7, x = lin & 7, j = lin >> 3;
+    const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+#if COUNTR_ZMAP
+    zz = v / nx; lt = v - zz * nx;
+#else
+    zz = blockIdx.z; lt = v;
+#endif
   }
   const int tile_m = lt / tilesN, tile_n = lt - tile_m * tilesN;
   const int m0 = tile_m * BMt, n0 = tile_n * BNt;
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
   // batch / split-K decode
   int kstart = 0, kend = g.K;
   int64_t offA = 0, offB = 0, offC = 0;
-  const int z = blockIdx.z;
+  const int z = zz;
   const bool split = g.partial != nullptr;  // raw fp32 partial sums (split-K, also with splitk == 1)
   if (split) {
     const int nsplit = g.splitk > 1 ? g.splitk : 1;
@@ -894,7 +912,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
 #pragma unroll
       for (int tm = 0; tm < TMW; ++tm) {
         const int m = m0 + mrow(tm);
-        if (m < g.M) g.rowsum_partial[(int64_t)blockIdx.z * g.M + m] = accb[tm][0];
+        if (m < g.M) g.rowsum_partial[(int64_t)z * g.M + m] = accb[tm][0];
       }
     }
   } else {
@@ -1238,7 +1256,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 }
 
 // Batched deferred reductions (one launch for many (partial slabs -> gradient) sums): table row e = {partial, out,
-// nslabs | accumulate << 32 | wide << 33, slab stride, count, N, taps, first block}, followed by the int32 map block -> entry.
+// nslabs | accumulate << 32 | wide << 33 | vec4 << 34, slab stride, count, N, taps, first block}, followed by the int32 map block -> entry.
 __global__ void reduce_table_kernel(const long long* __restrict__ tab, int n) {
   // block -> entry map (int32 [total_blocks]) behind the n rows: one load instead of a scan over the first-block column, which
   // was a chain of up to n dependent scalar loads in every block (~10 us of the launch at n = 40)
@@ -1263,6 +1281,39 @@ __global__ void reduce_table_kernel(const long long* __restrict__ tab, int n) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += red[k][c];
       out[col] = accumulate ? out[col] + tot : tot;
+    }
+    return;
+  }
+  if ((t[2] >> 34) & 1) {   // count, stride, both pointers multiples of 4 floats: 16-byte loads, four slabs in flight per thread
+    const long long i = (((long long)blockIdx.x - t[7]) * blockDim.x + threadIdx.x) * 4;
+    if (i >= count) return;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    const float* __restrict__ p = partial + i;
+    int z = 0;
+#define COUNTR_ACC4(a, v) { const float4 _v = (v); a.x += _v.x; a.y += _v.y; a.z += _v.z; a.w += _v.w; }
+    for (; z + 4 <= nslabs; z += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (long long)z * stride);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (long long)(z + 1) * stride);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (long long)(z + 2) * stride);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (long long)(z + 3) * stride);
+      COUNTR_ACC4(a0, v0) COUNTR_ACC4(a1, v1) COUNTR_ACC4(a2, v2) COUNTR_ACC4(a3, v3)
+    }
+    for (; z < nslabs; ++z) COUNTR_ACC4(a0, *reinterpret_cast<const float4*>(p + (long long)z * stride))
+#undef COUNTR_ACC4
+    // same association as the scalar path: (s0 + s1) + (s2 + s3)
+    float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    if (taps > 0) {  // [co][tap][ci] -> [co][ci][tap]; Cin % 4 == 0: the four elements share (co, tap), ci consecutive
+      const int cin = N / taps;
+      const long long co = i / N;
+      const int rr = (int)(i - co * N);
+      const int tap = rr / cin, ci = rr - tap * cin;
+      float* o = out + co * N + (long long)ci * taps + tap;
+      if (accumulate) { o[0] += r.x; o[taps] += r.y; o[2 * taps] += r.z; o[3 * taps] += r.w; }
+      else { o[0] = r.x; o[taps] = r.y; o[2 * taps] = r.z; o[3 * taps] = r.w; }
+    } else {
+      float4* o = reinterpret_cast<float4*>(out + i);
+      if (accumulate) { const float4 q = *o; r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+      *o = r;
     }
     return;
   }
@@ -1299,6 +1350,22 @@ extern "C" int countr_reduce_table(const long long* table, int n, int total_bloc
 
 int countr_lean_linear(const countr_gemm_args* a, hipStream_t s);   // linear.hip: 1 = does not qualify
 int countr_lean_conv(const countr_gemm_args* a, hipStream_t s);
+int countr_lean_wgrad(const countr_gemm_args* a, hipStream_t s);      // conv_wgrad.hip
+int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a);
+
+int countr_lean_wgrad_tiles(const countr_gemm_args* a);
+
+extern "C" int countr_gemm_tiles(const countr_gemm_args* a, int dtype, int modeA, int modeB) {
+  if (!a) return 0;
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_IM2COL) return countr_lean_wgrad_tiles(a);
+  return ((a->M + 127) / 128) * ((a->N + 127) / 128);
+}
+
+extern "C" int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, int modeA, int modeB) {
+  if (!a) return 0;
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_IM2COL) return countr_lean_wgrad_rowsum_slabs(a);
+  return a->splitk > 1 ? a->splitk : 1;
+}
 
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
@@ -1321,6 +1388,13 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_IM2ROW && modeB == COUNTR_OP_ROW) {
     const int rc = countr_lean_conv(a, s);     // 3x3 convolution forward / dgrad on the big maps: same kernel, im2row LDS-DMA addressing
     if (rc != 1) return rc;
+  }
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_IM2COL) {
+    const int rc = countr_lean_wgrad(a, s);    // 3x3 convolution weight (+ bias) gradient: both maps staged K-major, transposing reads
+    if (rc != 1) return rc;
+  }
+  if (a->rowsum_partial && a->rowsum_slabs > 0 && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1)) {
+    countr_set_error("countr_gemm: rowsum_slabs does not match countr_gemm_rowsum_slabs() for this launch"); return -1;
   }
   if (a->ln_xcopy || a->ln_stats_out || a->ln_stats || a->ln_colsum) {
     countr_set_error("countr_gemm: the LayerNorm-folding fields need the lean bf16 (ROW, ROW) kernel (N % 128 == 0, K % 64 == 0, aligned operands, bias)");

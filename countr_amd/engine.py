@@ -208,6 +208,7 @@ class Engine:
         self._ws = {}
         self._need = {}
         self._sizing = False
+        self.reduce_vec4 = os.environ.get("COUNTR_REDUCE_VEC4", "1") != "0"   # 16-byte loads in the deferred-sum kernel
         self._defer = {}             # id(ops) -> (ops, [pending reduction entries]): flushed into countr_reduce_table launches
         self._tables = []
         self.defer_reduce = os.environ.get("COUNTR_DEFER_REDUCE", "1") != "0"
@@ -457,8 +458,10 @@ class Engine:
         rows, blk = [], 0
         for (pp, op, nslabs, stride, count, N, taps, acc, _owner) in entries:
             wide = int(nslabs > 16 and taps == 0)          # LayerNorm block partials: 16 columns x 16 slab groups per block
-            rows.append([pp, op, nslabs | (acc << 32) | (wide << 33), stride, count, N, taps, blk])
-            blk += -(-count // (16 if wide else 256))
+            cin = N // taps if taps else 4
+            vec = int(not wide and self.reduce_vec4 and count % 4 == 0 and stride % 4 == 0 and pp % 16 == 0 and op % 16 == 0 and cin % 4 == 0)
+            rows.append([pp, op, nslabs | (acc << 32) | (wide << 33) | (vec << 34), stride, count, N, taps, blk])
+            blk += -(-count // (16 if wide else (1024 if vec else 256)))
         tab = torch.tensor(rows, dtype=torch.int64).reshape(-1)
         owner = torch.repeat_interleave(torch.arange(len(rows), dtype=torch.int32),
                                         torch.tensor([(rows[i + 1][7] if i + 1 < len(rows) else blk) - rows[i][7] for i in range(len(rows))]))
@@ -655,7 +658,9 @@ class Engine:
     def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout, bias_name=None):
         bk = 64 if self.code == BF16 else 32
         Kp = Bn * H * W
-        tiles = -(-Cout // 128) * -(-(9 * Cin) // 128)
+        q = GemmArgs()
+        q.M, q.N, q.K, q.H, q.W, q.Cin, q.lda, q.ldc, q.alpha, q.nbatch, q.nb1 = Cout, 9 * Cin, Kp, H, W, Cin, Cout, 9 * Cin, 1.0, 1, 1
+        tiles = int(self.L.countr_gemm_tiles(C.byref(q), self.code, OP_COL, OP_IM2COL))   # 128x128, or 128x256 on the lean kernel
         sk = self._splitk(tiles, -(-Kp // bk))
         defer = self.defer_reduce
         part = self._shared(("skp." + self._role(wname)) if defer else "splitk", sk * Cout * 9 * Cin)
@@ -663,13 +668,25 @@ class Engine:
         rs = self._shared(("rsp." + self._role(wname)) if defer else "rowsum", 64 * 4096) if fuse_bias else None
         if defer:
             self._claim(part.data_ptr())
-        self._gemm(ops, self.code, OP_COL, OP_IM2COL, A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout,
-                   ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W, Cin=Cin, splitk=sk,
-                   rowsum_partial=(rs.data_ptr() if fuse_bias else None))
+        kw = dict(A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout, ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W,
+                  Cin=Cin, splitk=sk)
+        rslabs = sk
+        if fuse_bias:
+            # the lean weight-gradient kernel (conv_wgrad.hip) deals the bias-gradient work over more waves: more, thinner slabs.  Only
+            # the table-driven finisher sums an arbitrary slab count; countr_splitk_reduce keeps the [splitk][M] layout (rowsum_slabs 0)
+            q = GemmArgs()
+            for k_, v_ in kw.items():
+                setattr(q, k_, v_)
+            q.alpha, q.nbatch, q.nb1 = 1.0, 1, 1
+            n = int(self.L.countr_gemm_rowsum_slabs(C.byref(q), self.code, OP_COL, OP_IM2COL)) if defer else sk
+            if n * Cout <= 64 * 4096:
+                rslabs = n
+            kw.update(rowsum_partial=rs.data_ptr(), rowsum_slabs=(rslabs if defer else 0))
+        self._gemm(ops, self.code, OP_COL, OP_IM2COL, **kw)
         if defer:
             self._reduce_later(ops, part.data_ptr(), part.data_ptr(), self._gp(wname), sk, Cout * 9 * Cin, Cout * 9 * Cin, N=9 * Cin, taps=9)
             if fuse_bias:
-                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), sk, Cout, Cout)
+                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), rslabs, Cout, Cout)
         else:
             self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, Cout, 9 * Cin, 9, self._acc,
                      rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)

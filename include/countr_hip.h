@@ -90,9 +90,21 @@ typedef struct countr_gemm_args {
   const float* ln_colsum;
   int32_t ln_nblk;
   float ln_eps;
+  int32_t rowsum_slabs; /* slabs the caller sized rowsum_partial for: 0 = max(splitk,1) (the layout above); otherwise it must be
+                           countr_gemm_rowsum_slabs() of this launch (the lean convolution weight gradient deals the bias-gradient
+                           work over more waves and writes [rowsum_slabs][M]; the sum over ALL slabs is the bias gradient)        */
 } countr_gemm_args;
 
 int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream);
+
+/* Number of [M]-slabs the launch described by a (rowsum_slabs ignored) writes to rowsum_partial.  Depends on the shape and on the
+ * environment switches only; callers size rowsum_partial with it and pass the value back in a->rowsum_slabs. */
+int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, int modeA, int modeB);
+
+/* Output tiles (= workgroups per split-K slab) the launch described by a would run with (pointers, splitk and partial may still be
+ * unset): a split-K caller picks splitk ~ CUs / tiles.  128 x 128 tiles everywhere except the lean convolution weight gradient on
+ * maps with Cin % 256 == 0 (128 x 256). */
+int countr_gemm_tiles(const countr_gemm_args* a, int dtype, int modeA, int modeB);
 
 /* out[M,N] (+)= sum_z partial[z][M][N]; optional permute for conv weights:
  * perm_taps > 0: partial is [Cout][taps][Cin] (OHWI) and out is torch OIHW [Cout][Cin][taps].

@@ -551,6 +551,65 @@ def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin,
     assert (outs[0].double() - outs[1].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout,sk,with_bias", [(2, 96, 96, 256, 256, 7, True), (4, 48, 48, 256, 256, 5, True), (8, 24, 24, 512, 256, 3, True),
+                                                          (3, 32, 48, 128, 128, 2, False), (1, 64, 64, 256, 384, 40, True), (2, 8, 16, 128, 128, 1, True)])
+def test_lean_conv_wgrad_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H, W, Cin, Cout, sk, with_bias):
+    """Weight (+ bias) gradient of the 3x3 convolutions as the (COL, IM2COL) split-K GEMM: the lean kernel of conv_wgrad.hip (both maps
+    staged K-major by LDS-DMA, transposing fragment reads, bias-gradient MFMAs dealt over the waves) against torch fp64 autograd on the
+    same bf16 maps and against gemm_kernel (COUNTR_LEAN_WGRAD=0).  Rows narrower than a 64-pixel k-tile (W = 48, 24, 16), k-tiles
+    spanning image boundaries, 128x128 and 128x256 tiles, more slabs than k-tiles per slab allow (sk = 40 of 64 k-tiles: empty slabs
+    must come out as zeros), a single slab, Cin = 128 / 512."""
+    dy = _mk((Bsz, H, W, Cout), torch.bfloat16, 71)
+    x = _mk((Bsz, H, W, Cin), torch.bfloat16, 72)
+    P, N = Bsz * H * W, 9 * Cin
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wz = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    bz = torch.zeros(Cout, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = torch.nn.functional.conv2d(xd, wz, bz, padding=1)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    ref_w = wz.grad.permute(0, 2, 3, 1).reshape(Cout, N)          # OHWI
+    ref_b = bz.grad
+    res = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("COUNTR_LEAN_WGRAD", lean)
+        monkeypatch.setenv("COUNTR_LEAN_WGRAD_FORM", form)
+        a = _lib.GemmArgs()
+        a.A, a.B = dy.data_ptr(), x.data_ptr()
+        a.lda, a.ldc = Cout, N
+        a.M, a.N, a.K = Cout, N, P
+        a.H, a.W, a.Cin = H, W, Cin
+        a.alpha = 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = sk
+        slabs = hip.countr_gemm_rowsum_slabs(C.byref(a), 1, 1, 3)
+        assert slabs == (sk * (N // 128) if lean == "1" else sk)
+        part = torch.full((sk, Cout, N), float("nan"), device="cuda", dtype=torch.float32)
+        rs = torch.full((slabs, Cout), float("nan"), device="cuda", dtype=torch.float32)
+        a.partial = part.data_ptr()
+        if with_bias:
+            a.rowsum_partial, a.rowsum_slabs = rs.data_ptr(), slabs
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 1, 3, _stream()), "wgrad")
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        gw = part.double().sum(0)
+        assert (gw - ref_w).abs().max().item() <= 2e-5 * ref_w.abs().max().item() + 1e-9, lean
+        if with_bias:
+            assert torch.isfinite(rs).all()
+            gb = rs.double().sum(0)
+            assert (gb - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item() + 1e-9, lean
+        res.append(gw)
+    assert (res[0] - res[1]).abs().max().item() <= 4e-5 * ref_w.abs().max().item() + 1e-9
+    # legacy layout request (rowsum_slabs = 0) must stay on the generic kernel and fill exactly [splitk][M]
+    if with_bias:
+        monkeypatch.setenv("COUNTR_LEAN_WGRAD", "1")
+        rs = torch.full((sk + 1, Cout), float("nan"), device="cuda", dtype=torch.float32)
+        a.rowsum_partial, a.rowsum_slabs = rs.data_ptr(), 0
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 1, 3, _stream()), "wgrad")
+        torch.cuda.synchronize()
+        assert torch.isfinite(rs[:sk]).all() and torch.isnan(rs[sk]).all()
+        assert (rs[:sk].double().sum(0) - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item() + 1e-9
+
+
 @pytest.mark.parametrize("M", [4608, 576, 14976])
 @pytest.mark.parametrize("act", [0, 1])
 def test_lean_linear_layernorm_folding(hip, M, act):
