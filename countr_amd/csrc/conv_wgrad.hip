@@ -25,6 +25,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef CWG_ABL
+#define CWG_ABL 0   // timing experiments (tools/exp_cwg.sh, results are WRONG): 1 = no MFMA, 2 = no fragment reads, 3 = no DMA after the first tiles
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -111,6 +115,9 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
   }
   auto issue = [&](int t, int slot_) {   // called with t = 0, 1, 2, ... in order (the coordinates advance by one tile per call)
     char* dst = smem + slot_ * STAGE_BYTES + cw * 1024;
+#if CWG_ABL == 3
+    if (t >= 2) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * 4096), 16, voffA, t * tileA + i * passA, 0, 0);
@@ -158,10 +165,24 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 
   Frag fr[4][4];   // [set = k-step][a0, a1, b0, b1]
+#if CWG_ABL == 2
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { fr[a][b].lo = s16x4_t{(short)lane, 1, 2, 3}; fr[a][b].hi = s16x4_t{3, 2, 1, (short)lane}; }
+#endif
   uint32_t a0, a1, b0, b1;
   auto addr = [&](uint32_t sbase) { a0 = sbase + offA[0]; a1 = sbase + offA[1]; b0 = sbase + offB[0]; b1 = sbase + offB[1]; };
+#if CWG_ABL == 2
+#define CWG_RD(SET, Q, KK, A) { fr[SET][Q].lo[0] += (short)(A); }
+#else
 #define CWG_RD(SET, Q, KK, A) { fr[SET][Q].lo = ds_tr<(KK) * 4096>(A); fr[SET][Q].hi = ds_tr<(KK) * 4096 + 1024>(A); }
+#endif
+#if CWG_ABL == 1
+#define CWG_MM(SET, TM, TN) acc[TM][TN][(SET) * 4 + (TM) * 2 + (TN)] += (float)fr[SET][TM].lo[0] * (float)fr[SET][2 + TN].hi[1]
+#else
 #define CWG_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(fr[SET][TM]), frag_bits(fr[SET][2 + TN]), acc[TM][TN], 0, 0, 0)
+#endif
 #define CWG_SB __builtin_amdgcn_sched_barrier(0)
 #define CWG_BIAS(SET) if (mine) { accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(tmr ? fr[SET][1] : fr[SET][0]), ones, accb, 0, 0, 0); CWG_SB; }
   // MFMAs of set U with the reads of set R = k-step KK of the stage at a0 / a1 / b0 / b1 between them
