@@ -358,12 +358,13 @@ __global__ void cast_permute_kernel(const float* __restrict__ src, T* __restrict
 }
 
 // all conv-weight shadows of the model in ONE launch: blockIdx.y = convolution, both permuted forms per element
+constexpr int CS_MAX = 32;
 struct ConvShadowTable {
   int n;
-  const float* src[8];
-  void* wf[8];
-  void* wd[8];
-  int co[8], ci[8], taps[8];
+  const float* src[CS_MAX];
+  void* wf[CS_MAX];     // may be null: only the transposed form is wanted (a Linear weight, taps = 1: wd = W^T)
+  void* wd[CS_MAX];
+  int co[CS_MAX], ci[CS_MAX], taps[CS_MAX];
 };
 // One block = a 32 (co) x 8 (ci) tile of one convolution with all its taps: the torch OIHW source [co][ci][tap] is read as 32 runs of
 // 8 x taps contiguous floats, the OHWI form [co][tap][ci] is written with ci fastest and the dgrad form [ci][taps-1-tap][co] -- the
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_shadows_kernel(const ConvShadowTable
       {  // OHWI [Co][tap][Ci]: lanes walk ci
         const int cl = i % CS_CI, rt = i / CS_CI, tap = rt % taps, r = rt / taps;
         const int co = co0 + r, ci = ci0 + cl;
-        if (co < Co && ci < Ci) stf<T>(wf + ((int64_t)co * taps + tap) * Ci + ci, tile[r][cl * taps + tap]);
+        if (wf && co < Co && ci < Ci) stf<T>(wf + ((int64_t)co * taps + tap) * Ci + ci, tile[r][cl * taps + tap]);
       }
       {  // dgrad form [Ci][taps-1-tap][Co]: lanes walk co
         const int rl = i & 31, ct = i >> 5, tap = ct % taps, cl = ct / taps;
@@ -628,12 +629,12 @@ extern "C" int countr_cast_permute(const float* src, void* dst, int64_t n, int m
 
 extern "C" int countr_conv_shadows(int n, const float* const* src, void* const* wf, void* const* wd, const int* co, const int* ci,
                                    const int* taps, int dtype, void* stream) {
-  if (n < 1 || n > 8 || !src || !wf || !wd || !co || !ci || !taps) { countr_set_error("countr_conv_shadows: 1..8 convolutions"); return -1; }
+  if (n < 1 || n > CS_MAX || !src || !wf || !wd || !co || !ci || !taps) { countr_set_error("countr_conv_shadows: 1..32 weights"); return -1; }
   ConvShadowTable t;
   t.n = n;
   int64_t big = 0;
   for (int i = 0; i < n; ++i) {
-    if (!src[i] || !wf[i] || !wd[i]) { countr_set_error("countr_conv_shadows: null"); return -1; }
+    if (!src[i] || !wd[i]) { countr_set_error("countr_conv_shadows: null"); return -1; }
     t.src[i] = src[i]; t.wf[i] = wf[i]; t.wd[i] = wd[i]; t.co[i] = co[i]; t.ci[i] = ci[i]; t.taps[i] = taps[i];
     const int64_t m = (int64_t)co[i] * ci[i] * taps[i];
     if (m > big) big = m;

@@ -542,7 +542,12 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   if (a->M < 1 || (a->N % 128) || (a->K % 64) || a->K < 128) return 1;      // any M: rows beyond it stage zeros and are not stored
   if ((a->lda % 8) || (a->ldb % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2) & 15)) return 1;
   if ((int64_t)128 * a->lda * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll || (int64_t)256 * a->ldb * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll) return 1;   // per-tile descriptor offsets
-  if (!a->bias || ((uintptr_t)a->bias & 15)) return 1;
+  if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
+  static float* zero_bias = nullptr;     // no bias (input gradients): the epilogue adds a vector of zeros
+  if (!a->bias) {
+    if (a->N > 8192) return 1;
+    if (!zero_bias && (hipMalloc(&zero_bias, 8192 * sizeof(float)) != hipSuccess || hipMemset(zero_bias, 0, 8192 * sizeof(float)) != hipSuccess)) { zero_bias = nullptr; return 1; }
+  }
   int epi;
   if (a->out_bf16) {
     if (a->resid || (a->ldc % 8)) return 1;
@@ -565,7 +570,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   if (ln_in && (epi == EPI_RES || !a->ln_stats || !a->ln_colsum || (((uintptr_t)a->ln_stats | (uintptr_t)a->ln_colsum) & 15) || a->ln_nblk != a->K / 64)) return 1;
   LinArgs g;
   g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps;
-  g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias; g.resid = a->resid;
+  g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias ? a->bias : zero_bias; g.resid = a->resid;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
   g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.H = g.Wd = g.Cin = 0;
   const long tiles = (long)((a->M + 127) / 128) * g.tilesN;

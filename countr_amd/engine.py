@@ -189,6 +189,17 @@ class Engine:
             numel = math.prod(lay.shapes[n])
             self.Wf[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
             self.Wd[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
+        # transposed bf16 shadows of the trainable decoder Linear weights: dx = dy W becomes a (ROW, ROW) GEMM on W^T and runs the lean
+        # kernel (linear.hip) like the forward -- ~4 us per launch against the (ROW, COL) form on gemm_kernel; written by the shadow
+        # launch that follows AdamW.  Frozen-encoder engine only: for the MAE step (every Linear trains) the transposes would cost
+        # what they save.  COUNTR_DGRAD_T=0 restores the (ROW, COL) launches
+        self.WtT = {}
+        if (precision == "bf16" and self.FROZEN_ENCODER and os.environ.get("COUNTR_DGRAD_T", "1") != "0"
+                and os.environ.get("COUNTR_LEAN", "1") != "0"):
+            for n in lay.train_names:
+                shp = lay.shapes[n]
+                if n.startswith("decoder_blocks.") and n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
+                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
         self.plans = {}
         self.hyper = torch.zeros(8, device=self.device, dtype=torch.float32)   # {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
         self.step_count = 0
@@ -529,6 +540,11 @@ class Engine:
     def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None):
         """dx[M,K] = dy[M,N] W[N,K] (+ resid)."""
         out_bf16 = (dx.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        if wname in self.WtT:      # W^T [K][N]: (ROW, ROW), the lean kernel
+            self._gemm(ops, self.code, OP_ROW, OP_ROW, A=dy.data_ptr(), B=self.WtT[wname].data_ptr(), C=dx.data_ptr(),
+                       resid=(resid.data_ptr() if resid is not None else None), lda=N, ldb=N, ldc=K, ldres=K, M=M, N=K, K=N,
+                       out_bf16=int(out_bf16))
+            return
         self._gemm(ops, self.code, OP_ROW, OP_COL, A=dy.data_ptr(), B=self._wp(wname), C=dx.data_ptr(),
                    resid=(resid.data_ptr() if resid is not None else None), lda=N, ldb=K, ldc=K, ldres=K, M=M, N=K, K=N,
                    out_bf16=int(out_bf16))
@@ -1085,15 +1101,17 @@ class Engine:
 
     def _refresh_conv_shadows(self):
         """OHWI + dgrad-form shadows of every conv weight, one launch (the table of pointers is built once)."""
-        if not self.conv_names:
+        if not self.conv_names and not self.WtT:
             return
         if getattr(self, "_shadow_tab", None) is None:
-            n = len(self.conv_names)
-            shp = [self.layout.shapes[c] for c in self.conv_names]
-            self._shadow_tab = (n, (C.c_void_p * n)(*[self._pp(c) for c in self.conv_names]),
-                                (C.c_void_p * n)(*[self.Wf[c].data_ptr() for c in self.conv_names]),
-                                (C.c_void_p * n)(*[self.Wd[c].data_ptr() for c in self.conv_names]),
+            lin = list(self.WtT)                      # Linear weights [N][K]: taps = 1, only the transposed form
+            names = self.conv_names + lin
+            n = len(names)
+            shp = [self.layout.shapes[c] for c in names]
+            self._shadow_tab = (n, (C.c_void_p * n)(*[self._pp(c) for c in names]),
+                                (C.c_void_p * n)(*([self.Wf[c].data_ptr() for c in self.conv_names] + [None] * len(lin))),
+                                (C.c_void_p * n)(*([self.Wd[c].data_ptr() for c in self.conv_names] + [self.WtT[c].data_ptr() for c in lin])),
                                 (C.c_int * n)(*[s_[0] for s_ in shp]), (C.c_int * n)(*[s_[1] for s_ in shp]),
-                                (C.c_int * n)(*[s_[2] * s_[3] for s_ in shp]))
+                                (C.c_int * n)(*[(s_[2] * s_[3] if len(s_) == 4 else 1) for s_ in shp]))
         n, src, wf, wd, co, ci, taps = self._shadow_tab
         _lib.check(self.L.countr_conv_shadows(n, src, wf, wd, co, ci, taps, self.code, self._stream()), "conv_shadows")

@@ -224,8 +224,10 @@ int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co
 /* -------- loss + optimizer (FSC_finetune_cross.py:290-303, :235) */
 /* sums (fp32 [1+2B]) = {loss, pred counts[B], gt counts[B]}; dpred optional (= dloss/dpred * grad_scale);
  * workspace: fp32 [countr_masked_mse_workspace_floats(B)].  Deterministic two-stage reduction. */
-/* both permuted shadows (OHWI and dgrad form, see countr_cast_permute modes 1 and 2) of up to 8 conv weights in ONE launch;
- * the arrays are HOST arrays of n device pointers / shapes (the optimiser step refreshes all conv shadows at once). */
+/* both permuted shadows (OHWI and dgrad form, see countr_cast_permute modes 1 and 2) of up to 32 weights in ONE launch;
+ * the arrays are HOST arrays of n device pointers / shapes (the optimiser step refreshes all shadows at once).  wf[i] may be NULL
+ * (only wd is written); with taps = 1 a weight is an nn.Linear matrix [co][ci] and wd its TRANSPOSE [ci][co] -- the K-contiguous
+ * B operand that turns the input gradient dx = dy W (autograd of models_crossvit.py:62-65, 84-92, 115-127) into a (ROW, ROW) GEMM. */
 int countr_conv_shadows(int n, const float* const* src, void* const* wf, void* const* wd, const int* co, const int* ci,
                         const int* taps, int dtype, void* stream);
 int countr_masked_mse_workspace_floats(int B);

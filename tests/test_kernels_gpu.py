@@ -451,3 +451,26 @@ def test_conv_shadows_permutations(hip, dt):
         ref_f = w.reshape(co, ci, 9).permute(0, 2, 1).to(dt)
         ref_d = w.reshape(co, ci, 9).flip(2).permute(1, 2, 0).to(dt)
         assert torch.equal(f, ref_f) and torch.equal(d, ref_d)
+
+
+def test_conv_shadows_transposes_linear_weights(hip):
+    """taps = 1, wf = NULL: the entry is an nn.Linear weight [N][K] and wd receives its bf16 transpose [K][N] (the B operand of the
+    (ROW, ROW) input-gradient GEMM); 20 weights in one launch beside a 3x3 convolution (the table holds up to 32)."""
+    import ctypes as C
+    lin = [(512, 512), (1536, 512), (2048, 512), (512, 2048), (40, 24)] * 4
+    ws = [torch.randn(n, k, device="cuda") for n, k in lin]
+    wt = [torch.full((k, n), float("nan"), device="cuda", dtype=torch.bfloat16) for n, k in lin]
+    cw = torch.randn(64, 32, 3, 3, device="cuda")
+    cf = torch.full((64, 9, 32), float("nan"), device="cuda", dtype=torch.bfloat16)
+    cd = torch.full((32, 9, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+    n = len(lin) + 1
+    vp, ip = C.c_void_p * n, C.c_int * n
+    _lib.check(hip.countr_conv_shadows(n, vp(*([w.data_ptr() for w in ws] + [cw.data_ptr()])), vp(*([None] * len(lin) + [cf.data_ptr()])),
+                                       vp(*([w.data_ptr() for w in wt] + [cd.data_ptr()])), ip(*([s[0] for s in lin] + [64])),
+                                       ip(*([s[1] for s in lin] + [32])), ip(*([1] * len(lin) + [9])), 1,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv_shadows")
+    torch.cuda.synchronize()
+    for w, t in zip(ws, wt):
+        assert torch.equal(t, w.t().contiguous().to(torch.bfloat16))
+    assert torch.equal(cf, cw.reshape(64, 32, 9).permute(0, 2, 1).to(torch.bfloat16))
+    assert torch.equal(cd, cw.reshape(64, 32, 9).flip(2).permute(1, 2, 0).to(torch.bfloat16))
