@@ -98,6 +98,7 @@ _SIGS = {
     "countr_colsum_nparts": [],
     "countr_colsum": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "countr_cast_permute": [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "countr_copy_multi": [_i, _vp, _vp, _vp, _vp],
     "countr_gather_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "countr_mae_indices": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "countr_patch_mse_workspace_floats": [_i, _i, _i, _i],

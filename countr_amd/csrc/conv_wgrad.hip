@@ -183,7 +183,11 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
 #else
 #define CWG_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(fr[SET][TM]), frag_bits(fr[SET][2 + TN]), acc[TM][TN], 0, 0, 0)
 #endif
+#ifdef CWG_NOSB
+#define CWG_SB
+#else
 #define CWG_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 #define CWG_BIAS(SET) if (mine) { accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(tmr ? fr[SET][1] : fr[SET][0]), ones, accb, 0, 0, 0); CWG_SB; }
   // MFMAs of set U with the reads of set R = k-step KK of the stage at a0 / a1 / b0 / b1 between them
 #define CWG_STEP_RD(U, R, KK) CWG_MM(U, 0, 0); CWG_SB; CWG_RD(R, 0, KK, a0); CWG_SB; CWG_MM(U, 0, 1); CWG_SB; CWG_RD(R, 2, KK, b0); CWG_SB; \

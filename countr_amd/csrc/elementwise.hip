@@ -606,6 +606,44 @@ extern "C" int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, 
   COUNTR_LAUNCH_CHECK("countr_upsample2x_bwd");
 }
 
+// Several device-to-device copies in ONE launch (the per-step staging of a batch: images, exemplar crops, ground-truth map, loss mask --
+// four ~5-us copy launches in front of every step otherwise).  16-byte aligned pointers and sizes.
+struct CopyTable { int n; const uint4* src[8]; uint4* dst[8]; long long n16[8]; int first[8]; };
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyTable t) {
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) e += (i < t.n && (int)blockIdx.x >= t.first[i]) ? 1 : 0;
+  const int nb = (e + 1 < t.n ? t.first[e + 1] : (int)gridDim.x) - t.first[e];
+  const uint4* __restrict__ s = t.src[e];
+  uint4* __restrict__ d = t.dst[e];
+  const long long n = t.n16[e], stride = (long long)nb * 256 * 4;
+  for (long long i = ((long long)blockIdx.x - t.first[e]) * 256 + threadIdx.x; i < n; i += stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) v[u] = s[i + (long long)u * nb * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) d[i + (long long)u * nb * 256] = v[u];
+  }
+}
+
+extern "C" int countr_copy_multi(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream) {
+  if (n < 1 || n > 8 || !src || !dst || !bytes) { countr_set_error("countr_copy_multi: 1..8 copies"); return -1; }
+  CopyTable t;
+  t.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || !dst[i] || bytes[i] <= 0 || (bytes[i] & 15) || (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15)) {
+      countr_set_error("countr_copy_multi: null, empty or not 16-byte aligned"); return -1;
+    }
+    t.src[i] = reinterpret_cast<const uint4*>(src[i]); t.dst[i] = reinterpret_cast<uint4*>(dst[i]); t.n16[i] = bytes[i] / 16;
+    t.first[i] = blocks;
+    blocks += nblocks(t.n16[i], 1024, 2048);     // 4 x 16 bytes per thread and trip
+  }
+  for (int i = n; i < 8; ++i) { t.src[i] = nullptr; t.dst[i] = nullptr; t.n16[i] = 0; t.first[i] = blocks; }
+  hipLaunchKernelGGL(copy_multi_kernel, dim3(blocks), dim3(256), 0, STREAM(stream), t);
+  COUNTR_LAUNCH_CHECK("countr_copy_multi");
+}
+
 extern "C" int countr_gelu_bwd(const void* dh, const void* pre, void* dpre, int64_t n, int dtype, void* stream) {
   if (!dh || !pre || !dpre || (n & 7)) { countr_set_error("countr_gelu_bwd: n must be a multiple of 8"); return -1; }
   const int nb = nblocks(n / 8, 256, 8192);

@@ -6,6 +6,7 @@ per-step host syncs; bf16 needs no GradScaler.  With use_graph=True each phase i
 hipGraph and replayed (torch.cuda.CUDAGraph is only the capture/replay handle; every node is one of our kernels).
 """
 
+import ctypes as C
 import os
 
 import torch
@@ -424,13 +425,35 @@ class FinetuneStep(_GraphStep):
         imgs, boxes, gt, mask = self._to_device(src)
         with torch.cuda.stream(self.stream):
             p = self.eng.plan(self.B, S, True)
-            self.eng._load_inputs(p, imgs, boxes, S)
-            self.gt.copy_(gt, non_blocking=True)
-            self.mask.copy_(mask, non_blocking=True)
+            if not self._load_fused(p, imgs, boxes, gt, mask, S):
+                self.eng._load_inputs(p, imgs, boxes, S)
+                self.gt.copy_(gt, non_blocking=True)
+                self.mask.copy_(mask, non_blocking=True)
             self._staging_consumed()
         for t in src:                          # their memory must not be recycled before our copies have run
             if t.is_cuda:
                 t.record_stream(self.stream)
+
+    def _load_fused(self, p, imgs, boxes, gt, mask, S):
+        """All staging copies of a batch in ONE launch (countr_copy_multi) when every source is a dense fp32 device tensor of the
+        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices)."""
+        if os.environ.get("COUNTR_FUSED_LOAD", "1") == "0":
+            return False
+        pairs = [(imgs, p.buf["img"]), (gt, self.gt), (mask, self.mask)]
+        if S > 0:
+            if boxes.dim() != 5 or boxes.shape[1] != S:
+                return False
+            pairs.append((boxes, p.buf["boxes"]))
+        for src, dst in pairs:
+            if (not torch.is_tensor(src) or not src.is_cuda or src.dtype != dst.dtype or not src.is_contiguous() or src.numel() != dst.numel()
+                    or (src.numel() * src.element_size()) % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16):
+                return False
+        n = len(pairs)
+        vp = C.c_void_p * n
+        _lib.check(self.eng.L.countr_copy_multi(n, vp(*[s_.data_ptr() for s_, _ in pairs]), vp(*[d.data_ptr() for _, d in pairs]),
+                                                (C.c_int64 * n)(*[s_.numel() * s_.element_size() for s_, _ in pairs]), self.eng._stream()),
+                   "copy_multi")
+        return True
 
     def step(self, S, lr=None):
         """One (micro-)step on the inputs last given to load(): with accum_iter == k, every k-th call reduces the accumulated

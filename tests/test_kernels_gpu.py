@@ -474,3 +474,20 @@ def test_conv_shadows_transposes_linear_weights(hip):
         assert torch.equal(t, w.t().contiguous().to(torch.bfloat16))
     assert torch.equal(cf, cw.reshape(64, 32, 9).permute(0, 2, 1).to(torch.bfloat16))
     assert torch.equal(cd, cw.reshape(64, 32, 9).flip(2).permute(1, 2, 0).to(torch.bfloat16))
+
+
+def test_copy_multi(hip):
+    """countr_copy_multi: several dense device-to-device copies in one launch (the staging of a batch), sizes from 16 bytes to 14 MB,
+    nothing outside the destinations touched."""
+    import ctypes as C
+    sizes = [4, 3 * 384 * 384 * 8, 8 * 384 * 384, 384 * 384, 8 * 3 * 3 * 64 * 64, 1028, 12]
+    src = [torch.randn(n, device="cuda") for n in sizes]
+    dst = [torch.full((n + 8,), float("nan"), device="cuda") for n in sizes]
+    n = len(sizes)
+    vp = C.c_void_p * n
+    _lib.check(hip.countr_copy_multi(n, vp(*[s.data_ptr() for s in src]), vp(*[d.data_ptr() + 16 for d in dst]),
+                                     (C.c_int64 * n)(*[4 * k for k in sizes]), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "copy_multi")
+    torch.cuda.synchronize()
+    for s, d in zip(src, dst):
+        assert torch.equal(d[4:4 + s.numel()], s) and torch.isnan(d[:4]).all() and torch.isnan(d[4 + s.numel():]).all()
+    assert hip.countr_copy_multi(1, vp(*[src[0].data_ptr()] * n), vp(*[dst[0].data_ptr() + 4] * n), (C.c_int64 * n)(*[16] * n), None) != 0   # misaligned
