@@ -397,6 +397,22 @@ def main():
     dts = sorted(b[0] for b in blocks)
     dt, sums = dts[len(dts) // 2], blocks[-1][1]
     exposed = step.sync.exposed_us() if step.sync.profile else None
+    comm_mode, host_issued = None, None
+    if step.sync.comm:
+        comm_mode = "captured" if getattr(step.sync, "capturable", False) else "host-issued"
+        if comm_mode == "captured":
+            # the headline blocks replayed ONE graph per step with the RCCL all-reduces as nodes of it: nothing to bracket.  The exposed
+            # communication is measured on a short extra run in the per-phase-graph mode (host-issued collectives between the phases),
+            # whose step time is reported beside it
+            step.sync.capturable = False
+            for k in range(3):
+                one(k, 3)
+            torch.cuda.synchronize()
+            step.sync.exposed_us()          # (drops the warm-up steps' event pairs)
+            dt_h, _ = timed([3] * min(args.steps, 20))
+            exposed = step.sync.exposed_us()
+            host_issued = 1e3 * dt_h / min(args.steps, 20)
+            step.sync.capturable = True
     # the reference draws shot_num uniformly from 0..3 per iteration (FSC_finetune_cross.py:276-284): same loop on that mix,
     # reported beside the headline (shot_num = 3) number
     from countr_amd.parallel import shared_shot_num
@@ -445,10 +461,14 @@ def main():
             model.train()
         else:
             line["multi_gpu"] = {"ranks_seen": ranks_seen, "bucket_bytes": step.sync.bucket_bytes(),
+                                 "collectives": ("RCCL all-reduces captured as nodes of the step's hipGraph (side stream between the backward phases): "
+                                                 "one graph replay per step" if comm_mode == "captured" else
+                                                 "issued by the host between per-phase graph replays"),
+                                 "ms_per_step_host_issued": host_issued,
                                  "exposed_comm_us": exposed,
                                  "note": "buckets in backward-completion order (head | decoder blocks | exemplar CNN | shot_token); every bucket but "
                                          "the last is all-reduced on a side stream under the next backward phase; exposed_comm_us = median time the "
-                                         "step stream waited in GradSync.finish()"}
+                                         "step stream waited in GradSync.finish() (measured in the host-issued mode: event pairs cannot be captured)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

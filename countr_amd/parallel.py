@@ -41,6 +41,11 @@ class GradSync:
         # then run the REAL RCCL path -- communicator set-up, side stream, ordering against the graph replays (tests/test_ddp_gpu.py)
         self.comm = self.world > 1 or (os.environ.get("COUNTR_FORCE_COMM", "0") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = None
+        # RCCL collectives can be CAPTURED into a hipGraph (stream capture records them as graph nodes; gloo's host-side collectives
+        # cannot): the trainer then replays a whole communicating step as one graph (COUNTR_GRAPH_COMM=0: one graph per phase with the
+        # collectives issued by the host in between, as in rounds 1-2)
+        self.capturable = bool(self.comm and flat_grad.is_cuda and dist.is_available() and dist.is_initialized()
+                               and dist.get_backend(group) == "nccl" and os.environ.get("COUNTR_GRAPH_COMM", "1") != "0")
         self._started = set()
         self.profile = False        # bench.py: event pair around the join of every finish() -> exposed_us()
         self._exposed = []
@@ -83,14 +88,15 @@ class GradSync:
             else:
                 runs.append([s, e])
         main = torch.cuda.current_stream(self.g.device) if self.g.is_cuda else None
-        if self.profile and main is not None:
+        prof = self.profile and main is not None and not torch.cuda.is_current_stream_capturing()   # (timing events cannot be captured)
+        if prof:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(main)
         for s, e in runs:
             dist.all_reduce(self.g[s:e], group=self.group)
         if self.stream is not None:
             main.wait_stream(self.stream)
-        if self.profile and main is not None:
+        if prof:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(main)
             self._exposed.append((e0, e1))

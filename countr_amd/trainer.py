@@ -318,6 +318,26 @@ class _GraphStep:
                     if k[1] is not None:
                         self._phase_c(k[1])
                 self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), ckey))
+            elif self.use_graph and self.sync.capturable:
+                # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
+                # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
+                ckey, cskip = None, ()
+                if last:
+                    touched = frozenset(self._touched)
+                    cskip = tuple(self._comm_skip(touched))
+                    skip, zero = self._adam_sets(touched)
+                    self._upload_hyper(skip)
+                    ckey = (tuple(skip), tuple(zero))
+
+                def whole(k, phases=phases, cskip=cskip):
+                    for i, (_name, fn, gkey) in enumerate(phases):
+                        fn(gkey)
+                        if k[1] is not None and i + 1 < len(phases):
+                            self.sync.start(i)
+                    if k[1] is not None:
+                        self.sync.finish(skip=cskip)
+                        self._phase_c(k[1])
+                self._run_phase("allc", whole, (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip))
             else:
                 for i, (name, fn, gkey) in enumerate(phases):
                     self._run_phase(name, fn, gkey)

@@ -50,6 +50,7 @@ def run_finetune(rank, world, per_rank, use_graph=True):
         step.load(*(torch.from_numpy(a).cuda() for a in (imgs[sl], boxes[sl], gt[sl], mask)), S)
         losses.append(step.step(S)[0].item())
     torch.cuda.synchronize()
+    m._graph_kinds = sorted({k[0] for k in step.graphs})
     return m, losses
 
 
@@ -84,6 +85,7 @@ def run_pretrain(rank, world, per_rank, use_graph=True):
         step.load(torch.from_numpy(imgs[sl]).cuda(), ids_shuffle=torch.from_numpy(ids[sl]).cuda())
         losses.append(step.step().item())
     torch.cuda.synchronize()
+    m._graph_kinds = sorted({k[0] for k in step.graphs})
     return m, losses
 
 
@@ -99,7 +101,8 @@ if __name__ == "__main__":
     else:
         m, losses = (run_finetune if what == "finetune" else run_pretrain)(rank, world, 2 if world > 1 else 4)
         keep = lambda k: True
-    torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters() if keep(k)}, "losses": losses},
+    torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters() if keep(k)}, "losses": losses,
+                "graph_kinds": getattr(m, "_graph_kinds", None)},
                os.path.join(outdir, "%s_rank%d.pt" % (what, rank)))
     dist.barrier()
     dist.destroy_process_group()

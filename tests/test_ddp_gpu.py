@@ -166,6 +166,13 @@ def test_rccl_path_with_one_rank(what, tmp_path):
     assert r0["losses"] == losses
     for k, p in single.named_parameters():
         assert torch.equal(p.detach().cpu(), r0["params"][k]), k
+    # over RCCL the collectives are CAPTURED: the communicating step is one graph ("allc"), not one graph per phase
+    assert r0["graph_kinds"] == ["allc"], r0["graph_kinds"]
+    # ... and with COUNTR_GRAPH_COMM=0 (host-issued collectives between per-phase graphs, what gloo always does) the result is the same
+    (r1,) = launch(what, tmp_path, nproc=1, backend="nccl", extra_env={"COUNTR_FORCE_COMM": "1", "COUNTR_GRAPH_COMM": "0"})
+    assert r1["losses"] == losses and "allc" not in r1["graph_kinds"] and len(r1["graph_kinds"]) >= 3
+    for k, p in single.named_parameters():
+        assert torch.equal(p.detach().cpu(), r1["params"][k]), k
 
 
 def test_bench_rccl_one_rank():
