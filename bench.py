@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b32", action="store_true", help="skip roofline_b32 (profiling runs: keeps the attention kernel's launches of the "
+                                                           "kernel-stats CSV at the one problem size of the step)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="finetune only: batches start in pinned HOST memory (the DataLoader's hand-over) -> the PCIe-inclusive rate "
                          "quoted in DESIGN.md; never the headline value (inputs are HBM-resident there)")
@@ -452,13 +454,14 @@ def main():
                                          "is 2.0 PF (1.92 GHz under load), and the GEMM family is bound by the LDS-DMA path (~42 B/clk per CU), DESIGN.md"}
         if world == 1:
             line["roofline_families"] = family_breakdown(model, step, B)
-            # BASELINE configs[4]: the same kernel at 32 windows (zero-shot inference plan), amortising the per-launch fixed cost
-            model.eval()
-            with torch.no_grad():
-                model(torch.rand(32, 3, 384, 384, device=dev), torch.zeros(32, 0, device=dev), 0)
-            r32 = attention_roofline(model, 32, shot=0, train=False)
-            line["roofline_b32"] = {k: r32[k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_launch", "us_per_launch_back_to_back")}
-            model.train()
+            if not args.no_b32:
+                # BASELINE configs[4]: the same kernel at 32 windows (zero-shot inference plan), amortising the per-launch fixed cost
+                model.eval()
+                with torch.no_grad():
+                    model(torch.rand(32, 3, 384, 384, device=dev), torch.zeros(32, 0, device=dev), 0)
+                r32 = attention_roofline(model, 32, shot=0, train=False)
+                line["roofline_b32"] = {k: r32[k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_launch", "us_per_launch_back_to_back")}
+                model.train()
         else:
             line["multi_gpu"] = {"ranks_seen": ranks_seen, "bucket_bytes": step.sync.bucket_bytes(),
                                  "collectives": ("RCCL all-reduces captured as nodes of the step's hipGraph (side stream between the backward phases): "
