@@ -79,6 +79,10 @@ template <int PENDING> __device__ __forceinline__ void frag_wait(bf16x8_t (&f)[4
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(PENDING));
 }
 
+template <int PENDING> __device__ __forceinline__ void frag_wait5(bf16x8_t (&f)[4], bf16x8_t& f2) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f2) : "n"(PENDING));
+}
+
 // packed form of common.cuh's gelu_fast (same operations on fp32 pairs: bit-identical results)
 __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
   const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -8.f, 8.f), __builtin_amdgcn_fmed3f(x[1], -8.f, 8.f)};
@@ -98,17 +102,24 @@ __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
 // for grids that still fill the chip with half as many tiles); NLD = loader waves (0: every wave stages and multiplies).
 // CONV: the A operand is the 3x3 im2row view of an NHWC map (implicit GEMM, forward and -- with dgrad-form weights -- dgrad of the
 // density-head / exemplar convolutions): only the LDS-DMA source addresses differ, the tile in LDS and everything behind it is the same.
-template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false>
-__global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 : (4 * WMB * WNB + NLD) / 4) : 2) void lin_kernel(const LinArgs g) {
+// TM = 32-row MFMA tiles per compute wave (2: 64x64 wave tiles; 3: 96x64 -- the 192 x 256 workgroup tile, 8 compute + 4 loader waves on
+// a TWO-stage ring of 56 KB: 1.5 x the work of a 256x128 / 128x256 tile per workgroup, for shapes whose 256x128 grid is a little over one
+// round of 256 workgroups -- qkv at B = 8: 324 workgroups = two rounds, 216 of these = one -- and 86 % of the staged bytes per MFMA).
+template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false, int TM = 2>
+__global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && TM == 2) ? 4 : (4 * WMB * WNB + NLD) / 4) : 2) void lin_kernel(const LinArgs g) {
   constexpr bool SPEC = NLD > 0;
-  constexpr bool TWO = SPEC && STAGES == 2;     // wave-specialised with a 2-stage ring: TWO workgroups per CU (64 KB, 128 VGPRs each)
+  constexpr bool T3 = TM == 3;
+  constexpr bool TWO = SPEC && STAGES == 2 && !T3;     // wave-specialised with a 2-stage ring: TWO workgroups per CU (64 KB, 128 VGPRs each)
+  static_assert(TM == 2 || TM == 3, "wave tile = 64x64 or 96x64");
+  static_assert(!T3 || (SPEC && STAGES == 2 && WMB == 1 && WNB == 2 && NLD == 4 && EPI != EPI_RES), "192x256 form: bf16 outputs, 2-stage ring");
   static_assert(SPEC ? (STAGES >= 2 && STAGES <= 5) : (STAGES == 2 && WMB == 1), "ring depth / plain form");
   static_assert(!TWO || (WMB == 1 && WNB == 1 && NLD == 4), "two-per-CU form");
-  static_assert(WMB * WNB <= 2 && (SPEC || WMB * WNB == 1), "tile = 128x128, 256x128 or 128x256");
-  constexpr int NCW = 4 * WMB * WNB;            // compute waves, (2 WMB) x (2 WNB) sub-tiles of 64x64
+  static_assert(WMB * WNB <= 2 && (SPEC || WMB * WNB == 1), "tile = 128x128, 256x128, 128x256 or 192x256");
+  constexpr int NCW = 4 * WMB * WNB;            // compute waves, (2 WMB) x (2 WNB) sub-tiles of (32 TM) x 64
   constexpr int NLW = SPEC ? NLD : 4;           // waves that stage tiles
   static_assert(NLW == 4, "four staging waves");
-  constexpr int BMt = 128 * WMB, BNt = 128 * WNB, SUBN = 2 * WNB;   // SUBN = 64-column sub-tiles per row of sub-tiles
+  constexpr int RW = 32 * TM;                   // rows of a compute wave's sub-tile
+  constexpr int BMt = 2 * RW * WMB, BNt = 128 * WNB, SUBN = 2 * WNB;   // SUBN = 64-column sub-tiles per row of sub-tiles
   constexpr int A_BYTES = BMt * 128, STAGE_BYTES = A_BYTES + BNt * 128;
   constexpr int PA = BMt / (8 * NLW), PB = BNt / (8 * NLW);   // 1-KiB pieces per operand per staging wave per k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
   if constexpr (RPRE) {
     {
       constexpr int u = 0;
-      const int mrow0 = m0 + ((sub0 + 4 * u) / SUBN) * 64 + half0 * 32 + rrow;
+      const int mrow0 = m0 + ((sub0 + 4 * u) / SUBN) * RW + half0 * 32 + rrow;
       if (g.res_mod > 0) {   // row modulo (pos-embed adds): one division, then steps of 4 rows with a conditional wrap
         int mr = mrow0 % g.res_mod;
 #pragma unroll
@@ -288,18 +299,19 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
   uint32_t xoff[4], woff[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    xoff[kk] = (uint32_t)((wm * 64 + l31) * 128 + (((kk * 2 + lh) ^ swx) << 4));
+    xoff[kk] = (uint32_t)((wm * RW + l31) * 128 + (((kk * 2 + lh) ^ swx) << 4));   // (RW / 2 is a multiple of 8: the swizzle term does not see wm)
     woff[kk] = (uint32_t)(A_BYTES + (wn * 64 + prow) * 128 + (((kk * 2 + lh) ^ sww) << 4));
   }
-  f32x16_t acc[2][2];
+  f32x16_t acc[TM][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  bf16x8_t fr[TWO ? 2 : 4][4];   // [set][x0, x1, w0, w1]; set = k-step (two-per-CU form: alternating)
+  bf16x8_t fr[(TWO || T3) ? 2 : 4][4];   // [set][x0, x1, w0, w1]; set = k-step (two-per-CU and 192-row forms: alternating)
+  bf16x8_t fr2[T3 ? 2 : 1];              // [set] x2: the third 32-row tile of the 96-row wave tile
   uint32_t sbase = lds_u32(smem);
   uint32_t xa, wa;
   auto addr = [&](auto KK) { constexpr int kk = decltype(KK)::value; xa = sbase + xoff[kk]; wa = sbase + woff[kk]; };
@@ -323,6 +335,19 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
                           LIN_MM(U, 1, 0); LIN_SB; LIN_RD(R, 1, 4096, xa); LIN_SB; LIN_MM(U, 1, 1); LIN_SB; LIN_RD(R, 3, 4096, wa); LIN_SB
 #define LIN_STEP(U) LIN_MM(U, 0, 0); LIN_MM(U, 0, 1); LIN_MM(U, 1, 0); LIN_MM(U, 1, 1); LIN_SB
 #define LIN_RD4(SET) LIN_RD(SET, 0, 0, xa); LIN_RD(SET, 1, 4096, xa); LIN_RD(SET, 2, 0, wa); LIN_RD(SET, 3, 4096, wa)
+  // 96-row wave tile: the third x fragment and its two MFMAs
+#if LIN_ABL == 2
+#define LIN_RDX2(SET) fr2[SET] = __builtin_bit_cast(bf16x8_t, u32x4_t{xa, 8192u, 9u, 1u})
+#else
+#define LIN_RDX2(SET) fr2[SET] = ds_read128<8192>(xa)
+#endif
+#if LIN_ABL == 1
+#define LIN_MM2(SET, TN) { const u32x4_t a_ = __builtin_bit_cast(u32x4_t, fr[SET][2 + TN]), b_ = __builtin_bit_cast(u32x4_t, fr2[SET]); \
+        acc[TM - 1][TN][0] += __uint_as_float(a_[0] ^ b_[0]); acc[TM - 1][TN][7] += __uint_as_float(a_[2] ^ b_[3]); }
+#else
+#define LIN_MM2(SET, TN) acc[TM - 1][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[SET][2 + TN], fr2[SET], acc[TM - 1][TN], 0, 0, 0)
+#endif
+#define LIN_STEP6(U) LIN_MM(U, 0, 0); LIN_MM(U, 0, 1); LIN_MM(U, 1, 0); LIN_MM(U, 1, 1); LIN_MM2(U, 0); LIN_MM2(U, 1); LIN_SB
 #ifdef LIN_STAMP   // s_memtime anatomy (tools/stamp_lin.py): loaders [1] load wait [2] barrier [3] DMA issue; compute waves [2] barrier
 #define LSTAMP(x) const uint64_t x = __builtin_readcyclecounter()
 #else
@@ -391,6 +416,22 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
           LIN_STEP(1);
         }
         frag_wait<0>(fr[0]);
+      } else if constexpr (T3) {
+        // 168-VGPR budget (12 waves), 96 accumulator registers: two fragment sets, reads one k-step ahead in a block; the SIMD's other
+        // compute wave covers the bubbles.  Two stages: the loaders refill the stage a tile has just left while the next is multiplied
+        addr(K0{}); LIN_RD4(0); LIN_RDX2(0); LIN_SB;
+        for (int t = 0; t < ntiles; ++t) {
+          addr(K1{}); LIN_RD4(1); LIN_RDX2(1); frag_wait5<5>(fr[0], fr2[0]); LIN_STEP6(0);
+          addr(K2{}); LIN_RD4(0); LIN_RDX2(0); frag_wait5<5>(fr[1], fr2[1]); LIN_STEP6(1);
+          addr(K3{}); LIN_RD4(1); LIN_RDX2(1); frag_wait5<5>(fr[0], fr2[0]); LIN_STEP6(0);
+          frag_wait5<0>(fr[1], fr2[1]);
+          slot ^= 1;
+          __builtin_amdgcn_s_barrier();
+          sbase = lds_u32(smem) + slot * STAGE_BYTES;
+          addr(K0{}); LIN_RD4(0); LIN_RDX2(0); LIN_SB;
+          LIN_STEP6(1);
+        }
+        frag_wait5<0>(fr[0], fr2[0]);
       } else {
       addr(K0{}); LIN_RD4(0);
       addr(K1{}); LIN_RD4(1);
@@ -445,17 +486,18 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
   // ---- epilogue.  Staging: compute wave w owns smem + w * REGION; row r of its sub-tile at r * OPITCH (SPEC: all 64 rows, plain: 32).
   constexpr int REGION = (SPEC ? 64 : 32) * OPITCH;
   // (launch_lin sizes the dynamic LDS as max(ring, NCW * REGION): the two-per-CU form's 64-KB ring is smaller than its staging)
-  auto stage_out = [&](int tm) {   // lane: row tm*32 + l31 (plain: l31), columns tn*32 + 16 lh + [0, 16)
-    char* dst = smem + wv * REGION + ((SPEC ? tm * 32 : 0) + l31) * OPITCH + lh * 64;
+  auto stage_out = [&](int tm, int rslot) {   // lane: row rslot*32 + l31 of the wave's region (plain: l31), columns tn*32 + 16 lh + [0, 16)
+    char* dst = smem + wv * REGION + ((SPEC ? rslot * 32 : 0) + l31) * OPITCH + lh * 64;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f4_t*>(dst + tn * 128 + q * 16) = f4_t{acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
   };
-  auto finish_half = [&](int sub, int half, int j0, auto USE_RPRE) {   // rows [32 half, +32) of sub-tile `sub`; j0 = index of its rpre[0]
+  // rows [32 half, +32) of sub-tile `sub`'s staging region = rows [32 tmrow, +32) of its RW-row wave tile; j0 = index of its rpre[0]
+  auto finish_half = [&](int sub, int half, int j0, auto USE_RPRE, int tmrow) {
     const char* src = smem + sub * REGION + ((SPEC ? half * 32 : 0) + rrow) * OPITCH + ccol * 4;
-    const int mrow = m0 + (sub / SUBN) * 64 + half * 32 + rrow;
+    const int mrow = m0 + (sub / SUBN) * RW + tmrow * 32 + rrow;
 #pragma unroll
     for (int j = 0; j < NIT_HALF; ++j) {
       const int m = mrow + RSTEP * j;
@@ -499,37 +541,45 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? (STAGES == 2 ? 4 
     }
   };
   if constexpr (SPEC) {
-    if (!loader) { stage_out(0); stage_out(1); }
+    if (!loader) { stage_out(0, 0); stage_out(1, 1); }
     __syncthreads();
-    if (!loader) finish_half(sub0, 0, 0, std::bool_constant<RPRE>{});
+    if (!loader) finish_half(sub0, 0, 0, std::bool_constant<RPRE>{}, 0);
     else if (cw < 4) {
-      finish_half(sub0, 1, 0, std::bool_constant<RPRE>{});
+      finish_half(sub0, 1, 0, std::bool_constant<RPRE>{}, 1);
 #pragma unroll
-      for (int u = 1; u < NUNITS; ++u) finish_half(sub0 + 4 * u, 1, 0, std::false_type{});
+      for (int u = 1; u < NUNITS; ++u) finish_half(sub0 + 4 * u, 1, 0, std::false_type{}, 1);
+    }
+    if constexpr (T3) {   // third 32-row tile of the 96-row wave tiles: a second pass through the same regions
+      __syncthreads();
+      if (!loader) stage_out(2, 0);
+      __syncthreads();
+      if (!loader) finish_half(sub0, 0, 0, std::false_type{}, 2);
     }
   } else {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
-      stage_out(tm);
+      stage_out(tm, tm);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      finish_half(sub0, tm, 0, std::false_type{});
+      finish_half(sub0, tm, 0, std::false_type{}, tm);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false>
+template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false, int TM = 2>
 int launch_lin(const LinArgs& a, hipStream_t s) {
-  constexpr int ring = STAGES * (128 * WMB + 128 * WNB) * 128, staging = NLD ? 4 * WMB * WNB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
-  constexpr int lds = (ring > staging ? ring : staging) + ((LN && EPI != EPI_RES) ? 128 * WMB * 8 : 0);   // + the consumer's row statistics
+  constexpr int BMt = 64 * TM * WMB;
+  constexpr int ring = STAGES * (BMt + 128 * WNB) * 128, staging = NLD ? 4 * WMB * WNB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
+  constexpr int lds = (ring > staging ? ring : staging) + ((LN && EPI != EPI_RES) ? BMt * 8 : 0);   // + the consumer's row statistics
+  static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN>), dim3(((a.M + 128 * WMB - 1) / (128 * WMB)) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), dim3(((a.M + BMt - 1) / BMt) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -592,6 +642,22 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   // waves -- the loaders are not waiting for data, their LDS-DMA instructions ISSUE at ~95 cycles each: 32 KB per k-tile at ~42 B/clk per
   // CU is what bounds this form, profiles/r3_linear_stamps.txt)
   if (tiles <= spec_max) LIN_LAUNCH(1, 4, 3)
+  // 192 x 256 tiles (96x64 wave tiles, TM = 3) where the 256x128 grid is a little over one round of workgroups and this one fits in one:
+  // qkv at B = 8 (M = 4608, N = 2304): 324 workgroups of 256x128 = two rounds, 216 of 192x256 = one round of 1.5 x the work
+  {
+    int t3 = 1;
+    { const char* e = getenv("COUNTR_LEAN_T3"); if (e) t3 = atoi(e); }
+    const long g256 = (long)((a->M + 255) / 256) * (a->N / 128), g192 = (long)((a->M + 191) / 192) * (a->N / 256);
+    if (t3 && epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && g192 <= 256) {
+      g.tilesN = a->N / 256;
+      if (ln_in) {
+        if (epi == EPI_BF16) return launch_lin<1, 4, EPI_BF16, 2, false, 2, true, 3>(g, s);
+        return launch_lin<1, 4, EPI_GELU, 2, false, 2, true, 3>(g, s);
+      }
+      if (epi == EPI_BF16) return launch_lin<1, 4, EPI_BF16, 2, false, 2, false, 3>(g, s);
+      return launch_lin<1, 4, EPI_GELU, 2, false, 2, false, 3>(g, s);
+    }
+  }
   // bigger grids.  Default (COUNTR_LEAN_BIG=1): 256x128 tiles, 8 compute + 4 loader waves, 144-KB ring -- 2/3 of the staged bytes per
   // MFMA; =2: 128x128 wave-specialised on a 2-stage ring, two workgroups per CU in 128 VGPRs; =0 (and M % 256 != 0): the plain form,
   // two workgroups per CU, every wave stages and multiplies.  Finetune step on one box: 5.03 / 4.99 / 5.01 ms for 0 / 1 / 2 (with the
@@ -633,6 +699,7 @@ int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
   // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128
   int form = (a->N % 256) == 0 ? 2 : 1;
   { const char* e = getenv("COUNTR_LEAN_CONV_FORM"); if (e) form = atoi(e); }
+  if (form == 3 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 2, true, 2, false, 3>(g, s); }   // 192 x 256 (experiment)
   if (form == 2 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 3, true, 2>(g, s); }
   return launch_lin<2, 4, EPI_BF16, 3, true>(g, s);
 }

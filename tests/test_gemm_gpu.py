@@ -410,7 +410,8 @@ def test_splitk_finish_matches_unsplit_conv(hip, obf):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 192), (4608, 512, 512), (1152, 768, 3072), (4608, 1536, 256), (4736, 1024, 128),
-                                   (2304, 3072, 768), (576, 768, 768), (1728, 512, 512), (2880, 3072, 768), (40, 128, 128)])
+                                   (2304, 3072, 768), (576, 768, 768), (1728, 512, 512), (2880, 3072, 768), (40, 128, 128),
+                                   (4608, 2304, 768), (4544, 2304, 128), (3520, 3072, 192)])   # (the last three: the 192x256 form, 96x64 wave tiles)
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "gelu_pre", "res", "resmod"])
 def test_lean_linear_matches_fp64_and_generic(hip, monkeypatch, M, N, K, epi):
     """csrc/linear.hip (full-tile nn.Linear forward: 32x32x16 MFMA, staged epilogue, sigmoid-polynomial GELU) through countr_gemm:
@@ -517,7 +518,8 @@ def test_lean_linear_in_place_residual(hip):
 
 @pytest.mark.parametrize("Bsz,H,W,Cin,Cout,use_bias", [(2, 96, 96, 256, 256, True), (8, 48, 48, 512, 256, True), (4, 48, 96, 256, 256, False),
                                                    (32, 24, 24, 64, 256, True), (2, 96, 96, 256, 512, False), (3, 100, 100, 64, 256, True)])
-def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin, Cout, use_bias):
+@pytest.mark.parametrize("form", ["", "3"])      # "3": the 192 x 256 tile (96x64 wave tiles, two-stage ring)
+def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H, W, Cin, Cout, use_bias):
     """The density-head / exemplar 3x3 convolutions on the big maps (forward, and dgrad through the dgrad-form weights) run the lean
     kernel of linear.hip with im2row LDS-DMA addressing (256x128 tiles, 8 compute + 4 loader waves): against torch conv2d in fp64 and
     against gemm_kernel (COUNTR_LEAN_CONV=0) on the same bf16 inputs -- zero padding at every image border, tiles that span image
@@ -531,6 +533,8 @@ def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin,
     ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double() if use_bias else None, padding=1)
     ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
     outs = []
+    if form:
+        monkeypatch.setenv("COUNTR_LEAN_CONV_FORM", form)
     for lean in ("1", "0"):
         monkeypatch.setenv("COUNTR_LEAN_CONV", lean)
         out = torch.full((M, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -610,9 +614,9 @@ def test_lean_conv_wgrad_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H
         assert (rs[:sk].double().sum(0) - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item() + 1e-9
 
 
-@pytest.mark.parametrize("M", [4608, 576, 14976])
+@pytest.mark.parametrize("M,N2", [(4608, 1536), (576, 1536), (14976, 1536), (4608, 2304), (4400, 2304)])   # N2 = 2304 at B = 8: the 192x256 form
 @pytest.mark.parametrize("act", [0, 1])
-def test_lean_linear_layernorm_folding(hip, M, act):
+def test_lean_linear_layernorm_folding(hip, M, N2, act):
     """LayerNorm folded into the Linear layers around it (frozen encoder): a producer GEMM (bias + fp32 residual) also emits the bf16
     copy of its output and the {sum, sum of squares} of every 64-column block of each output row; a consumer GEMM on that copy with
     gamma folded into its weights applies rstd (acc - mean colsum) + (b + W beta).  Reference: torch fp64
@@ -620,7 +624,7 @@ def test_lean_linear_layernorm_folding(hip, M, act):
     rounded RAW row instead of the rounded normalised row, so its rounding error relative to sigma grows by sqrt(1 + (mean / sigma)^2).
     Rows with mean ~ 0 (the transformer's case: per-token means of the residual stream are a fraction of sigma) must match the unfolded
     path's error; every 7th row here has |mean| = 12 sigma and is held to that factor (documented limit, COUNTR_LN_FOLD=0 is the way out)."""
-    D, N2 = 768, 1536
+    D = 768
     eps = 1e-6
     A0 = _mk((M, D), torch.bfloat16, 61)
     W0 = (_mk((D, D), torch.float32, 62) * 0.05).to(torch.bfloat16)
