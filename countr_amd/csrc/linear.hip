@@ -642,13 +642,15 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   // waves -- the loaders are not waiting for data, their LDS-DMA instructions ISSUE at ~95 cycles each: 32 KB per k-tile at ~42 B/clk per
   // CU is what bounds this form, profiles/r3_linear_stamps.txt)
   if (tiles <= spec_max) LIN_LAUNCH(1, 4, 3)
-  // 192 x 256 tiles (96x64 wave tiles, TM = 3) where the 256x128 grid is a little over one round of workgroups and this one fits in one:
-  // qkv at B = 8 (M = 4608, N = 2304): 324 workgroups of 256x128 = two rounds, 216 of 192x256 = one round of 1.5 x the work
+  // 192 x 256 tiles (96x64 wave tiles, TM = 3) where they need fewer tile-times than the 256x128 grid: qkv at B = 8 (M = 4608, N = 2304) is
+  // 324 workgroups of 256x128 = two rounds of 2 units, or 216 of 192x256 = one round of 3
   {
     int t3 = 1;
     { const char* e = getenv("COUNTR_LEAN_T3"); if (e) t3 = atoi(e); }
     const long g256 = (long)((a->M + 255) / 256) * (a->N / 128), g192 = (long)((a->M + 191) / 192) * (a->N / 256);
-    if (t3 && epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && g192 <= 256) {
+    // rounds x tile work (in 128x128 units: 2 vs 3) of the two grids on 256 CUs
+    const long span256 = ((g256 + 255) / 256) * 2, span192 = ((g192 + 255) / 256) * 3;
+    if (t3 && epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && span192 < span256) {
       g.tilesN = a->N / 256;
       if (ln_in) {
         if (epi == EPI_BF16) return launch_lin<1, 4, EPI_BF16, 2, false, 2, true, 3>(g, s);
