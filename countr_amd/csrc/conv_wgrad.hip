@@ -37,12 +37,13 @@ typedef __attribute__((address_space(3))) void* lds_vptr_t;
 typedef __attribute__((address_space(3))) const char* lds_cptr_t;
 
 struct CwgArgs {
-  const char* dy;      // [P, Cout] bf16 (NHWC output gradient)
-  const char* x;       // [P, Cin] bf16 (NHWC input map)
-  float* part;         // [Z][Cout][9 Cin]
+  const char* dy;      // [P, lda] bf16 (NHWC output gradient; LIN: dy [rows, lda])
+  const char* x;       // [P, ldb] bf16 (NHWC input map; LIN: x [rows, ldb])
+  float* part;         // [Z][Cout][N]
   float* rowsum;       // [Z * NC][Cout] or null
-  int Cout, Cin, H, Wd;
-  int N;               // 9 Cin
+  int Cout, Cin, H, Wd;   // Cout = rows of the output (M of the GEMM); Cin / H / Wd: convolution only
+  int lda, ldb;        // row pitches of dy and x in elements (convolution: Cout, Cin)
+  int N;               // 9 Cin (LIN: in_features)
   int tiles, tilesN;   // tiles = (Cout / 128) * tilesN
   int nkt, per, Z;     // k-tiles (P / 64), k-tiles per z, slabs
 };
@@ -66,7 +67,9 @@ template <int PENDING> __device__ __forceinline__ void frag_wait(Frag (&f)[4]) {
                : "n"(PENDING));
 }
 
-template <int WNB>
+// LIN: the same kernel as the weight gradient of an nn.Linear, dW[n][k] = sum_r dy[r][n] x[r][k] (the (COL, COL) split-K launches): the
+// contraction index is the token row, again the slow dimension of both operands -- no taps, no padding, nothing else differs.
+template <int WNB, bool LIN>
 __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel(const CwgArgs g) {
   constexpr int STAGES = 3, NCW = 4 * WNB, NLW = 4, SUBN = 2 * WNB;
   constexpr int A_BYTES = 64 * 256, STAGE_BYTES = A_BYTES * (1 + WNB);
@@ -85,25 +88,25 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
   }
   const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
   const int m0 = tile_m * 128, n0 = tile_n * (128 * WNB);
-  const int tap = n0 / g.Cin, ci0 = n0 - tap * g.Cin;
+  const int tap = LIN ? 4 : n0 / g.Cin, ci0 = LIN ? n0 : n0 - tap * g.Cin;
   const int dyt = tap / 3 - 1, dxt = tap - (tap / 3) * 3 - 1;
   const int kt0 = min(z * g.per, g.nkt), kt1 = min(kt0 + g.per, g.nkt);
   const int ntiles = kt1 - kt0;
 
   // ---- staging (loader waves).  Piece (pass i, wave w) = pixel rows [16 i + 4 w, +4) of a 128-channel operand tile; lane -> (row, slot)
   const int krow = lane >> 4, c8 = (lane & 15) ^ (krow << 2);
-  const uint32_t voffA = (uint32_t)(((cw * 4 + krow) * g.Cout + c8 * 8) * 2);
-  const uint32_t voffB = (uint32_t)(((cw * 4 + krow) * g.Cin + c8 * 8) * 2);
-  const int64_t cshift = (int64_t)(g.Wd + 1) * g.Cin * 2;     // descriptor base (Wd + 1) pixels in front of the map: every tap shift >= 0
+  const uint32_t voffA = (uint32_t)(((cw * 4 + krow) * g.lda + c8 * 8) * 2);
+  const uint32_t voffB = (uint32_t)(((cw * 4 + krow) * g.ldb + c8 * 8) * 2);
+  const int64_t cshift = LIN ? 0 : (int64_t)(g.Wd + 1) * g.ldb * 2;     // descriptor base (Wd + 1) pixels in front of the map: every tap shift >= 0
   const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(g.dy + ((int64_t)kt0 * 64 * g.Cout + m0) * 2), 0, 0x7ffffff0, 0x00020000);
+      (void*)(g.dy + ((int64_t)kt0 * 64 * g.lda + m0) * 2), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(g.x + ((int64_t)kt0 * 64 * g.Cin + ci0) * 2 - cshift), 0, 0x7ffffff0, 0x00020000);
-  const uint32_t tapoff = (uint32_t)(cshift + (int64_t)(dyt * g.Wd + dxt) * g.Cin * 2);
-  const uint32_t passA = (uint32_t)g.Cout * 32u, passB = (uint32_t)g.Cin * 32u;       // 16 pixel rows further, bytes
-  const uint32_t tileA = (uint32_t)g.Cout * 128u, tileB = (uint32_t)g.Cin * 128u;     // 64 pixel rows further
-  int px[4], py[4];   // pixel coordinates of this lane's row in pass i of the NEXT tile to be issued
-  if (loader) {
+      (void*)(g.x + ((int64_t)kt0 * 64 * g.ldb + ci0) * 2 - cshift), 0, 0x7ffffff0, 0x00020000);
+  const uint32_t tapoff = LIN ? 0u : (uint32_t)(cshift + (int64_t)(dyt * g.Wd + dxt) * g.ldb * 2);
+  const uint32_t passA = (uint32_t)g.lda * 32u, passB = (uint32_t)g.ldb * 32u;       // 16 pixel rows further, bytes
+  const uint32_t tileA = (uint32_t)g.lda * 128u, tileB = (uint32_t)g.ldb * 128u;     // 64 pixel rows further
+  int px[LIN ? 1 : 4], py[LIN ? 1 : 4];   // pixel coordinates of this lane's row in pass i of the NEXT tile to be issued
+  if (!LIN && loader) {
     const int p = kt0 * 64 + cw * 4 + krow;
     int xx = p % g.Wd, yy = (p / g.Wd) % g.H;
 #pragma unroll
@@ -123,14 +126,19 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * 4096), 16, voffA, t * tileA + i * passA, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = (unsigned)(py[i] + dyt) < (unsigned)g.H && (unsigned)(px[i] + dxt) < (unsigned)g.Wd;
-      const uint32_t vo = ok ? voffB : 0x80000000u;   // (a named variable: hipcc 7.2 drops the kernel stub for a conditional written as the argument)
+      uint32_t vo = voffB;
+      if constexpr (!LIN) {
+        const bool ok = (unsigned)(py[i] + dyt) < (unsigned)g.H && (unsigned)(px[i] + dxt) < (unsigned)g.Wd;
+        vo = ok ? voffB : 0x80000000u;   // (a named variable: hipcc 7.2 drops the kernel stub for a conditional written as the argument)
+      }
 #pragma unroll
       for (int j = 0; j < WNB; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + A_BYTES + j * A_BYTES + i * 4096), 16, vo,
                                                  tapoff + t * tileB + i * passB + j * 256, 0, 0);
-      px[i] += 64;
-      while (px[i] >= g.Wd) { px[i] -= g.Wd; py[i] = (py[i] + 1 == g.H) ? 0 : py[i] + 1; }
+      if constexpr (!LIN) {
+        px[i] += 64;
+        while (px[i] >= g.Wd) { px[i] -= g.Wd; py[i] = (py[i] + 1 == g.H) ? 0 : py[i] + 1; }
+      }
     }
   };
   if (loader) {
@@ -255,70 +263,80 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
   }
 }
 
-template <int WNB>
+template <int WNB, bool LIN>
 int launch_cwg(const CwgArgs& a, hipStream_t s) {
   constexpr int lds = 3 * 64 * 256 * (1 + WNB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg_kernel<WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg_kernel<WNB, LIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((cwg_kernel<WNB>), dim3(a.tiles * a.Z), dim3(256 * WNB + 256), lds, s, a);
+  hipLaunchKernelGGL((cwg_kernel<WNB, LIN>), dim3(a.tiles * a.Z), dim3(256 * WNB + 256), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean conv wgrad)");
 }
 
-// form: 0 = does not qualify, 1 = 128x128 tiles, 2 = 128x256 tiles
-int cwg_form(const countr_gemm_args* a) {
+// form: 0 = does not qualify, 1 = 128x128 tiles, 2 = 128x256 tiles.  lin: the (COL, COL) launch of an nn.Linear weight gradient
+int cwg_form(const countr_gemm_args* a, bool lin) {
   { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 0; }
-  { const char* e = getenv("COUNTR_LEAN_WGRAD"); if (e && atoi(e) == 0) return 0; }
+  { const char* e = getenv(lin ? "COUNTR_LEAN_LWGRAD" : "COUNTR_LEAN_WGRAD"); if (e && atoi(e) == 0) return 0; }
   if (!a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->bias || a->resid || a->C2 || a->act != COUNTR_ACT_NONE) return 0;
   if (a->ln_xcopy || a->ln_stats_out || a->ln_stats || a->ln_colsum) return 0;
-  if ((a->M % 128) || (a->Cin % 128) || a->N != 9 * a->Cin || (a->K % 64) || a->K < 64 || a->H < 2 || a->W < 2) return 0;
-  if (a->lda != a->M || a->ldc != a->N) return 0;
+  if ((a->M % 128) || (a->N % 128) || (a->K % 64) || a->K < 64 || a->ldc != a->N) return 0;
+  if (lin) {
+    if ((a->lda % 8) || (a->ldb % 8) || a->lda < a->M || a->ldb < a->N) return 0;
+    if ((int64_t)a->K * a->ldb * 2 >= (int64_t)0x7f000000ll || (int64_t)a->K * a->lda * 2 >= (int64_t)0x7f000000ll) return 0;
+  } else {
+    if ((a->Cin % 128) || a->N != 9 * a->Cin || a->H < 2 || a->W < 2 || a->lda != a->M) return 0;
+    if ((int64_t)(a->K + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->K * a->M * 2 >= (int64_t)0x7f000000ll) return 0;
+  }
   if ((((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->partial) & 15)) return 0;
   if (a->rowsum_partial && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1) * (a->N / 128)) return 0;   // caller sized the legacy layout
-  if ((int64_t)(a->K + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->K * a->M * 2 >= (int64_t)0x7f000000ll) return 0;
-  // 128 x 256 tiles (a whole tap of a 256-channel map per workgroup: 48 KB staged per 32 MFMAs instead of 32 KB per 16) when the map
-  // has the channels for it -- 192x192: 316 vs 391 us with the slab count that fills the chip in either form
-  // (countr_gemm_wgrad_tiles() is what a caller divides 256 by), profiles/r3_conv_wgrad_microbench.txt
-  int form = (a->Cin % 256) == 0 ? 2 : 1;
+  // 128 x 256 tiles (a whole tap of a 256-channel map per workgroup: 48 KB staged per 32 MFMAs instead of 32 KB per 16) when the
+  // operand has the columns for it AND a chip-filling split still leaves every workgroup >= 8 k-tiles -- 192x192: 316 vs 391 us with
+  // the slab count that fills the chip in either form (countr_gemm_tiles() is what a caller divides 256 by),
+  // profiles/r3_conv_wgrad_microbench.txt
+  const int wide = lin ? a->N : a->Cin;
+  const long t256 = (long)(a->M / 128) * (a->N / 256);
+  int form = ((wide % 256) == 0 && t256 > 0 && (long)(a->K / 64) * t256 >= 8 * 256) ? 2 : 1;
   { const char* e = getenv("COUNTR_LEAN_WGRAD_FORM"); if (e) form = atoi(e); }
-  if (form == 2 && (a->Cin % 256)) form = 1;
+  if (form == 2 && (wide % 256)) form = 1;
   return form == 2 ? 2 : 1;
 }
 
 }  // namespace
 
-// Slabs of rowsum_partial a (COL, IM2COL) bf16 split-K launch writes ([slabs][M]): splitk on the generic kernel, splitk x NC here.
-int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a) {
+// Slabs of rowsum_partial a (COL, IM2COL) / (COL, COL) bf16 split-K launch writes ([slabs][M]): splitk on the generic kernel, splitk x NC here.
+int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a, int lin) {
   countr_gemm_args b = *a;
   b.rowsum_slabs = (a->splitk > 1 ? a->splitk : 1) * (a->N / 128);
   if (!b.partial) b.partial = reinterpret_cast<float*>(16);   // (a sizing call may come before the workspace exists)
-  const int form = cwg_form(&b);
+  const int form = cwg_form(&b, lin != 0);
   const int sk = a->splitk > 1 ? a->splitk : 1;
   if (!form) return sk;
   return sk * (a->N / 128);     // NC = tilesN * SUBN / 2 = (N / (128 WNB)) * WNB
 }
 
-// Output tiles (workgroups per split-K slab) of a (COL, IM2COL) bf16 launch: what the caller divides the CU count by to pick splitk.
-int countr_lean_wgrad_tiles(const countr_gemm_args* a) {
+// Output tiles (workgroups per split-K slab) of such a launch: what the caller divides the CU count by to pick splitk.
+int countr_lean_wgrad_tiles(const countr_gemm_args* a, int lin) {
   countr_gemm_args b = *a;
   b.rowsum_partial = nullptr;
   if (!b.partial) b.partial = reinterpret_cast<float*>(16);
-  const int form = cwg_form(&b);
+  const int form = cwg_form(&b, lin != 0);
   if (!form) return ((a->M + 127) / 128) * ((a->N + 127) / 128);
   return (a->M / 128) * (a->N / (128 * form));
 }
 
 // Returns 1 when the launch does not qualify (gemm_kernel then runs it), otherwise the launch status.
-int countr_lean_wgrad(const countr_gemm_args* a, hipStream_t s) {
-  const int form = cwg_form(a);
+int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s) {
+  const int form = cwg_form(a, lin != 0);
   if (!form) return 1;
   CwgArgs g;
   g.dy = (const char*)a->A; g.x = (const char*)a->B; g.part = a->partial; g.rowsum = a->rowsum_partial;
-  g.Cout = a->M; g.Cin = a->Cin; g.H = a->H; g.Wd = a->W; g.N = a->N;
+  g.Cout = a->M; g.Cin = lin ? 0 : a->Cin; g.H = lin ? 0 : a->H; g.Wd = lin ? 0 : a->W; g.N = a->N;
+  g.lda = lin ? (int)a->lda : a->M; g.ldb = lin ? (int)a->ldb : a->Cin;
   g.tilesN = a->N / (128 * form); g.tiles = (a->M / 128) * g.tilesN;
   g.nkt = a->K / 64; g.Z = a->splitk > 1 ? a->splitk : 1;
   g.per = (g.nkt + g.Z - 1) / g.Z;
-  return form == 2 ? launch_cwg<2>(g, s) : launch_cwg<1>(g, s);
+  if (lin) return form == 2 ? launch_cwg<2, true>(g, s) : launch_cwg<1, true>(g, s);
+  return form == 2 ? launch_cwg<2, false>(g, s) : launch_cwg<1, false>(g, s);
 }

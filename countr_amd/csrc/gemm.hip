@@ -1350,20 +1350,22 @@ extern "C" int countr_reduce_table(const long long* table, int n, int total_bloc
 
 int countr_lean_linear(const countr_gemm_args* a, hipStream_t s);   // linear.hip: 1 = does not qualify
 int countr_lean_conv(const countr_gemm_args* a, hipStream_t s);
-int countr_lean_wgrad(const countr_gemm_args* a, hipStream_t s);      // conv_wgrad.hip
-int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a);
+int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s);      // conv_wgrad.hip
+int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a, int lin);
 
-int countr_lean_wgrad_tiles(const countr_gemm_args* a);
+int countr_lean_wgrad_tiles(const countr_gemm_args* a, int lin);
 
 extern "C" int countr_gemm_tiles(const countr_gemm_args* a, int dtype, int modeA, int modeB) {
   if (!a) return 0;
-  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_IM2COL) return countr_lean_wgrad_tiles(a);
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && (modeB == COUNTR_OP_IM2COL || modeB == COUNTR_OP_COL))
+    return countr_lean_wgrad_tiles(a, modeB == COUNTR_OP_COL);
   return ((a->M + 127) / 128) * ((a->N + 127) / 128);
 }
 
 extern "C" int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, int modeA, int modeB) {
   if (!a) return 0;
-  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_IM2COL) return countr_lean_wgrad_rowsum_slabs(a);
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && (modeB == COUNTR_OP_IM2COL || modeB == COUNTR_OP_COL))
+    return countr_lean_wgrad_rowsum_slabs(a, modeB == COUNTR_OP_COL);
   return a->splitk > 1 ? a->splitk : 1;
 }
 
@@ -1389,8 +1391,9 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
     const int rc = countr_lean_conv(a, s);     // 3x3 convolution forward / dgrad on the big maps: same kernel, im2row LDS-DMA addressing
     if (rc != 1) return rc;
   }
-  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_IM2COL) {
-    const int rc = countr_lean_wgrad(a, s);    // 3x3 convolution weight (+ bias) gradient: both maps staged K-major, transposing reads
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && (modeB == COUNTR_OP_IM2COL || modeB == COUNTR_OP_COL)) {
+    // weight (+ bias) gradient of a 3x3 convolution or an nn.Linear: both operands staged K-major, transposing fragment reads
+    const int rc = countr_lean_wgrad(a, modeB == COUNTR_OP_COL, s);
     if (rc != 1) return rc;
   }
   if (a->rowsum_partial && a->rowsum_slabs > 0 && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1)) {

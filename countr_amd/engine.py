@@ -512,7 +512,13 @@ class Engine:
         lddy = N if lddy is None else lddy
         ldx = K if ldx is None else ldx
         bk = 64 if self.code == BF16 else 32
-        tiles = -(-N // 128) * -(-K // 128)
+        kw = dict(A=dy.data_ptr() if not isinstance(dy, int) else dy, B=x.data_ptr() if not isinstance(x, int) else x,
+                  lda=lddy, ldb=ldx, ldc=K, M=N, N=K, K=M)
+        q = GemmArgs()
+        for k_, v_ in kw.items():
+            setattr(q, k_, v_)
+        q.alpha, q.nbatch, q.nb1 = 1.0, 1, 1
+        tiles = int(self.L.countr_gemm_tiles(C.byref(q), self.code, OP_COL, OP_COL))     # 128x128, or 128x256 on the lean kernel (conv_wgrad.hip)
         sk = self._splitk(tiles, -(-M // bk))
         defer = self.defer_reduce
         part = self._shared(("skp." + self._role(wname)) if defer else "splitk", sk * N * K)
@@ -520,13 +526,19 @@ class Engine:
         rs = self._shared(("rsp." + self._role(wname)) if defer else "rowsum", 64 * 4096) if fuse_bias else None
         if defer:
             self._claim(part.data_ptr())
-        self._gemm(ops, self.code, OP_COL, OP_COL, A=dy.data_ptr() if not isinstance(dy, int) else dy,
-                   B=x.data_ptr() if not isinstance(x, int) else x, partial=part.data_ptr(), lda=lddy, ldb=ldx, ldc=K,
-                   M=N, N=K, K=M, splitk=sk, rowsum_partial=(rs.data_ptr() if fuse_bias else None))
+        kw.update(partial=part.data_ptr(), splitk=sk)
+        rslabs = sk
+        if fuse_bias:
+            q.splitk = sk
+            n = int(self.L.countr_gemm_rowsum_slabs(C.byref(q), self.code, OP_COL, OP_COL)) if defer else sk
+            if n * N <= 64 * 4096:
+                rslabs = n
+            kw.update(rowsum_partial=rs.data_ptr(), rowsum_slabs=(rslabs if defer else 0))
+        self._gemm(ops, self.code, OP_COL, OP_COL, **kw)
         if defer:
             self._reduce_later(ops, part.data_ptr(), part.data_ptr(), self._gp(wname), sk, N * K, N * K)
             if fuse_bias:
-                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), sk, N, N)
+                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), rslabs, N, N)
         else:
             self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, self._acc,
                      rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)

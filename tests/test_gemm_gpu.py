@@ -614,6 +614,46 @@ def test_lean_conv_wgrad_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H
         assert (rs[:sk].double().sum(0) - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item() + 1e-9
 
 
+@pytest.mark.parametrize("R,N,K,lddy,ldx,sk,with_bias", [(4608, 512, 512, 512, 512, 16, True), (2304, 3072, 768, 3072, 768, 1, True), (2304, 768, 3072, 768, 3072, 2, True),
+                                                         (4608, 512, 512, 1536, 512, 8, False), (1152, 256, 384, 256, 512, 3, True), (64, 128, 128, 128, 128, 1, True),
+                                                         (4608, 2048, 512, 2048, 512, 4, True)])
+def test_lean_linear_wgrad_matches_fp64_and_generic(hip, monkeypatch, R, N, K, lddy, ldx, sk, with_bias):
+    """Weight (+ bias) gradient of an nn.Linear as the (COL, COL) split-K GEMM dW[N][K] = dy^T x on the lean kernel of conv_wgrad.hip
+    (LIN form: both operands staged K-major as they lie in memory, transposing reads) against fp64 and gemm_kernel
+    (COUNTR_LEAN_LWGRAD=0): operand pitches larger than the matrix (a q / k / v slice of a packed qkv gradient, an x with a wider
+    row), 128x128 and 128x256 tiles, one slab, a single k-tile per slab."""
+    dyf = _mk((R, lddy), torch.bfloat16, 81)
+    xf = _mk((R, ldx), torch.bfloat16, 82)
+    ref_w = dyf[:, :N].double().t() @ xf[:, :K].double()
+    ref_b = dyf[:, :N].double().sum(0)
+    res = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("COUNTR_LEAN_LWGRAD", lean)
+        a = _lib.GemmArgs()
+        a.A, a.B = dyf.data_ptr(), xf.data_ptr()
+        a.lda, a.ldb, a.ldc = lddy, ldx, K
+        a.M, a.N, a.K = N, K, R
+        a.alpha = 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = sk
+        slabs = hip.countr_gemm_rowsum_slabs(C.byref(a), 1, 1, 1)
+        assert slabs == (sk * (K // 128) if lean == "1" else sk)
+        part = torch.full((sk, N, K), float("nan"), device="cuda", dtype=torch.float32)
+        rs = torch.full((slabs, N), float("nan"), device="cuda", dtype=torch.float32)
+        a.partial = part.data_ptr()
+        if with_bias:
+            a.rowsum_partial, a.rowsum_slabs = rs.data_ptr(), slabs
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 1, 1, _stream()), "wgrad")
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        gw = part.double().sum(0)
+        assert (gw - ref_w).abs().max().item() <= 2e-5 * ref_w.abs().max().item() + 1e-9, lean
+        if with_bias:
+            assert torch.isfinite(rs).all()
+            assert (rs.double().sum(0) - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item() + 1e-9, lean
+        res.append(gw)
+    assert (res[0] - res[1]).abs().max().item() <= 4e-5 * ref_w.abs().max().item() + 1e-9
+
+
 @pytest.mark.parametrize("M,N2", [(4608, 1536), (576, 1536), (14976, 1536), (4608, 2304), (4400, 2304)])   # N2 = 2304 at B = 8: the 192x256 form
 @pytest.mark.parametrize("act", [0, 1])
 def test_lean_linear_layernorm_folding(hip, M, N2, act):
