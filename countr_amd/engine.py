@@ -200,6 +200,15 @@ class Engine:
                 shp = lay.shapes[n]
                 if n.startswith("decoder_blocks.") and n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
                     self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
+        elif (precision == "bf16" and not self.FROZEN_ENCODER and os.environ.get("COUNTR_DGRAD_T_ALL", "0") == "1"
+                and os.environ.get("COUNTR_LEAN", "1") != "0"):
+            # MAE pretraining (every Linear trains and has an input gradient): all 82 transposes = 222 MB for ViT-B in three shadow
+            # launches behind AdamW.  Measured and OFF: 8.40 / 8.39 ms against 8.12 / 8.14 ms -- the transposes cost more than the
+            # (ROW, ROW) launches save at M = 2304
+            for n in lay.train_names:
+                shp = lay.shapes[n]
+                if n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
+                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
         self.plans = {}
         self.hyper = torch.zeros(8, device=self.device, dtype=torch.float32)   # {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
         self.step_count = 0
@@ -1126,4 +1135,9 @@ class Engine:
                                 (C.c_int * n)(*[s_[0] for s_ in shp]), (C.c_int * n)(*[s_[1] for s_ in shp]),
                                 (C.c_int * n)(*[(s_[2] * s_[3] if len(s_) == 4 else 1) for s_ in shp]))
         n, src, wf, wd, co, ci, taps = self._shadow_tab
-        _lib.check(self.L.countr_conv_shadows(n, src, wf, wd, co, ci, taps, self.code, self._stream()), "conv_shadows")
+        vp, ip = C.c_void_p, C.c_int
+        for i0 in range(0, n, 32):           # the launch takes 32 entries
+            m = min(32, n - i0)
+            off = lambda arr, ty: C.cast(C.byref(arr, i0 * C.sizeof(ty)), C.POINTER(ty))
+            _lib.check(self.L.countr_conv_shadows(m, off(src, vp), off(wf, vp), off(wd, vp), off(co, ip), off(ci, ip), off(taps, ip),
+                                                  self.code, self._stream()), "conv_shadows")
