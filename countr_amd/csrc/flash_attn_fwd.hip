@@ -29,6 +29,9 @@
 // v_cvt_pk_bf16_f32 4.7 cycles per wave instruction.  A tile costs a wave 16 MFMAs and ~570 VALU cycles (half of them the 32
 // v_exp_f32), so the loop is VALU-bound by construction at dh = 64.
 #include "common.cuh"
+#ifndef COUNTR_FA_NOPIN
+#define COUNTR_FA_NOPIN 0   // experiments: 1 = no end-of-slot sched_barrier in the pipelined step, 2 = one every fourth slot, 3 = none at all
+#endif
 #include <stdlib.h>
 #include <utility>
 
@@ -440,7 +443,9 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
           constexpr int pend = lds_after(j);
           static_assert(pend <= 15, "lgkmcnt is a 4-bit counter");
           fa_lds_wait<pend>(fr[j]);
+#if COUNTR_FA_NOPIN != 3
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if constexpr (j < NQK) {
           constexpr int blk = j & 1, ks = j >> 1;
@@ -482,7 +487,11 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
 #pragma unroll
           for (int r = r0; r < r0 + PER; ++r) mx = (r == 0) ? fmaxf(Sn[0][0], Sn[1][0]) : max3(mx, Sn[0][r], Sn[1][r]);
         }
+#if COUNTR_FA_NOPIN == 0
         __builtin_amdgcn_sched_barrier(0);
+#elif COUNTR_FA_NOPIN == 2
+        if constexpr ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // a pin every fourth slot only
+#endif
       });
       if (ABL != 9 && ABL != 10) rescale_for(xor32_max(mx), Sn);
     }

@@ -337,7 +337,22 @@ class _GraphStep:
                     if k[1] is not None:
                         self.sync.finish(skip=cskip)
                         self._phase_c(k[1])
-                self._run_phase("allc", whole, (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip))
+                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip))
+                fresh = gk not in self.graphs
+                try:
+                    self._run_phase(gk[0], whole, gk[1])
+                except Exception as e:  # noqa: BLE001
+                    # _run_phase runs a new key EAGERLY first (the step has been done) and only then captures it: if the capture of the
+                    # collectives is what failed (an RCCL build that cannot be captured), keep the eager result, say so, and issue the
+                    # collectives from the host between per-phase graphs from now on.  Anything else is a real error.
+                    if not fresh or gk in self.graphs:
+                        raise
+                    import warnings
+                    warnings.warn("countr_amd: capturing the RCCL all-reduces into the step graph failed (%r); falling back to "
+                                  "host-issued collectives between per-phase graphs (COUNTR_GRAPH_COMM=0)" % (e,))
+                    self.sync.capturable = False
+                    self.sync._started = set()
+                    torch.cuda.synchronize()
             else:
                 for i, (name, fn, gkey) in enumerate(phases):
                     self._run_phase(name, fn, gkey)
