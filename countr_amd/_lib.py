@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 
 F32, BF16 = 0, 1
+ABI_VERSION = 2
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
@@ -49,6 +50,10 @@ def lib():
                 "the HIP path has no CPU fallback")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
+        if _lib.countr_version() != ABI_VERSION:      # a stale build: its countr_gemm_args is shorter than GemmArgs above
+            v = _lib.countr_version()
+            _lib = None
+            raise CountrError("libcountr_hip.so has ABI version %d, this package needs %d: rebuild (python -m countr_amd.build)" % (v, ABI_VERSION))
     return _lib
 
 

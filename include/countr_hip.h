@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 1                            */
+int countr_version(void);               /* ABI version, currently 2 (round 3: countr_gemm_args grew at its end -- ln_* fields, rowsum_slabs -- so a caller built against version 1 must be rebuilt) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
