@@ -84,8 +84,8 @@ _SIGS = {
     "countr_groupnorm_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "countr_groupnorm_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "countr_instnorm_workspace_floats": [_i, _i],
-    "countr_instnorm_relu_pool_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp],
-    "countr_instnorm_relu_pool_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "countr_instnorm_relu_pool_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp],
+    "countr_instnorm_relu_pool_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "countr_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "countr_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "countr_softmax_fwd": [_vp, _vp, _i64, _i, _i, _vp],

@@ -508,24 +508,34 @@ __device__ __forceinline__ void reduce8_same_cv(float (&v)[8], float* sm /* [4][
   for (int i = 0; i < 8; ++i) v[i] = sm[c * 8 + i] + sm[(NCV + c) * 8 + i] + sm[(2 * NCV + c) * 8 + i] + sm[(3 * NCV + c) * 8 + i];
 }
 
+// x-hat storage (xh_out / x_is_xhat): the forward can rewrite the map as the NORMALISED activation, rounded to T, and compute the pooled
+// output from those rounded values; the backward then reads x-hat itself.  In bf16 that matters: x-hat recomputed from a rounded x
+// carries a relative error of (|mean| / sigma + |x-hat|) * 2^-9 -- several per cent on the channels of a 64-pixel map whose mean is a
+// few sigma -- which the two reductions of the InstanceNorm backward turn into a 0.975 cosine of dx against fp32 (the whole exemplar CNN's
+// weight gradients: 0.96, tools/diag_exemplar_bf16.py); a stored x-hat is good to |x-hat| * 2^-9.
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
 // NCV = 8-channel vectors per block: 8 (64 channels, 32 pixel slots) or 1 (8 channels, 256 pixel slots: 8x the blocks for the
 // 64- and 128-channel layers, whose (C/64, S) grid leaves most CUs idle)
-template <typename T, int NCV>
-__global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+template <typename T, int NCV, typename TX = T>   // TX: dtype of the map x (fp32 conv outputs in front of bf16 activations: see x-hat above)
+__global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const TX* x, T* __restrict__ y,
                                                                float* __restrict__ stats /* [S][C][2] */, int H, int W, int C,
-                                                               int avgpool, float eps) {
+                                                               int avgpool, float eps, T* xh_out /* may alias x */) {
   __shared__ float sm[4 * 8 * 8];
   const int s = blockIdx.y, c0 = blockIdx.x * (NCV * 8);
   constexpr int NSLOT = 256 / NCV;
   const int cv = threadIdx.x % NCV, slot = threadIdx.x / NCV;
   const int HW = H * W;
-  const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  const TX* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  T* xho = xh_out ? xh_out + (int64_t)s * HW * C + c0 + cv * 8 : nullptr;
   float sum[8], sq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
   for (int p = slot; p < HW; p += NSLOT) {
     float v[8];
-    ld8<T>(xs + (int64_t)p * C, v);
+    ld8<TX>(xs + (int64_t)p * C, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum[e] += v[e];
   }
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
   for (int e = 0; e < 8; ++e) mean[e] = sum[e] / HW;
   for (int p = slot; p < HW; p += NSLOT) {
     float v[8];
-    ld8<T>(xs + (int64_t)p * C, v);
+    ld8<TX>(xs + (int64_t)p * C, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float d = v[e] - mean[e]; sq[e] += d * d; }
   }
@@ -560,9 +570,17 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float v[8];
-        ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v);
+        const int64_t off = (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C;
+        ld8<TX>(xs + off, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (v[e] - mean[e]) * rstd[e]);
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * rstd[e];
+        if (xho) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = round_as<T>(v[e]);
+          st8<T>(xho + off, v);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
       }
       st8<T>(ys + (int64_t)po * C, m);
     }
@@ -572,9 +590,16 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (int p = slot; p < HW; p += NSLOT) {
       float v[8];
-      ld8<T>(xs + (int64_t)p * C, v);
+      ld8<TX>(xs + (int64_t)p * C, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += fmaxf((v[e] - mean[e]) * rstd[e], 0.f);
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * rstd[e];
+      if (xho) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = round_as<T>(v[e]);
+        st8<T>(xho + (int64_t)p * C, v);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += fmaxf(v[e], 0.f);
     }
     float o[8];
     reduce8_same_cv<NCV>(acc, sm);
@@ -590,7 +615,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
 template <typename T, int NCV>
 __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
                                                                const float* __restrict__ stats, T* __restrict__ dx, int H,
-                                                               int W, int C, int avgpool) {
+                                                               int W, int C, int avgpool, int x_is_xhat) {
   __shared__ float sm[4 * 8 * 8];
   const int s = blockIdx.y, c0 = blockIdx.x * (NCV * 8);
   constexpr int NSLOT = 256 / NCV;
@@ -604,6 +629,9 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
     mean[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2];
     rstd[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2 + 1];
   }
+  float xm[8], xr[8];      // x-hat = (v - xm) * xr: identity when the forward stored x-hat
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { xm[e] = x_is_xhat ? 0.f : mean[e]; xr[e] = x_is_xhat ? 1.f : rstd[e]; }
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -621,7 +649,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
       ld8<T>(xs + (int64_t)po * C, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xh = (v[e] - mean[e]) * rstd[e];
+        const float xh = (v[e] - xm[e]) * xr[e];
         const float g = xh > 0.f ? davg[e] : 0.f;
         s1[e] += g; s2[e] += g * xh;
       }
@@ -640,7 +668,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xh = (best[e] - mean[e]) * rstd[e];
+        const float xh = (best[e] - xm[e]) * xr[e];
         const float g = xh > 0.f ? d[e] : 0.f;
         s1[e] += g; s2[e] += g * xh;
       }
@@ -657,7 +685,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
       ld8<T>(xs + (int64_t)po * C, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xh = (v[e] - mean[e]) * rstd[e];
+        const float xh = (v[e] - xm[e]) * xr[e];
         const float g = xh > 0.f ? davg[e] : 0.f;
         o[e] = rstd[e] * (g - s1[e] - xh * s2[e]);
       }
@@ -682,7 +710,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = (v[q][e] - mean[e]) * rstd[e];
+          const float xh = (v[q][e] - xm[e]) * xr[e];
           const float g = (arg[e] == q && xh > 0.f) ? d[e] : 0.f;
           o[e] = rstd[e] * (g - s1[e] - xh * s2[e]);
         }
@@ -729,9 +757,9 @@ __global__ __launch_bounds__(256) void in_stats_split_kernel(const T* __restrict
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void in_apply_split_kernel(const T* __restrict__ x, const float* __restrict__ partial, T* __restrict__ y,
-                                                             float* __restrict__ stats, int H, int W, int C, float eps) {
+template <typename T, typename TX = T>
+__global__ __launch_bounds__(256) void in_apply_split_kernel(const TX* x, const float* __restrict__ partial, T* __restrict__ y,
+                                                             float* __restrict__ stats, int H, int W, int C, float eps, T* xh_out /* may alias x */) {
   const int s = blockIdx.y, cb = blockIdx.x, split = blockIdx.z, NS = gridDim.z;
   const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int HW = H * W, n = HW / NS;
@@ -765,7 +793,8 @@ __global__ __launch_bounds__(256) void in_apply_split_kernel(const T* __restrict
     }
   }
   const int Ho = H / 2, Wo = W / 2, orow = Ho / NS;
-  const T* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  const TX* xs = x + (int64_t)s * HW * C + c0 + cv * 8;
+  T* xho = xh_out ? xh_out + (int64_t)s * HW * C + c0 + cv * 8 : nullptr;
   T* ys = y + (int64_t)s * Ho * Wo * C + c0 + cv * 8;
   for (int po = split * orow * Wo + slot; po < (split + 1) * orow * Wo; po += 32) {
     const int oy = po / Wo, ox = po - oy * Wo;
@@ -775,9 +804,17 @@ __global__ __launch_bounds__(256) void in_apply_split_kernel(const T* __restrict
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float v[8];
-      ld8<T>(xs + (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C, v);
+      const int64_t off = (int64_t)((2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C;
+      ld8<TX>(xs + off, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (v[e] - mean[e]) * rstd[e]);
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * rstd[e];
+      if (xho) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = round_as<T>(v[e]);
+        st8<T>(xho + off, v);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
     }
     st8<T>(ys + (int64_t)po * C, m);
   }
@@ -786,7 +823,7 @@ __global__ __launch_bounds__(256) void in_apply_split_kernel(const T* __restrict
 // backward, max-pool case only: APPLY = false -> band sums of g and g * xhat; true -> dx of the band
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void in_bwd_split_kernel(const T* __restrict__ x, const T* __restrict__ dyp, const float* __restrict__ stats,
-                                                           float* __restrict__ partial, T* __restrict__ dx, int H, int W, int C) {
+                                                           float* __restrict__ partial, T* __restrict__ dx, int H, int W, int C, int x_is_xhat) {
   __shared__ float sm[4 * 8 * 8];
   const int s = blockIdx.y, cb = blockIdx.x, split = blockIdx.z, NS = gridDim.z;
   const int cv = threadIdx.x & 7, slot = threadIdx.x >> 3, c0 = cb * 64;
@@ -800,6 +837,9 @@ __global__ __launch_bounds__(256) void in_bwd_split_kernel(const T* __restrict__
     rstd[e] = stats[((int64_t)s * C + c0 + cv * 8 + e) * 2 + 1];
     s1[e] = 0.f; s2[e] = 0.f;
   }
+  float xm[8], xr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { xm[e] = x_is_xhat ? 0.f : mean[e]; xr[e] = x_is_xhat ? 1.f : rstd[e]; }
   float* pp = partial + (((int64_t)s * gridDim.x + cb) * NS * 2) * 64 + cv * 8;
   if (APPLY) {
     for (int q = 0; q < NS; ++q) {
@@ -829,7 +869,7 @@ __global__ __launch_bounds__(256) void in_bwd_split_kernel(const T* __restrict__
     if (!APPLY) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xh = (best[e] - mean[e]) * rstd[e];
+        const float xh = (best[e] - xm[e]) * xr[e];
         const float g = xh > 0.f ? d[e] : 0.f;
         s1[e] += g; s2[e] += g * xh;
       }
@@ -839,7 +879,7 @@ __global__ __launch_bounds__(256) void in_bwd_split_kernel(const T* __restrict__
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = (v[q][e] - mean[e]) * rstd[e];
+          const float xh = (v[q][e] - xm[e]) * xr[e];
           const float g = (arg[e] == q && xh > 0.f) ? d[e] : 0.f;
           o[e] = rstd[e] * (g - s1[e] - xh * s2[e]);
         }
@@ -995,43 +1035,48 @@ static int in_splits(int S, int H, int C, int avgpool) {
 extern "C" int countr_instnorm_workspace_floats(int S, int C) { return S * C * 16 * 2; }
 
 extern "C" int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C, int avgpool,
-                                             float eps, int dtype, float* workspace, void* stream) {
+                                             float eps, int dtype, float* workspace, void* xhat_out, int x_f32, void* stream) {
   if (!x || !y || C % 64 || (H & 1) || (W & 1)) { countr_set_error("countr_instnorm_relu_pool_fwd: bad args (C % 64, even H/W)"); return -1; }
+  if (x_f32 && dtype == COUNTR_BF16 && xhat_out == x) { countr_set_error("countr_instnorm_relu_pool_fwd: a bf16 x-hat cannot be stored in place of an fp32 map"); return -1; }
   const int ns = workspace ? in_splits(S, H, C, avgpool) : 0;
   if (ns) {
     dim3 grid(C / 64, S, ns), block(256);
-    if (dtype == COUNTR_BF16) {
+    if (dtype == COUNTR_BF16 && x_f32) {
+      hipLaunchKernelGGL(in_stats_split_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, workspace, H, W, C);
+      hipLaunchKernelGGL((in_apply_split_kernel<bf16_t, float>), grid, block, 0, STREAM(stream), (const float*)x, workspace, (bf16_t*)y, stats, H, W, C, eps, (bf16_t*)xhat_out);
+    } else if (dtype == COUNTR_BF16) {
       hipLaunchKernelGGL(in_stats_split_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, workspace, H, W, C);
-      hipLaunchKernelGGL(in_apply_split_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, workspace, (bf16_t*)y, stats, H, W, C, eps);
+      hipLaunchKernelGGL(in_apply_split_kernel<bf16_t>, grid, block, 0, STREAM(stream), (const bf16_t*)x, workspace, (bf16_t*)y, stats, H, W, C, eps, (bf16_t*)xhat_out);
     } else {
       hipLaunchKernelGGL(in_stats_split_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, workspace, H, W, C);
-      hipLaunchKernelGGL(in_apply_split_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, workspace, (float*)y, stats, H, W, C, eps);
+      hipLaunchKernelGGL(in_apply_split_kernel<float>, grid, block, 0, STREAM(stream), (const float*)x, workspace, (float*)y, stats, H, W, C, eps, (float*)xhat_out);
     }
     COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_fwd");
   }
   dim3 grid(C / 64, S), block(256);
-  if (dtype == COUNTR_BF16) hipLaunchKernelGGL((in_relu_pool_fwd_kernel<bf16_t, 8>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, stats, H, W, C, avgpool, eps);
-  else hipLaunchKernelGGL((in_relu_pool_fwd_kernel<float, 8>), grid, block, 0, STREAM(stream), (const float*)x, (float*)y, stats, H, W, C, avgpool, eps);
+  if (dtype == COUNTR_BF16 && x_f32) hipLaunchKernelGGL((in_relu_pool_fwd_kernel<bf16_t, 8, float>), grid, block, 0, STREAM(stream), (const float*)x, (bf16_t*)y, stats, H, W, C, avgpool, eps, (bf16_t*)xhat_out);
+  else if (dtype == COUNTR_BF16) hipLaunchKernelGGL((in_relu_pool_fwd_kernel<bf16_t, 8>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, stats, H, W, C, avgpool, eps, (bf16_t*)xhat_out);
+  else hipLaunchKernelGGL((in_relu_pool_fwd_kernel<float, 8>), grid, block, 0, STREAM(stream), (const float*)x, (float*)y, stats, H, W, C, avgpool, eps, (float*)xhat_out);
   COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_fwd");
 }
 
 extern "C" int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H, int W,
-                                             int C, int avgpool, int dtype, float* workspace, void* stream) {
+                                             int C, int avgpool, int dtype, float* workspace, int x_is_xhat, void* stream) {
   if (!x || !dyp || !stats || !dx || C % 64) { countr_set_error("countr_instnorm_relu_pool_bwd: bad args"); return -1; }
   const int ns = workspace ? in_splits(S, H, C, avgpool) : 0;
   if (ns) {
     dim3 grid(C / 64, S, ns), block(256);
     if (dtype == COUNTR_BF16) {
-      hipLaunchKernelGGL((in_bwd_split_kernel<bf16_t, false>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, workspace, (bf16_t*)dx, H, W, C);
-      hipLaunchKernelGGL((in_bwd_split_kernel<bf16_t, true>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, workspace, (bf16_t*)dx, H, W, C);
+      hipLaunchKernelGGL((in_bwd_split_kernel<bf16_t, false>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, workspace, (bf16_t*)dx, H, W, C, x_is_xhat);
+      hipLaunchKernelGGL((in_bwd_split_kernel<bf16_t, true>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, workspace, (bf16_t*)dx, H, W, C, x_is_xhat);
     } else {
-      hipLaunchKernelGGL((in_bwd_split_kernel<float, false>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, workspace, (float*)dx, H, W, C);
-      hipLaunchKernelGGL((in_bwd_split_kernel<float, true>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, workspace, (float*)dx, H, W, C);
+      hipLaunchKernelGGL((in_bwd_split_kernel<float, false>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, workspace, (float*)dx, H, W, C, x_is_xhat);
+      hipLaunchKernelGGL((in_bwd_split_kernel<float, true>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, workspace, (float*)dx, H, W, C, x_is_xhat);
     }
     COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_bwd");
   }
   dim3 grid(C / 64, S), block(256);
-  if (dtype == COUNTR_BF16) hipLaunchKernelGGL((in_relu_pool_bwd_kernel<bf16_t, 8>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, (bf16_t*)dx, H, W, C, avgpool);
-  else hipLaunchKernelGGL((in_relu_pool_bwd_kernel<float, 8>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, (float*)dx, H, W, C, avgpool);
+  if (dtype == COUNTR_BF16) hipLaunchKernelGGL((in_relu_pool_bwd_kernel<bf16_t, 8>), grid, block, 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dyp, stats, (bf16_t*)dx, H, W, C, avgpool, x_is_xhat);
+  else hipLaunchKernelGGL((in_relu_pool_bwd_kernel<float, 8>), grid, block, 0, STREAM(stream), (const float*)x, (const float*)dyp, stats, (float*)dx, H, W, C, avgpool, x_is_xhat);
   COUNTR_LAUNCH_CHECK("countr_instnorm_relu_pool_bwd");
 }

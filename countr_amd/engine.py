@@ -813,20 +813,29 @@ class Engine:
             boxes = A("boxes", (BS, 3, 64, 64), f32)
             chans = [64, 128, 256, Dd]
             sizes = [64, 32, 16, 8]
-            c = [A("c%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)]
+            # bf16 engine: the exemplar CNN's convolutions write fp32 (c*) and the InstanceNorm stage turns them into bf16 pooled
+            # activations and -- training plans -- the bf16 NORMALISED maps (ch*) its backward reads.  A bf16 conv output is rounded at
+            # 2^-9 of its value; on channels whose mean is several sigma that moves pixels across the ReLU boundary of the normalised
+            # map, and the InstanceNorm backward turned it into cos 0.975 per layer / 0.96 for the CNN's weight gradients against fp32
+            # (tools/diag_exemplar_bf16.py).  COUNTR_IN_XHAT=0: bf16 maps, x-hat recomputed (rounds 1-2)
+            xh = bool(code == BF16 and os.environ.get("COUNTR_IN_XHAT", "1") != "0")
+            p.in_xhat = xh
+            c = [A("c%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), f32 if xh else T) for i in range(4)]
+            ch = [A("ch%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)] if (xh and train) else None
+            p.in_maps = ch if ch is not None else c
             pl = [A("p%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
             stats = [A("instats%d" % (i + 1), (BS, chans[i], 2), f32) for i in range(4)]
             self._op(ops, L.countr_conv3x3_c3_fwd, boxes.data_ptr(), self._pp("decoder_proj1.0.weight"), self._pp("decoder_proj1.0.bias"),
-                     c[0].data_ptr(), BS, 64, 64, code)
+                     c[0].data_ptr(), BS, 64, 64, F32 if xh else code)
             in_ws = self._shared("in_ws", L.countr_instnorm_workspace_floats(BS, Dd))
             self._op(ops, L.countr_instnorm_relu_pool_fwd, c[0].data_ptr(), pl[0].data_ptr(), stats[0].data_ptr(), BS, 64, 64, 64, 0, 1e-5,
-                     code, in_ws.data_ptr())
+                     code, in_ws.data_ptr(), ch[0].data_ptr() if ch is not None else None, int(xh))
             for i in (1, 2, 3):
                 wn = "decoder_proj%d.0.weight" % (i + 1)
                 self._conv_fwd(ops, pl[i - 1], self.Wf[wn], self._pp(wn[:-6] + "bias"), c[i], BS, sizes[i], sizes[i], chans[i - 1], chans[i])
                 last = i == 3
                 self._op(ops, L.countr_instnorm_relu_pool_fwd, c[i].data_ptr(), (ytok if last else pl[i]).data_ptr(), stats[i].data_ptr(),
-                         BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code, in_ws.data_ptr())
+                         BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code, in_ws.data_ptr(), ch[i].data_ptr() if ch is not None else None, int(xh))
         # the cross-attention keys / values depend on the exemplar tokens only: all blocks' wk / wv projections (tiny GEMMs, 4 tiles each)
         # follow the tokens directly -- with exemplars that is inside the side lane that runs beside the encoder
         kv = []
@@ -1041,8 +1050,8 @@ class Engine:
                 dc = [A("dc%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)]
                 dpl = [A("dp%d" % (i + 1), (BS, sizes[i] // 2, sizes[i] // 2, chans[i]), T) for i in range(3)]
                 for i in (3, 2, 1, 0):
-                    self._op(ops, L.countr_instnorm_relu_pool_bwd, c[i].data_ptr(), (g_y if i == 3 else dpl[i]).data_ptr(), stats[i].data_ptr(),
-                             dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code, in_ws.data_ptr())
+                    self._op(ops, L.countr_instnorm_relu_pool_bwd, p.in_maps[i].data_ptr(), (g_y if i == 3 else dpl[i]).data_ptr(), stats[i].data_ptr(),
+                             dc[i].data_ptr(), BS, sizes[i], sizes[i], chans[i], int(i == 3), code, in_ws.data_ptr(), int(p.in_xhat))
                     wn = "decoder_proj%d.0.weight" % (i + 1)
                     if i == 0:
                         ws = self._shared("c3wgrad", L.countr_conv3x3_c3_wgrad_nblocks() * 64 * 28)

@@ -166,10 +166,18 @@ int countr_groupnorm_relu_bwd(const void* x, const void* dy, const float* d1, co
 /* workspace (optional, fp32 [countr_instnorm_workspace_floats(S, C)]): lets the wide first layers (few (sample, 64-channel)
  * blocks) run as two pixel-band kernels with Chan-combined statistics; NULL = single-kernel path. */
 int countr_instnorm_workspace_floats(int S, int C);
+/* xhat_out (optional; may be x itself = in place): the forward also stores the NORMALISED activation (x - mean) * rstd, rounded to the
+ * dtype, and computes the pooled output from those rounded values; the backward is then given that buffer as x with x_is_xhat = 1.
+ * What it is for: in bf16 an x-hat recomputed from a rounded x is off by (|mean| / sigma + |x-hat|) * 2^-9 relative, which the two
+ * reductions of the InstanceNorm backward amplify (exemplar-CNN weight gradients: cosine 0.96 against fp32); a stored x-hat is good
+ * to |x-hat| * 2^-9.
+ * x_f32 = 1: the map x is fp32 although y / xhat_out have `dtype` (a convolution that writes its output -- bias included -- in fp32:
+ * a bf16 map is rounded at 2^-9 of its VALUE, which for a channel whose mean is several sigma moves pixels across the ReLU boundary of
+ * x-hat and costs the backward ~2 % in cosine per layer; the normalised activation does not have that problem). */
 int countr_instnorm_relu_pool_fwd(const void* x, void* y, float* stats, int S, int H, int W, int C,
-                                  int avgpool, float eps, int dtype, float* workspace, void* stream);
+                                  int avgpool, float eps, int dtype, float* workspace, void* xhat_out, int x_f32, void* stream);
 int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* stats, void* dx, int S, int H,
-                                  int W, int C, int avgpool, int dtype, float* workspace, void* stream);
+                                  int W, int C, int avgpool, int dtype, float* workspace, int x_is_xhat, void* stream);
 
 /* -------- fused self-attention forward (Attention.forward, models_crossvit.py:82-94 == timm Attention):
  * out = softmax(q k^T * scale) v on a packed bf16 qkv [B, N, 3, H, dh] (dh = 32 or 64) -> bf16 [B, N, H*dh].

@@ -161,10 +161,11 @@ def test_gradients_fp32_match_reference_golden(fp32_model, tag, shots):
 @pytest.mark.parametrize("B,S,seed", [(2, 3, 1), (8, 3, 3), (2, 0, 2)])
 def test_bf16_gradients_close_to_oracle(bf16_model, B, S, seed):
     """bf16 training mode vs the fp32 oracle, per trainable tensor (direction and magnitude), at B = 2 and at the BASELINE config-2
-    batch B = 8.  Bars sit just outside what tools/diag_bf16_grads.py measures (gpurun_out -> profiles/r2_bf16_gradient_quality.txt):
-    shot_num = 3: every decoder-side tensor cos >= 0.9998, norm within 0.5 %; the exemplar CNN (its gradient arrives through the tiny
-    cross-attention k/v signal) cos 0.960-0.963, norm within 1.4 %.  shot_num = 0 has the smallest map magnitude, its forward
-    cancellation error (counts 6 %, see the module docstring) scales dL/dout: cos >= 0.988, norms 0.81-0.95 of the oracle's."""
+    batch B = 8.  Bars sit just outside what tools/diag_bf16_grads.py measures (profiles/r3_bf16_gradient_quality.txt):
+    shot_num = 3: every decoder-side tensor cos >= 0.9998; norms 0.990-0.998 of the oracle's (they follow the magnitude of the density
+    map: dL/dout ~ out where gt = 0, and the bf16 forward's counts are good to ~1 % -- module docstring); the exemplar CNN cos 0.979-0.990
+    (0.960 before its convolutions wrote fp32 maps for the InstanceNorm stage: tools/diag_exemplar_bf16.py), norm within 1.2 %.
+    shot_num = 0 has the smallest map magnitude, its forward cancellation error scales dL/dout: cos >= 0.992, norms 0.84-0.96."""
     m, sd = bf16_model
     imgs, boxes, gt, mask = W.make_inputs(batch=B, shots=3, seed=seed)
     m.train()
@@ -187,11 +188,11 @@ def test_bf16_gradients_close_to_oracle(bf16_model, B, S, seed):
         cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
         ratio = (got.norm() / ref.norm()).item()
         if S == 0:
-            assert cos > 0.98 and 0.75 < ratio < 1.02, (k, cos, ratio)
+            assert cos > 0.985 and 0.78 < ratio < 1.02, (k, cos, ratio)
         elif k.startswith("decoder_proj"):
-            assert cos > 0.95 and abs(ratio - 1) < 0.03, (k, cos, ratio)
+            assert cos > 0.97 and abs(ratio - 1) < 0.02, (k, cos, ratio)
         else:
-            assert cos > 0.999 and abs(ratio - 1) < 0.01, (k, cos, ratio)
+            assert cos > 0.999 and abs(ratio - 1) < 0.015, (k, cos, ratio)
         checked += 1
     assert checked >= (50 if S == 0 else 55)
 

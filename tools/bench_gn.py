@@ -29,8 +29,8 @@ for H, Cc, avg in ((64, 64, 0), (32, 128, 0), (16, 256, 0), (8, 512, 1)):
     y = torch.empty(S, H // 2, H // 2, Cc, device="cuda", dtype=torch.bfloat16) if not avg else torch.empty(S, Cc, device="cuda", dtype=torch.bfloat16)
     dyp = torch.randn_like(y); dx = torch.empty_like(x); stats = torch.empty(S, Cc, 2, device="cuda")
     iws = torch.empty(L.countr_instnorm_workspace_floats(S, Cc), device="cuda")
-    f = lambda: L.countr_instnorm_relu_pool_fwd(P(x), P(y), P(stats), S, H, H, Cc, avg, 1e-5, 1, P(iws), st())
-    bw = lambda: L.countr_instnorm_relu_pool_bwd(P(x), P(dyp), P(stats), P(dx), S, H, H, Cc, avg, 1, P(iws), st())
+    f = lambda: L.countr_instnorm_relu_pool_fwd(P(x), P(y), P(stats), S, H, H, Cc, avg, 1e-5, 1, P(iws), None, 0, st())
+    bw = lambda: L.countr_instnorm_relu_pool_bwd(P(x), P(dyp), P(stats), P(dx), S, H, H, Cc, avg, 1, P(iws), 0, st())
     print("IN %2dx%2d C%3d: fwd %6.1f us   bwd %6.1f us" % (H, H, Cc, timeit(f), timeit(bw)), flush=True)
 # first exemplar conv (3 -> 64, direct) forward / wgrad
 S, H = 24, 64
