@@ -650,7 +650,10 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
     const long g256 = (long)((a->M + 255) / 256) * (a->N / 128), g192 = (long)((a->M + 191) / 192) * (a->N / 256);
     // rounds x tile work (in 128x128 units: 2 vs 3) of the two grids on 256 CUs
     const long span256 = ((g256 + 255) / 256) * 2, span192 = ((g192 + 255) / 256) * 3;
-    if (t3 && epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && span192 < span256) {
+    // ... and on big grids (>= 4 rounds) also when it needs up to 10 % more tile-times: its unit is cheaper (86 % of the staged bytes
+    // per MFMA) -- zero-shot inference at 32 windows: 8.42-8.46 -> 8.27-8.37 ms with qkv AND fc1 on this form (COUNTR_LEAN_T3=0: never)
+    const long slack = g256 >= 1024 ? 110 : 100;
+    if (t3 && epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && span192 * 100 <= span256 * slack) {
       g.tilesN = a->N / 256;
       if (ln_in) {
         if (epi == EPI_BF16) return launch_lin<1, 4, EPI_BF16, 2, false, 2, true, 3>(g, s);
