@@ -1350,6 +1350,8 @@ extern "C" int countr_reduce_table(const long long* table, int n, int total_bloc
 
 int countr_lean_linear(const countr_gemm_args* a, hipStream_t s);   // linear.hip: 1 = does not qualify
 int countr_lean_conv(const countr_gemm_args* a, hipStream_t s);
+int countr_big_linear(const countr_gemm_args* a, hipStream_t s);    // gemm256.hip: 256 x 256 tiles, 8-phase schedule; 1 = does not qualify
+int countr_big_conv(const countr_gemm_args* a, hipStream_t s);
 int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s);      // conv_wgrad.hip
 int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a, int lin);
 
@@ -1384,10 +1386,14 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   if ((modeA == COUNTR_OP_IM2ROW || modeB == COUNTR_OP_IM2COL) && (a->Cin % 64 || a->H <= 0 || a->W <= 0)) { countr_set_error("countr_gemm: conv modes need Cin % 64 == 0"); return -1; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_ROW && modeB == COUNTR_OP_ROW && a->act <= COUNTR_ACT_GELU) {
+    const int rb = countr_big_linear(a, s);    // chip-filling grids of 256 x 256 tiles (fc1): the 8-phase kernel of gemm256.hip
+    if (rb != 1) return rb;
     const int rc = countr_lean_linear(a, s);   // full-tile nn.Linear forward shapes: the lean kernel of linear.hip
     if (rc != 1) return rc;
   }
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_IM2ROW && modeB == COUNTR_OP_ROW) {
+    const int rb = countr_big_conv(a, s);      // ... on the 192x192 maps: 256 x 256 tiles, 8-phase schedule (gemm256.hip)
+    if (rb != 1) return rb;
     const int rc = countr_lean_conv(a, s);     // 3x3 convolution forward / dgrad on the big maps: same kernel, im2row LDS-DMA addressing
     if (rc != 1) return rc;
   }
