@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 import models_mae_cross
-from countr_amd.parallel import shared_shot_num
+from countr_amd.parallel import rank_shot_nums, shared_shot_num
 from countr_amd.synthetic import make_batch
 from countr_amd.trainer import FinetuneStep
 from countr_amd.util import lr_sched, misc
@@ -67,6 +67,9 @@ def get_args_parser():
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--synthetic_steps", default=0, type=int,
                    help="K > 0: K iterations per epoch on synthetic batches; 0: FSC147 from --data_path (synthetic, 50 it/epoch, if absent)")
+    p.add_argument("--per_rank_shot", action="store_true",
+                   help="reference semantics for N > 1: every rank draws its own shot_num per iteration (FSC_finetune_cross.py:276-284; "
+                        "default: one draw shared by all ranks)")
     p.add_argument("--log_every", default=50, type=int, help="iterations between loss reports (each report is a host sync)")
     return p
 
@@ -86,11 +89,11 @@ def main(args):
         args.lr = args.blr * eff_batch / 256     # :218-221
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95),
-                        accum_iter=args.accum_iter)
-    if ckpt is not None and args.do_resume and "epoch" in ckpt:      # util/misc.py:400-421: optimizer / epoch only with --do_resume
-        # (raises when the entry fits neither this model's torch.optim.AdamW layout nor the older flat form: continuing late in the
-        # LR schedule with zeroed moments would be a silent restart of the bias correction)
-        step.load_optimizer_state(ckpt.get("optimizer"))
+                        accum_iter=args.accum_iter, per_rank_shot=args.per_rank_shot)
+    if ckpt is not None and args.do_resume and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:415: all three, else skipped
+        # (raises when the entry EXISTS and fits neither this model's torch.optim.AdamW layout nor the older flat form: continuing late
+        # in the LR schedule with zeroed moments would be a silent restart of the bias correction)
+        step.load_optimizer_state(ckpt["optimizer"])
         args.start_epoch = ckpt["epoch"] + 1
         print("With optim & sched!")
     from countr_amd.data import fsc147
@@ -137,14 +140,21 @@ def main(args):
             else:
                 imgs, boxes, gt, mask = make_batch(B, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
                 mosaic = False
-            if flag_group is not None:               # shot_num is shared by all ranks, so is the ban: any rank with a Type-2 mosaic.
-                flag = torch.tensor([int(mosaic)])   # Host data, host collective (gloo): reading a device flag back would drain the
-                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=flag_group)   # GPU queue every step
-                mosaic = bool(flag.item())
+            world = misc.get_world_size()
+            mosaics = [mosaic] * world
+            if flag_group is not None:               # Host data, host collective (gloo): reading a device flag back would drain the
+                flags = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]                         # GPU queue every step
+                torch.distributed.all_gather(flags, torch.tensor([int(mosaic)]), group=flag_group)
+                mosaics = [bool(f.item()) for f in flags]
             # :276-284: "If there is at least one image in the batch using Type 2 Mosaic, 0-shot is banned."
-            S = shared_shot_num(epoch * n_iter + it, seed=args.seed, allow_zero=not mosaic)
+            if args.per_rank_shot:                   # the reference: every rank draws for ITS batch, the ban is ITS batch's
+                shots_all = rank_shot_nums(epoch * n_iter + it, world, seed=args.seed, allow_zero=[not m_ for m_ in mosaics])
+                S = shots_all[misc.get_rank()]
+            else:                                    # one draw for all ranks, so the ban is shared too: any rank with a Type-2 mosaic
+                shots_all = None
+                S = shared_shot_num(epoch * n_iter + it, seed=args.seed, allow_zero=not any(mosaics))
             step.load(imgs, boxes, gt, mask, S)
-            sums = step.step(S, lr=lr)
+            sums = step.step(S, lr=lr, shots_all=shots_all)
             err = (sums[1:1 + B] - sums[1 + B:1 + 2 * B]).abs().double()                # :296-304, no host sync
             train_acc[0] += err.mean()
             train_acc[1] += (err ** 2).mean()

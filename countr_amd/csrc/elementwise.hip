@@ -607,7 +607,8 @@ extern "C" int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, 
 }
 
 // Several device-to-device copies in ONE launch (the per-step staging of a batch: images, exemplar crops, ground-truth map, loss mask --
-// four ~5-us copy launches in front of every step otherwise).  16-byte aligned pointers and sizes.
+// four ~5-us copy launches in front of every step otherwise).  16-byte aligned pointers and sizes.  A NULL source zero-fills its
+// destination (a gradient bucket this rank has no gradient for while another rank has: per-rank shot_num, trainer.py).
 struct CopyTable { int n; const uint4* src[8]; uint4* dst[8]; long long n16[8]; int first[8]; };
 __global__ __launch_bounds__(256) void copy_multi_kernel(const CopyTable t) {
   int e = 0;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void copy_multi_kernel(const CopyTable t) {
   for (long long i = ((long long)blockIdx.x - t.first[e]) * 256 + threadIdx.x; i < n; i += stride) {
     uint4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) v[u] = s[i + (long long)u * nb * 256];
+    for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) v[u] = s ? s[i + (long long)u * nb * 256] : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) d[i + (long long)u * nb * 256] = v[u];
   }
@@ -632,7 +633,7 @@ extern "C" int countr_copy_multi(int n, const void* const* src, void* const* dst
   t.n = n;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
-    if (!src[i] || !dst[i] || bytes[i] <= 0 || (bytes[i] & 15) || (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15)) {
+    if (!dst[i] || bytes[i] <= 0 || (bytes[i] & 15) || (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15)) {      // src[i] == NULL: zero fill
       countr_set_error("countr_copy_multi: null, empty or not 16-byte aligned"); return -1;
     }
     t.src[i] = reinterpret_cast<const uint4*>(src[i]); t.dst[i] = reinterpret_cast<uint4*>(dst[i]); t.n16[i] = bytes[i] / 16;

@@ -27,6 +27,16 @@ def shared_shot_num(step, seed=0, allow_zero=True):
     return rng.randint(0 if allow_zero else 1, 3)
 
 
+def rank_shot_nums(step, world, seed=0, allow_zero=True):
+    """The reference's semantics: every rank draws its OWN shot_num per iteration (random.randint(0, 3) per process,
+    FSC_finetune_cross.py:276-284).  Here rank r's draw comes from a generator seeded by (seed, step, r), so that every rank can
+    evaluate ALL ranks' draws locally: which conditional parameter sets (exemplar CNN / shot_token) have a gradient somewhere is
+    then known without a collective (trainer.FinetuneStep(per_rank_shot=True).step(S, shots_all=...)).  `allow_zero` may be a
+    sequence with one entry per rank (the mosaic ban of :276-277 is per rank in the reference)."""
+    az = list(allow_zero) if isinstance(allow_zero, (list, tuple)) else [allow_zero] * world
+    return [random.Random(1_000_003 * seed + 7919 * (r + 1) + 104_729 * step).randint(0 if az[r] else 1, 3) for r in range(world)]
+
+
 class GradSync:
     """Bucketed sum all-reduce of a flat gradient buffer.  Buckets are contiguous [start, end) slices ordered by the time their
     gradients become final in the backward pass; start(i) launches bucket i on a side stream as soon as the caller's stream

@@ -24,6 +24,8 @@ class _GraphStep:
         self.accum = int(accum_iter)   # micro-steps per optimisation step (reference --accum_iter: loss / accum_iter, update every
         self._micro = 0                # accum_iter-th iteration -- FSC_finetune_cross.py:300-305); gradients accumulate in eng.G
         self._touched = set()          # conditional buckets that received a gradient in the current accumulation window
+        self.per_rank = False          # FinetuneStep(per_rank_shot=True): every rank draws its own shot_num (reference semantics)
+        self._touched_any = set()      # ... then: conditional buckets that received a gradient on ANY rank in this window
         self.eng = model._engine()
         self.B = batch
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -107,6 +109,27 @@ class _GraphStep:
         """(skip, zero): buckets the optimizer skips (never had a gradient) / steps with a zero gradient."""
         return (), ()
 
+    def _window_sets(self):
+        """(touched, zero_fill) at the end of an accumulation window.  touched: conditional buckets with a gradient somewhere -- they
+        are all-reduced and stepped.  zero_fill: the ones among them THIS rank has no gradient for (per-rank shot_num only): DDP with
+        find_unused_parameters=True (FSC_finetune_cross.py:230) lets such a rank contribute zeros, so its range of the flat gradient is
+        zero-filled in front of the all-reduce."""
+        if not self.per_rank:
+            return frozenset(self._touched), ()
+        touched = frozenset(self._touched_any | self._touched)
+        return touched, tuple(sorted(touched - self._touched))
+
+    def _zero_buckets(self, buckets):
+        """Zero-fill the gradient ranges of `buckets` (one countr_copy_multi launch with NULL sources: a kernel node when captured)."""
+        rng = [self.sync.buckets[b] for b in buckets if self.sync.buckets[b][1] > self.sync.buckets[b][0]]
+        if not rng:
+            return
+        n = len(rng)
+        vp = C.c_void_p * n
+        base = self.eng.G.data_ptr()
+        _lib.check(self.eng.L.countr_copy_multi(n, vp(*[None] * n), vp(*[base + 4 * s0 for s0, _e in rng]),
+                                                (C.c_int64 * n)(*[4 * (e0 - s0) for s0, e0 in rng]), self.eng._stream()), "copy_multi(zero)")
+
     def _lists(self, plan, acc):
         """The plan's backward launch lists that overwrite (first micro-step) or accumulate into (later ones) eng.G."""
         return plan.acc if acc else plan
@@ -134,6 +157,48 @@ class _GraphStep:
             self.graphs[key] = g
             return
         g.replay()
+
+    def _run_captured_comm(self, gk, whole):
+        """One communicating step as ONE graph (RCCL collectives captured with the phases).  A new key runs EAGERLY first -- outside
+        any handler: a kernel-launch, memory or RCCL error of the step itself propagates -- and is then captured.  Only a failure of
+        that CAPTURE (an RCCL build whose collectives cannot become graph nodes) selects the host-issued form, and only at the first
+        capture this step object ever attempts, where every rank is in the same place: the ranks agree on the outcome with a MIN
+        all-reduce of a flag before any of them flips GradSync.capturable, so no rank replays captured collectives against another
+        rank's host-issued ones.  Later capture failures are real errors and raise."""
+        if self._gen != self.eng.generation:
+            self.graphs.clear()
+            self._gen = self.eng.generation
+        g = self.graphs.get(gk)
+        if g is not None:
+            g.replay()
+            return
+        whole(gk[1])                      # the step itself (eager); errors propagate
+        torch.cuda.synchronize()
+        first = not getattr(self, "_capture_agreed", False)
+        g, err = None, None
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                whole(gk[1])
+        except Exception as e:  # noqa: BLE001
+            if not first:
+                raise
+            g, err = None, e
+        if first:
+            import torch.distributed as dist
+            ok = torch.tensor([0 if g is None else 1], dtype=torch.int32, device=self.eng.device)
+            torch.cuda.synchronize()
+            if self.sync.comm:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+            self._capture_agreed = True
+            if int(ok.item()) == 0:
+                import warnings
+                warnings.warn("countr_amd: capturing the RCCL all-reduces into the step graph failed on some rank (%r here); every rank "
+                              "falls back to host-issued collectives between per-phase graphs (COUNTR_GRAPH_COMM=0)" % (err,))
+                self.sync.capturable = False
+                self.sync._started = set()
+                return
+        self.graphs[gk] = g
 
     def _upload_hyper(self, skip=()):
         """Step-dependent AdamW scalars go through a small device buffer so that graph replay sees new values.  Bias corrections
@@ -309,7 +374,7 @@ class _GraphStep:
                 # costs ~20 us of idle GPU (4 launches per step before).  The AdamW scalars are uploaded first; only phase c reads them.
                 ckey = None
                 if last:
-                    skip, zero = self._adam_sets(frozenset(self._touched))
+                    skip, zero = self._adam_sets(self._window_sets()[0])
                     self._upload_hyper(skip)
                     ckey = (tuple(skip), tuple(zero))
 
@@ -321,45 +386,34 @@ class _GraphStep:
             elif self.use_graph and self.sync.capturable:
                 # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
                 # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
-                ckey, cskip = None, ()
+                ckey, cskip, zfill = None, (), ()
                 if last:
-                    touched = frozenset(self._touched)
+                    touched, zfill = self._window_sets()
                     cskip = tuple(self._comm_skip(touched))
                     skip, zero = self._adam_sets(touched)
                     self._upload_hyper(skip)
                     ckey = (tuple(skip), tuple(zero))
 
-                def whole(k, phases=phases, cskip=cskip):
+                def whole(k, phases=phases, cskip=cskip, zfill=zfill):
                     for i, (_name, fn, gkey) in enumerate(phases):
                         fn(gkey)
                         if k[1] is not None and i + 1 < len(phases):
                             self.sync.start(i)
                     if k[1] is not None:
+                        self._zero_buckets(zfill)
                         self.sync.finish(skip=cskip)
                         self._phase_c(k[1])
-                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip))
-                fresh = gk not in self.graphs
-                try:
-                    self._run_phase(gk[0], whole, gk[1])
-                except Exception as e:  # noqa: BLE001
-                    # _run_phase runs a new key EAGERLY first (the step has been done) and only then captures it: if the capture of the
-                    # collectives is what failed (an RCCL build that cannot be captured), keep the eager result, say so, and issue the
-                    # collectives from the host between per-phase graphs from now on.  Anything else is a real error.
-                    if not fresh or gk in self.graphs:
-                        raise
-                    import warnings
-                    warnings.warn("countr_amd: capturing the RCCL all-reduces into the step graph failed (%r); falling back to "
-                                  "host-issued collectives between per-phase graphs (COUNTR_GRAPH_COMM=0)" % (e,))
-                    self.sync.capturable = False
-                    self.sync._started = set()
-                    torch.cuda.synchronize()
+                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip, zfill))
+                self._run_captured_comm(gk, whole)
             else:
                 for i, (name, fn, gkey) in enumerate(phases):
                     self._run_phase(name, fn, gkey)
                     if last and i + 1 < len(phases):
                         self.sync.start(i)
                 if last:
-                    touched = frozenset(self._touched)
+                    touched, zfill = self._window_sets()
+                    if zfill:
+                        self._run_phase("z", self._zero_buckets, zfill)
                     self.sync.finish(skip=tuple(self._comm_skip(touched)))
                     skip, zero = self._adam_sets(touched)
                     self._upload_hyper(skip)
@@ -369,6 +423,7 @@ class _GraphStep:
             self.model.mark_weights_synced()
             self._micro = 0
             self._touched = set()
+            self._touched_any = set()
         else:
             self._micro += 1
         return last
@@ -376,8 +431,13 @@ class _GraphStep:
 
 class FinetuneStep(_GraphStep):
     def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None, accum_iter=1):
+                 process_group=None, accum_iter=1, per_rank_shot=False):
+        """per_rank_shot: the reference's semantics (FSC_finetune_cross.py:276-284 draws shot_num per RANK; DDP's
+        find_unused_parameters=True at :230 makes differing parameter subsets legal): step(S, shots_all=...) takes this rank's
+        shot_num and every rank's; a conditional bucket (exemplar CNN / shot_token) some rank has a gradient for is all-reduced by
+        EVERY rank -- zero-filled on the ranks without one -- and stepped by every rank, so parameters stay identical."""
         super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter)
+        self.per_rank = bool(per_rank_shot)
         self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
         self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
@@ -410,7 +470,7 @@ class FinetuneStep(_GraphStep):
 
     def _comm_skip(self, touched):
         """Conditional buckets without a gradient in this window (exemplar CNN when every micro-step had shot_num 0, shot_token
-        when none had) are not all-reduced: their gradient is None / zero on every rank (shot_num is shared)."""
+        when none had) are not all-reduced: their gradient is None / zero on every rank (`touched` is the union over ranks)."""
         return tuple(b for b in (2, 3) if b not in touched)
 
     def _adam_sets(self, touched):
@@ -490,14 +550,31 @@ class FinetuneStep(_GraphStep):
                    "copy_multi")
         return True
 
-    def step(self, S, lr=None):
+    def step(self, S, lr=None, shots_all=None):
         """One (micro-)step on the inputs last given to load(): with accum_iter == k, every k-th call reduces the accumulated
         gradients and applies AdamW (self.applied tells which).  Returns the device tensor
-        [loss, pred counts (B), gt counts (B)] of this batch without synchronising the host."""
+        [loss, pred counts (B), gt counts (B)] of this batch without synchronising the host.
+        per_rank_shot mode: S is THIS rank's shot_num and shots_all the shot_num of every rank of the group in this micro-step (e.g.
+        parallel.rank_shot_nums: seeded per-rank draws every rank can evaluate -- no communication); without shots_all the ranks
+        all-gather their S (a host-synchronous collective per step)."""
         if lr is not None:
             self.lr = lr
+        if self.per_rank:
+            if shots_all is None:
+                shots_all = self._gather_shots(S)
+            self._touched_any |= {3 if int(s_) == 0 else 2 for s_ in shots_all}
         self.applied = self._step(S)
         return self.sums[S]
+
+    def _gather_shots(self, S):
+        import torch.distributed as dist
+        if self.world <= 1:
+            return [S]
+        dev = self.eng.device if dist.get_backend(self.pg) == "nccl" else "cpu"
+        mine = torch.tensor([int(S)], dtype=torch.int64, device=dev)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.pg)
+        return [int(t.item()) for t in out]
 
     def grad_norm(self):
         """Device scalar: L2 norm of the (averaged) gradients the last optimizer step consumed -- get_grad_norm_ of

@@ -228,7 +228,8 @@ int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int
 /* weight shadows: mode 0 cast, 1 OIHW->OHWI, 2 conv-dgrad form Wd[ci][tap'][co] = W[co][ci][T-1-tap'] */
 /* up to 8 device-to-device copies in one launch (src / dst / bytes are HOST arrays; 16-byte aligned pointers and sizes): the
  * per-iteration staging of a batch -- `samples.to(device)`, `boxes.to(device)`, `gt_density.to(device)` and the fresh loss mask of
- * FSC_finetune_cross.py:270-296 -- into the static input buffers of a plan. */
+ * FSC_finetune_cross.py:270-296 -- into the static input buffers of a plan.  src[i] == NULL zero-fills dst[i] (the gradients DDP's
+ * find_unused_parameters=True, FSC_finetune_cross.py:230, contributes for parameters a rank did not use in an iteration). */
 int countr_copy_multi(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
 int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co, int Ci, int taps, int dtype,
                         void* stream);

@@ -16,6 +16,8 @@ import torch.nn as nn  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 SHOTS = [3, 0, 3, 1]
+# per-rank shot_num (reference semantics, FSC_finetune_cross.py:276-284): PRS[it][rank]
+PRS = [[3, 0], [0, 0], [1, 3], [0, 2]]
 
 
 def finetune_model(precision="fp32"):
@@ -51,6 +53,24 @@ def run_finetune(rank, world, per_rank, use_graph=True):
         losses.append(step.step(S)[0].item())
     torch.cuda.synchronize()
     m._graph_kinds = sorted({k[0] for k in step.graphs})
+    return m, losses
+
+
+def run_finetune_per_rank_shot(rank, world, per_rank, use_graph=True):
+    """Every rank steps ITS half of the batch with ITS OWN shot_num; the last iteration lets the ranks all-gather the counts."""
+    from countr_amd.trainer import FinetuneStep
+    m = finetune_model()
+    step = FinetuneStep(m, batch=per_rank, lr=1e-3, weight_decay=0.05, eps=1e-4, use_graph=use_graph, per_rank_shot=True)
+    losses = []
+    for it, shots in enumerate(PRS):
+        S = shots[rank]
+        imgs, boxes, gt, mask = W.make_inputs(batch=per_rank * world, shots=3, seed=140 + it)
+        sl = slice(rank * per_rank, (rank + 1) * per_rank)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs[sl], boxes[sl], gt[sl], mask)), S)
+        losses.append(step.step(S, shots_all=shots if it + 1 < len(PRS) else None)[0].item())
+    torch.cuda.synchronize()
+    m._graph_kinds = sorted({k[0] for k in step.graphs})
+    m._group_steps = list(step.eng.group_steps)
     return m, losses
 
 
@@ -98,11 +118,14 @@ if __name__ == "__main__":
     if what == "finetune_real":
         m, losses = run_finetune_real(rank, world)
         keep = lambda k: k.startswith(("decoder", "decode_head", "shot_token"))
+    elif what == "finetune_prs":
+        m, losses = run_finetune_per_rank_shot(rank, world, 2)
+        keep = lambda k: True
     else:
         m, losses = (run_finetune if what == "finetune" else run_pretrain)(rank, world, 2 if world > 1 else 4)
         keep = lambda k: True
     torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters() if keep(k)}, "losses": losses,
-                "graph_kinds": getattr(m, "_graph_kinds", None)},
+                "graph_kinds": getattr(m, "_graph_kinds", None), "group_steps": getattr(m, "_group_steps", None)},
                os.path.join(outdir, "%s_rank%d.pt" % (what, rank)))
     dist.barrier()
     dist.destroy_process_group()

@@ -77,6 +77,92 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_prs(rank, world, port, out):
+    """Per-rank shot_num (reference semantics): rank 0 runs shot_num 3, rank 1 shot_num 0 on its half-batch; the flat gradient with the
+    locally unused conditional bucket ZERO-FILLED, all four buckets reduced, must equal the sum of the oracle's two half-batch
+    gradients (None -> 0), i.e. world x the mean gradient DDP(find_unused_parameters=True) hands to AdamW."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import math
+        from countr_amd.engine import ParamLayout
+        from countr_amd.parallel import GradSync, rank_shot_nums
+        from oracle import countr_ref as R, weights as W
+        torch.set_num_threads(4)
+        name = "tiny_test"
+        sd = W.make_state_dict(name, seed=3)
+        lay = ParamLayout([(k, tuple(v.shape)) for k, v in sd.items()])
+        shots = [3, 0]
+        imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=4)
+
+        def flat_of(r):
+            _, _, g = R.loss_and_grads(sd, imgs[r:r + 1], boxes[r:r + 1], gt[r:r + 1], mask, shots[r], name, dtype=torch.float64)
+            f = torch.full((lay.n_train,), float("nan"), dtype=torch.float64)      # NaN = "never written by this rank's backward"
+            for k in lay.train_names:
+                o = lay.off[k] - lay.train_start
+                n = math.prod(lay.shapes[k])
+                pad = -(-n // 4) * 4
+                f[o:o + pad] = 0
+                if g.get(k) is not None:
+                    f[o:o + n] = g[k].reshape(-1)
+            return f, g
+        mine, g_mine = flat_of(rank)
+        touched_local = {3 if shots[rank] == 0 else 2}
+        touched_any = {3 if s == 0 else 2 for s in shots}
+        assert touched_any == {2, 3}
+        # the locally untouched conditional bucket holds whatever the last step left there: poison it, then zero-fill (what the step does)
+        for b in touched_any - touched_local:
+            lo, hi = lay.bucket_range(b)
+            assert all(g_mine.get(k) is None for k in lay.train_names if lo <= lay.off[k] - lay.train_start < hi)
+            mine[lo:hi] = float("nan")
+            mine[lo:hi] = 0
+        mine = torch.nan_to_num(mine, nan=0.0)        # alignment padding between tensors
+        sync = GradSync(mine, None, None, buckets=[lay.bucket_range(b) for b in range(4)])
+        sync.start(0); sync.start(1)
+        sync.finish(skip=tuple(b for b in (2, 3) if b not in touched_any))
+        other, _ = flat_of(1 - rank)
+        for b in touched_any - {3 if shots[1 - rank] == 0 else 2}:
+            lo, hi = lay.bucket_range(b)
+            other[lo:hi] = 0
+        other = torch.nan_to_num(other, nan=0.0)
+        mine_again = torch.nan_to_num(flat_of(rank)[0], nan=0.0)
+        for b in touched_any - touched_local:
+            lo, hi = lay.bucket_range(b)
+            mine_again[lo:hi] = 0
+        assert torch.allclose(mine, mine_again + other, atol=1e-12)
+        # both conditional sets now carry a non-zero reduced gradient on BOTH ranks
+        for b in (2, 3):
+            lo, hi = lay.bucket_range(b)
+            assert mine[lo:hi].abs().max() > 0, b
+        # every rank can evaluate every rank's draw: same list everywhere, own entry = own draw, the ban is per rank
+        a = rank_shot_nums(11, world, seed=5)
+        allv = [None] * world
+        dist.all_gather_object(allv, a)
+        assert allv[0] == allv[1] and all(0 <= s <= 3 for s in a)
+        assert all(rank_shot_nums(t, world, seed=5, allow_zero=[False, True])[0] >= 1 for t in range(64))
+        assert {tuple(rank_shot_nums(t, world, seed=5)) for t in range(64)} != {(s, s) for s in range(4)}   # the ranks' draws differ
+        out.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_per_rank_shot_num_zero_filled_buckets_sum_to_the_oracle_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_prs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
 def test_two_rank_gradient_sync_and_adamw():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -60,6 +60,46 @@ def test_two_ranks_on_one_gpu_match_single_process(what, tmp_path):
             assert d.max().item() <= 0.3 * lr * n_steps, (k, d.max().item())
 
 
+def test_per_rank_shot_num_matches_oracle_mean_gradient(tmp_path):
+    """Reference semantics of the only multi-GPU path: every rank draws its own shot_num (FSC_finetune_cross.py:276-284) and DDP with
+    find_unused_parameters=True (:230) averages whatever gradients exist -- a parameter set unused on one rank contributes zeros, one
+    unused on EVERY rank keeps grad None and is skipped by AdamW.  Two ranks (gloo, one GPU, graph replay) with the schedule
+    rank 0: [3, 0, 1, 0], rank 1: [0, 0, 3, 2] against the oracle: gradients of each half-batch under its own shot_num, averaged, fed
+    to the real torch.optim.AdamW.  Iteration 0: rank 0 has no shot_token gradient, rank 1 none for the exemplar CNN -- both sets are
+    reduced (zero-filled where absent) and stepped; iteration 1: the exemplar CNN is stepped with a zero gradient (torch 1.13
+    zero_grad leaves zeros); the last iteration's counts are all-gathered instead of passed in."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_gpu_worker as Wk
+    from test_trainer_gpu import TorchAdamW
+    from oracle import countr_ref as R, weights as W
+    r0, r1 = launch("finetune_prs", tmp_path)
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k            # ranks stay bit-identical
+    assert r0["group_steps"] == [4, 4, 4] and r1["group_steps"] == [4, 4, 4]
+    lr, name = 1e-3, "tiny_test"
+    sd = W.make_state_dict(name, seed=3)
+    ref = TorchAdamW(sd, lr, 1e-4)
+    for it, shots in enumerate(Wk.PRS):
+        imgs, boxes, gt, mask = W.make_inputs(batch=4, shots=3, seed=140 + it)
+        cur = ref.state_dict_f32(sd)
+        for r, S in enumerate(shots):
+            sl = slice(2 * r, 2 * r + 2)
+            _out, rloss, rg = R.loss_and_grads(cur, imgs[sl], boxes[sl], gt[sl], mask, S, name)
+            got = (r0, r1)[r]["losses"][it]
+            assert abs(got - rloss.item()) <= 2e-3 * abs(rloss.item()), (it, r, S, got, rloss.item())
+            ref.accumulate(rg, scale=0.5)
+        ref.step()
+    n = len(Wk.PRS)
+    for k, v in ref.p.items():
+        d = (r0["params"][k].double() - v.detach()).abs()
+        assert d.pow(2).mean().sqrt().item() <= 0.03 * lr * n, (k, d.pow(2).mean().sqrt().item())
+        if not k.startswith("decoder_proj"):
+            assert d.max().item() <= 0.25 * lr * n, (k, d.max().item())
+    # shot_token and the exemplar CNN both moved in iteration 0 although each was unused on one rank
+    assert not np.array_equal(r0["params"]["shot_token"].numpy(), sd["shot_token"])
+
+
 def test_two_ranks_at_the_real_config(tmp_path):
     """The same two-rank step at BASELINE config 3's per-GPU shape -- ViT-B/16, bf16, 8 images per rank, graph replay (the tiny fp32
     model above proves the arithmetic, this one the production plans: lean GEMM kernels, fused attention backward, 4 buckets of

@@ -730,3 +730,125 @@ def test_lean_linear_layernorm_folding(hip, M, N2, act):
     # the generic kernel refuses the fields loudly (no silent un-normalised result)
     c.N = 1536 + 4
     assert hip.countr_gemm(C.byref(c), 1, 0, 0, _stream()) != 0
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 3072, 768), (2880, 3072, 768), (256, 256, 256), (1000, 512, 384), (4608, 2304, 768), (8192, 1024, 1280),
+                                   (40, 256, 256), (4608, 2048, 512)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "gelu_pre"])
+def test_g256_linear_matches_fp64_and_lean(hip, monkeypatch, M, N, K, epi):
+    """csrc/gemm256.hip (256 x 256 workgroup tile, 8 waves that stage AND multiply on the two-k-tile phase schedule, counted vmcnt,
+    M halves one barrier apart) through countr_gemm with COUNTR_G256=2 (wherever it qualifies): fc1's shape (the one it serves in the
+    step), ragged last row tiles (B = 5 images; 1000 and 40 rows: rows beyond M stage zeros and are never stored), the shortest
+    legal K (4 k-tiles: prologue and drain overlap), K = 20 k-tiles; every epilogue; against torch fp64 and against the 128-row
+    forms of linear.hip (COUNTR_G256=0).
+    The launch is repeated: a phase-schedule race (an LDS-DMA unit read before the barrier that orders it) shows as run-to-run
+    differences long before it shows against fp64."""
+    A = _mk((M, K), torch.bfloat16, 121)
+    W = (_mk((N, K), torch.float32, 122) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 123)
+    z = A.double() @ W.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(z) if epi.startswith("gelu") else z
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("COUNTR_G256", mode)
+        runs = []
+        for rep in range(3 if mode == "2" else 1):
+            out = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.bfloat16)     # 8 guard rows behind M
+            pre = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) if epi == "gelu_pre" else None
+            a = _lib.GemmArgs()
+            a.A, a.B, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+            a.C2 = pre.data_ptr() if pre is not None else None
+            a.bias = bias.data_ptr()
+            a.lda, a.ldb, a.ldc = K, K, N
+            a.M, a.N, a.K = M, N, K
+            a.act = 1 if epi.startswith("gelu") else 0
+            a.out_bf16 = 1
+            a.alpha = 1.0
+            a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+            _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+            torch.cuda.synchronize()
+            assert torch.isnan(out[M:].float()).all()                    # nothing stored behind the last row
+            out = out[:M]
+            assert torch.isfinite(out.float()).all()
+            scale = ref.abs().max().item()
+            assert (out.double() - ref).abs().max().item() <= 4e-3 * scale + 3e-5, (mode, (out.double() - ref).abs().max().item(), scale)
+            if pre is not None:
+                assert (pre.double() - z).abs().max().item() <= 4e-3 * z.abs().max().item()
+            runs.append(out)
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0]), "run-to-run difference (phase-schedule race)"
+        outs[mode] = runs[0]
+    d = (outs["2"].double() - outs["0"].double()).abs().max().item()
+    assert d <= 8e-3 * ref.abs().max().item(), d
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 3072, 768), (1152, 1536, 512), (300, 256, 256)])
+def test_g256_linear_layernorm_consumer(hip, monkeypatch, M, N, K):
+    """The LayerNorm-fold consumer epilogue of the 256 x 256 kernel (fc1 in the frozen encoder: rstd (acc - mean colsum) + bias' from the
+    producer's per-64-column {sum, sum of squares} row partials) against the same launch on linear.hip's kernel and against fp64."""
+    x = _mk((M, K), torch.float32, 131) * 2.0 + _mk((M, 1), torch.float32, 132)
+    xb = x.to(torch.bfloat16)
+    W = (_mk((N, K), torch.float32, 133) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 134)
+    xs = x.double()                                   # statistics of the fp32 row (what the producer's epilogue sums)
+    stats = torch.stack([xs.view(M, K // 64, 64).sum(-1), (xs * xs).view(M, K // 64, 64).sum(-1)], dim=-1).float().contiguous()
+    colsum = W.double().sum(1).float().contiguous()
+    mean = xs.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(xs.var(1, unbiased=False, keepdim=True) + 1e-6)
+    ref = torch.nn.functional.gelu(rstd * (xb.double() @ W.double().t() - mean * colsum.double()) + bias.double())
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("COUNTR_G256", mode)
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C, a.bias = xb.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr()
+        a.lda, a.ldb, a.ldc = K, K, N
+        a.M, a.N, a.K = M, N, K
+        a.act, a.out_bf16, a.alpha = 1, 1, 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        a.ln_stats, a.ln_colsum, a.ln_nblk, a.ln_eps = stats.data_ptr(), colsum.data_ptr(), K // 64, 1e-6
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert (out.double() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item() + 3e-5, mode
+        outs[mode] = out
+    assert (outs["2"].double() - outs["0"].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout,use_bias", [(2, 96, 96, 256, 256, True), (1, 192, 192, 256, 256, True), (8, 48, 48, 512, 256, False),
+                                                   (3, 100, 100, 128, 512, True), (32, 24, 24, 256, 256, True), (1, 20, 12, 128, 256, True)])
+def test_g256_conv3x3_matches_fp64_and_lean(hip, monkeypatch, Bsz, H, W, Cin, Cout, use_bias):
+    """3x3 convolution forward / dgrad on the 256 x 256 8-phase kernel (im2row LDS-DMA descriptors: tap shifts as scalar offsets, padding
+    taps and ragged rows as lanes pushed outside the descriptor) with COUNTR_G256=2: against torch conv2d in fp64 and against the
+    128x256 form of linear.hip on the same bf16 maps -- zero padding at every border, tiles that span image boundaries (100 x 100,
+    24 x 24 = 2.25 images per tile), a map smaller than one tile (20 x 12: most staged rows are masked), Cin = 128 / 256 / 512
+    (2 / 4 / 8 k-tiles per tap), with and without bias; three runs must agree bit for bit (race screen)."""
+    x = _mk((Bsz, H, W, Cin), torch.bfloat16, 151)
+    w = (_mk((Cout, 3, 3, Cin), torch.float32, 152) * 0.1).to(torch.bfloat16)
+    bias = _mk((Cout,), torch.float32, 153) if use_bias else None
+    M, K = Bsz * H * W, 9 * Cin
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double() if use_bias else None, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("COUNTR_G256", mode)
+        runs = []
+        for rep in range(3 if mode == "2" else 1):
+            out = torch.full((M, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            a = _lib.GemmArgs()
+            a.A, a.B, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+            a.bias = bias.data_ptr() if use_bias else None
+            a.ldb, a.ldc = K, Cout
+            a.M, a.N, a.K = M, Cout, K
+            a.H, a.W, a.Cin = H, W, Cin
+            a.out_bf16, a.alpha = 1, 1.0
+            a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+            _lib.check(hip.countr_gemm(C.byref(a), 1, 2, 0, _stream()), "conv")
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all()
+            assert (out.double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item(), mode
+            runs.append(out)
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0]), "run-to-run difference (phase-schedule race)"
+        outs[mode] = runs[0]
+    assert (outs["2"].double() - outs["0"].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()
