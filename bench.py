@@ -195,6 +195,41 @@ def family_breakdown(model, step, batch, passes=5):
            "us_per_step": {k: round(v, 1) for k, v in us.items()}}
     for k, g in gf.items():
         out[k] = {"achieved": g / (us[k] * 1e-6) / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": g / (us[k] * 1e-6) / MFMA_BF16_PEAK}
+    # algorithmic bytes of the GEMM families: every launch's operands once + its result once (split-K slabs, re-reads of an im2row
+    # operand per column tile, fp32 partials are NOT algorithmic: they show up as traffic above this figure)
+    alg = {"linear": 0, "conv": 0}
+    nl = {"linear": 0, "conv": 0}
+    for fn, args, keep in seq:
+        if fn is not L.countr_gemm or keep is None:
+            continue
+        f = fam(fn, args)
+        es = 2 if args[1] == 1 else 4
+        a = keep
+        nb = max(a.nbatch, 1)
+        if args[2] == 2:       # IM2ROW: the NHWC map once
+            bytes_a = (a.M * a.Cin) * es
+        elif args[3] == 3:     # (COL, IM2COL) wgrad: dy [P, Cout] and the map [P, Cin]
+            bytes_a = a.K * a.M * es
+        else:
+            bytes_a = a.M * a.K * es * nb
+        bytes_b = (a.K * a.Cin * es) if args[3] == 3 else a.N * a.K * es * nb
+        bytes_c = a.M * a.N * ((2 if a.out_bf16 else 4) if not a.partial else 4) * nb
+        extra = (a.M * a.N * 4 if a.resid else 0) + (a.M * a.N * 2 if (a.C2 and a.act == 1) else 0)
+        alg[f] += bytes_a + bytes_b + bytes_c + extra
+        nl[f] += 1
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r4_family_traffic.json")))
+    except Exception:  # noqa: BLE001
+        pass
+    for k in ("linear", "conv"):
+        out[k]["algorithmic_bytes"] = alg[k]
+        out[k]["gemm_launches"] = nl[k]
+        t = (traffic or {}).get(k) if batch == 8 else None
+        out[k]["traffic"] = t["traffic_bytes_per_step"] if t else None
+        out[k]["traffic_over_algorithmic"] = (t["traffic_bytes_per_step"] / alg[k]) if t else None
+        out[k]["traffic_source"] = ("static: profiles/r4_family_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over the eager "
+                                    "step, tools/pmc_step.sh: per step, all launches of the family), not measured in this run") if t else None
     return out
 
 
@@ -203,29 +238,27 @@ PRETRAIN_GF_PER_IMG = 3 * (288 * 12 * 2 * (12 * 768 * 768) + 12 * 4 * 288 * 288 
                            + 2 * (288 * 768 * 768 + 288 * 768 * 512 + 576 * 512 * 768))    # embeds + pixel head; x3 = fwd+bwd
 
 
-def bench_pretrain(args, world, rank, dev):
-    """MAE pretraining step (FSC_pretrain.py:254-301; mask_ratio 0.5, batch 8 per GPU by default): not the BASELINE.json
-    metric -- selected explicitly with --workload pretrain."""
+def time_pretrain(args, world, rank, dev, batch, steps, warmup):
+    """MAE pretraining step (FSC_pretrain.py:254-301; mask_ratio 0.5): (seconds for `steps` steps, max over ranks; last loss)."""
     import models_mae_noct
     from countr_amd.trainer import PretrainStep
     torch.manual_seed(rank)
     model = models_mae_noct.__dict__["mae_vit_base_patch16"](norm_pix_loss=False, precision=args.precision)
     model.to(dev).train()
-    B = args.batch
-    step = PretrainStep(model, batch=B, mask_ratio=0.5, lr=5e-6, weight_decay=0.05, use_graph=not args.no_graph)
-    imgs = torch.rand(B, 3, 384, 384, device=dev)
+    step = PretrainStep(model, batch=batch, mask_ratio=0.5, lr=5e-6, weight_decay=0.05, use_graph=not args.no_graph)
+    imgs = torch.rand(batch, 3, 384, 384, device=dev)
 
     def one():
         step.load(imgs)          # draws a fresh masking permutation (torch.rand + argsort) every step, as the reference
         return step.step()
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = one()
     torch.cuda.synchronize()
     if world > 1:
@@ -236,7 +269,13 @@ def bench_pretrain(args, world, rank, dev):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    lv = loss.item()
+    return dt, loss.item()
+
+
+def bench_pretrain(args, world, rank, dev):
+    """MAE pretraining step (batch 8 per GPU by default): not the BASELINE.json metric -- selected explicitly with --workload pretrain."""
+    B = args.batch
+    dt, lv = time_pretrain(args, world, rank, dev, B, args.steps, args.warmup)
     if rank == 0:
         ips = world * B * args.steps / dt
         print(json.dumps({
@@ -252,10 +291,10 @@ def bench_pretrain(args, world, rank, dev):
         dist.destroy_process_group()
 
 
-def bench_infer(args, world, rank, dev):
+def time_infer(args, world, rank, dev, steps, warmup):
     """BASELINE.json configs[4]: zero-shot sliding-window inference (demo_zero.py:41-74) on 1920x1080 frames -- resized to
     384 x 672 they give 4 windows each, so 8 frames = one forward batch of 32 windows (shot_num = 0, shot_token path), then the
-    per-column blend.  Replicas only: every rank counts its own frames, no collective.  Selected with --workload infer."""
+    per-column blend.  -> (seconds for `steps` passes over 8 frames, max over ranks; mean count)."""
     import models_mae_cross
     from countr_amd import inference
     from countr_amd.synthetic import wide_frames
@@ -268,14 +307,14 @@ def bench_infer(args, world, rank, dev):
     def one():
         dms = inference.density_maps(model, frames, empty, 0, max_batch=32)
         return torch.stack([d.sum() for d in dms]) / 60
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         cnt = one()
     torch.cuda.synchronize()
     if world > 1:
@@ -286,18 +325,42 @@ def bench_infer(args, world, rank, dev):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    return dt, float(cnt.mean().item())
+
+
+def bench_infer(args, world, rank, dev):
+    """Replicas only: every rank counts its own frames, no collective.  Selected with --workload infer."""
+    dt, mean_count = time_infer(args, world, rank, dev, args.steps, args.warmup)
     if rank == 0:
-        ips = world * len(frames) * args.steps / dt
+        ips = world * 8 * args.steps / dt
         print(json.dumps({
             "metric": "frames/sec (1920x1080 -> 384x672, zero-shot sliding window, 4 windows per frame)", "value": ips, "unit": "frames/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "zero-shot inference ViT-B/16 (mae_vit_base_patch16), 8 frames x 4 windows = batch 32 per GPU, "
                                    "forward + sliding-window blend + counts", "global_batch": world * 32, "parallelism": "replicas%d" % world},
-            "windows_per_sec": 4 * ips, "mean_count": float(cnt.mean().item()), "fwd_tflops": 180.89e9 * 4 * ips / 1e12}))
+            "windows_per_sec": 4 * ips, "mean_count": mean_count, "fwd_tflops": 180.89e9 * 4 * ips / 1e12}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_workloads(args, dev, steps=10, warmup=3):
+    """BASELINE configs[3] and [4] at their single-GPU shapes, timed in the SAME process as the headline so that the driver's one
+    `python bench.py` run clocks all three single-GPU workloads: MAE pretraining step at 16 images per GPU and
+    zero-shot inference on 8 frames = 32 windows (C5); `steps` timed steps each behind `warmup` untimed ones."""
+    out = {}
+    dt, loss = time_pretrain(args, 1, 0, dev, 16, steps, warmup)
+    out["pretrain"] = {"ms_per_step": 1e3 * dt / steps, "images_per_sec": 16 * steps / dt, "batch": 16, "steps": steps, "final_loss": loss,
+                       "step_tflops": PRETRAIN_GF_PER_IMG * 16 * steps / dt / 1e12,
+                       "workload": "MAE pretrain ViT-B/16 + 8x512-d decoder, mask_ratio 0.5: masking + fwd + all-patch MSE + full bwd + AdamW"}
+    torch.cuda.empty_cache()
+    dt, cnt = time_infer(args, 1, 0, dev, steps, warmup)
+    out["infer"] = {"ms_per_32_windows": 1e3 * dt / steps, "frames_per_sec": 8 * steps / dt, "windows_per_sec": 32 * steps / dt, "steps": steps,
+                    "mean_count": cnt, "fwd_tflops": 180.89e9 * 32 * steps / dt / 1e12,
+                    "workload": "zero-shot sliding-window inference, 8 frames 1920x1080 -> 384x672 = one forward of 32 windows + blend + counts"}
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -312,6 +375,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip roofline_b32 (profiling runs: keeps the attention kernel's launches of the "
                                                            "kernel-stats CSV at the one problem size of the step)")
+    ap.add_argument("--plain", action="store_true", help="counter / trace runs: warm-up + the timed blocks only -- no shot-mix loop, no roofline "
+                                                          "passes, no other workloads, no CPU baseline (every launch of the run belongs to a headline step)")
+    ap.add_argument("--no-families", action="store_true", help="skip roofline_families (counter runs: no eager event-bracketed replay)")
+    ap.add_argument("--no-other", action="store_true", help="skip other_workloads (pretrain / inference timed beside the headline)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="finetune only: batches start in pinned HOST memory (the DataLoader's hand-over) -> the PCIe-inclusive rate "
                          "quoted in DESIGN.md; never the headline value (inputs are HBM-resident there)")
@@ -417,6 +484,15 @@ def main():
             step.sync.capturable = True
     # the reference draws shot_num uniformly from 0..3 per iteration (FSC_finetune_cross.py:276-284): same loop on that mix,
     # reported beside the headline (shot_num = 3) number
+    if args.plain:
+        if rank == 0:
+            print(json.dumps({"metric": "images/sec (384x384, 3 exemplars) FSC147 finetune step", "value": world * B * args.steps / dt, "unit": "images/sec",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "plain": True,
+                              "hipgraph": not args.no_graph, "dtype": args.precision, "data": "synthetic"}))
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from countr_amd.parallel import shared_shot_num
     mix = [shared_shot_num(i, seed=0) for i in range(args.steps)]
     for S in sorted(set(mix) | {0, 1, 2}):
@@ -453,7 +529,8 @@ def main():
                                  "note": "whole step per GPU: 321.16 GF algorithmic per image (SURVEY 8d) x images/s; the sustained full-chip matrix peak "
                                          "is 2.0 PF (1.92 GHz under load), and the GEMM family is bound by the LDS-DMA path (~42 B/clk per CU), DESIGN.md"}
         if world == 1:
-            line["roofline_families"] = family_breakdown(model, step, B)
+            if not args.no_families:
+                line["roofline_families"] = family_breakdown(model, step, B)
             if not args.no_b32:
                 # BASELINE configs[4]: the same kernel at 32 windows (zero-shot inference plan), amortising the per-launch fixed cost
                 model.eval()
@@ -472,6 +549,9 @@ def main():
                                  "note": "buckets in backward-completion order (head | decoder blocks | exemplar CNN | shot_token); every bucket but "
                                          "the last is all-reduced on a side stream under the next backward phase; exposed_comm_us = median time the "
                                          "step stream waited in GradSync.finish() (measured in the host-issued mode: event pairs cannot be captured)"}
+        if world == 1 and not args.no_other and not args.no_graph:
+            del step
+            line["other_workloads"] = other_workloads(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

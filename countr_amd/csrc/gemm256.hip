@@ -47,6 +47,7 @@ struct BigArgs {
   int M, N, K;
   int lda, ldw, ldc;   // elements
   int tilesN;
+  int launch_tiles;    // tiles this launch covers (the first ones of the problem; the rest may run as a tail launch of linear.hip's kernel)
   int H, Wd, Cin, cpt_log;   // CONV: k-tiles per tap = Cin / 64 = 1 << cpt_log
   const float* stats_in;     // LN consumer (see linear.hip): [M][K/64][2]
   const float* colsum;       // [N]
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
           s2 += __uint_as_float(lnv[b2][1]) + __uint_as_float(lnv[b2][3]);
         }
       }
-      const float inv = 1.f / (float)g.K, mean = s1 * inv, var = fmaxf(s2 * inv - mean * mean, 0.f);
+      // (explicit fma: the two kernels that serve this epilogue -- linear.hip, gemm256.hip -- must not differ by a compiler's contraction choice)
+      const float inv = 1.f / (float)g.K, mean = s1 * inv, ex2 = s2 * inv, var = fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f);
       const float rs = rsqrtf(var + g.ln_eps);
       const uint32_t sa = lds_u32(smem) + LNST_OFF + tid * 8;
       asm volatile("ds_write_b64 %0, %1" ::"v"(sa), "v"(make_float2(mean, rs)) : "memory");   // (asm: a compiler-visible LDS store would wait vmcnt(0))
@@ -529,7 +531,7 @@ int launch_big(const BigArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g256_kernel<CONV, EPI, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((g256_kernel<CONV, EPI, LN>), dim3(((a.M + 255) / 256) * a.tilesN), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((g256_kernel<CONV, EPI, LN>), dim3(a.launch_tiles), dim3(512), LDS_BYTES, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(256x256 8-phase)");
 }
 
@@ -576,6 +578,7 @@ int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
   BigArgs g;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = bias;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = a->N / 256;
+  g.launch_tiles = (int)tiles;
   g.H = g.Wd = g.Cin = g.cpt_log = 0; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps; g.stamps = nullptr;
 #ifdef G256_STAMP
   g.stamps = (float*)a->C2; g.C2 = nullptr;
@@ -584,7 +587,13 @@ int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
   return epi == EPI_BF16 ? launch_big<false, EPI_BF16, false>(g, s) : launch_big<false, EPI_GELU, false>(g, s);
 }
 
+int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0);     // linear.hip
+
 // 3x3 convolution forward / dgrad as implicit GEMM (A = IM2ROW view of an NHWC bf16 map, B = [Cout][9 Cin] weights) on 256 x 256 tiles.
+// Split rounds: a grid of 4.5 rounds of workgroups (the 192x192 map at B = 8: 1152 tiles on 256 CUs) costs five tile-times, the last
+// one on half the chip.  When the tiles behind the last FULL round are at most half a round, those rows run as a tail launch of
+// linear.hip's 128 x 256 kernel instead (twice the workgroups at half the work each: one full round of a ~0.6x tile-time).  Results
+// do not depend on the split: the two kernels agree bit for bit (tests/test_gemm_gpu.py).
 int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   const int mode = env_int("COUNTR_G256", 1);
   if (mode == 0) return 1;
@@ -598,16 +607,30 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   if ((a->ldb % 8) || (a->ldc % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15)) return 1;
   if ((int64_t)(a->M + 2 * a->W + 2 + 256) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
-  const long tiles = (long)((a->M + 255) / 256) * (a->N / 256);
-  if (mode == 1) {
+  const long tilesN = a->N / 256, tiles = (long)((a->M + 255) / 256) * tilesN;
+  // split rounds (COUNTR_G256_SPLIT=0: never): full rounds here, at most half a round of tiles behind them on the 128-row kernel
+  long head = tiles;
+  {
+    const long full = (tiles / 256) * 256, rem = tiles - full;
+    if (env_int("COUNTR_G256_SPLIT", 1) && full >= 256 && rem > 0 && rem <= 128 && (full % tilesN) == 0 && mode != 0) head = full;
+  }
+  if (mode == 1 && head == tiles) {
     const long rounds = (tiles + 255) / 256;
     if (tiles < 200 || tiles * 100 < rounds * 256 * 80) return 1;
   }
   const float* bias = a->bias ? a->bias : zero_bias_vec();
   if (!bias) return 1;
+  if (head < tiles) {
+    // the tail first checks that it qualifies (same conditions as ours, plus its own) by launching: it runs BEHIND the head on the stream
+    // either way, so launch order on the host is free; launching it first lets a refusal fall back to the single launch
+    const int rc = countr_lean_conv_rows(a, s, (int)(head / tilesN) * 256);
+    if (rc < 0) return rc;
+    if (rc == 1) head = tiles;
+  }
   BigArgs g;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = nullptr; g.bias = bias;
-  g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = a->N / 256;
+  g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = (int)tilesN;
+  g.launch_tiles = (int)head;
   g.H = a->H; g.Wd = a->W; g.Cin = a->Cin; g.cpt_log = a->Cin == 128 ? 1 : a->Cin == 256 ? 2 : 3;
   g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f; g.stamps = nullptr;
 #ifdef G256_STAMP

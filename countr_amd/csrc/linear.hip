@@ -48,6 +48,7 @@ struct LinArgs {
   int M, N, K;
   int lda, ldw, ldc, ldres;   // elements
   int res_mod, tilesN;
+  int tile_m0;         // first row tile of this launch (a launch may cover the LAST row tiles of a problem only: gemm256.hip's split rounds)
   int H, Wd, Cin;      // CONV (3x3, pad 1, NHWC): A is the map [B, H, Wd, Cin], row m = pixel, k = tap * Cin + c
   // LayerNorm folding (LN template flag).  Producer (EPI_RES): xcopy = bf16 copy of the fp32 output, stats_out[m][N/64][2] = {sum, sum of
   // squares} of the fp32 output row over each 64-column block.  Consumer (EPI_BF16 / EPI_GELU): A is that bf16 copy of the UN-normalised
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
     const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
-  const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
+  const int tile_q = lt / g.tilesN, tile_n = lt - tile_q * g.tilesN, tile_m = tile_q + g.tile_m0;
   const int m0 = tile_m * BMt, n0 = tile_n * BNt;
   const int ntiles = g.K >> 6;
 
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
           if (nblk & 1) { const float2 v = *reinterpret_cast<const float2*>(g.stats_in + ((int64_t)m * nblk + nblk - 1) * 2); s1 += v.x; s2 += v.y; }
         }
       }
-      const float inv = 1.f / (float)g.K, mean = s1 * inv, var = fmaxf(s2 * inv - mean * mean, 0.f);
+      // (explicit fma: the two kernels that serve this epilogue -- linear.hip, gemm256.hip -- must not differ by a compiler's contraction choice)
+      const float inv = 1.f / (float)g.K, mean = s1 * inv, ex2 = s2 * inv, var = fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f);
       *reinterpret_cast<float2*>(smem + LNST_OFF + tid * 8) = make_float2(mean, rsqrtf(var + g.ln_eps));
     }
   }
@@ -579,7 +581,7 @@ int launch_lin(const LinArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), dim3(((a.M + BMt - 1) / BMt) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), dim3(((a.M + BMt - 1) / BMt - a.tile_m0) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -622,7 +624,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias ? a->bias : zero_bias; g.resid = a->resid;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
-  g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.H = g.Wd = g.Cin = 0;
+  g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.tile_m0 = 0; g.H = g.Wd = g.Cin = 0;
   const long tiles = (long)((a->M + 127) / 128) * g.tilesN;
   int spec_max = 256, big = 1;
   { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
@@ -675,9 +677,14 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
 
 // 3x3 convolution forward / dgrad as implicit GEMM (A = IM2ROW view of an NHWC bf16 map, B = [Cout][9 Cin] weights): 256 x 128 tiles,
 // 8 compute + 4 loader waves.  Returns 1 when the launch does not qualify (gemm_kernel then runs it).
-int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
+// row0 > 0 (a multiple of 128, N % 256 == 0): only the rows [row0, M) -- the tail of a launch whose first rows ran on gemm256.hip's tiles.
+int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0);
+int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) { return countr_lean_conv_rows(a, s, 0); }
+
+int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0) {
   { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 1; }
   { const char* e = getenv("COUNTR_LEAN_CONV"); if (e && atoi(e) == 0) return 1; }
+  if (row0 < 0 || (row0 % 128) || row0 >= a->M || (row0 > 0 && (a->N % 256))) return 1;
 #ifndef LIN_STAMP
   if (a->C2) return 1;
 #endif
@@ -687,7 +694,7 @@ int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
   if ((int64_t)(a->M + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll || a->N > 4096) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
   const long tiles = (long)((a->M + 127) / 128) * (a->N / 128);
-  if (tiles <= 256) return 1;     // small maps: the generic kernel's split-K / wave-specialised 128x128 forms
+  if (tiles <= 256 && row0 == 0) return 1;     // small maps: the generic kernel's split-K / wave-specialised 128x128 forms
   static float* zero_bias = nullptr;
   if (!a->bias && !zero_bias) {
     if (hipMalloc(&zero_bias, 4096 * sizeof(float)) != hipSuccess || hipMemset(zero_bias, 0, 4096 * sizeof(float)) != hipSuccess) { zero_bias = nullptr; return 1; }
@@ -698,12 +705,13 @@ int countr_lean_conv(const countr_gemm_args* a, hipStream_t s) {
   g.C2 = (char*)a->C2;   // stamp builds: the debug buffer
 #endif
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = 0;
-  g.res_mod = 0; g.tilesN = a->N / 128; g.H = a->H; g.Wd = a->W; g.Cin = a->Cin;
+  g.res_mod = 0; g.tilesN = a->N / 128; g.tile_m0 = row0 / 128; g.H = a->H; g.Wd = a->W; g.Cin = a->Cin;
   g.xcopy = nullptr; g.stats_out = nullptr; g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f;
   // 128 x 256 tiles when the width allows (the density head's 256 output channels in ONE workgroup: the im2row operand -- nine taps of
   // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128
   int form = (a->N % 256) == 0 ? 2 : 1;
   { const char* e = getenv("COUNTR_LEAN_CONV_FORM"); if (e) form = atoi(e); }
+  if (row0 > 0) form = 2;      // (128-row tiles: row0 is a multiple of 128)
   if (form == 3 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 2, true, 2, false, 3>(g, s); }   // 192 x 256 (experiment)
   if (form == 2 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 3, true, 2>(g, s); }
   return launch_lin<2, 4, EPI_BF16, 3, true>(g, s);

@@ -232,6 +232,7 @@ class Engine:
         self._defer = {}             # id(ops) -> (ops, [pending reduction entries]): flushed into countr_reduce_table launches
         self._tables = []
         self.defer_reduce = os.environ.get("COUNTR_DEFER_REDUCE", "1") != "0"
+        self.splitk_cap = int(os.environ.get("COUNTR_SPLITK_CAP", "64"))     # most fp32 slabs a weight-gradient GEMM is cut into
         self._acc = 0                # accumulate flag baked into the parameter-gradient launches being built (gradient accumulation)
         self.generation = 0
         self._sides = None
@@ -512,7 +513,7 @@ class Engine:
         fp32 slabs to reduce)."""
         # (round 1 gave 129..256-tile wgrads two slabs on the plain kernel -- fc1 wgrad 3072x768, 144 tiles: 26.5 vs 29.1 us; since the
         # wave-specialised loop hides its first-fragment latency one slab wins: 24.5 vs 28.1 us, MAE pretrain step 8.78 -> 8.66 ms)
-        return max(1, min(64, ktiles, 256 // max(tiles, 1)))
+        return max(1, min(self.splitk_cap, ktiles, 256 // max(tiles, 1)))
 
     # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
     def _linear_wgrad(self, ops, dy, x, wname, M, N, K, lddy=None, ldx=None, bias_name=None):

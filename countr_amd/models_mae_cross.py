@@ -65,7 +65,7 @@ class SupervisedMAE(HipModule):
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         num_patches = self.patch_embed.num_patches
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim), requires_grad=False)
-        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer, precision=precision)
                                      for _ in range(depth)])
         self.norm = norm_layer(embed_dim)
         # --- decoder (models_mae_cross.py:38-100)
@@ -81,7 +81,7 @@ class SupervisedMAE(HipModule):
         self.decoder_proj3 = proj(128, 256)
         self.decoder_proj4 = proj(256, decoder_embed_dim, last=True)
         self.decoder_blocks = nn.ModuleList([
-            CrossAttentionBlock(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+            CrossAttentionBlock(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer, precision=precision)
             for _ in range(decoder_depth)])
         self.decoder_norm = norm_layer(decoder_embed_dim)
 

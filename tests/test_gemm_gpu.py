@@ -778,11 +778,11 @@ def test_g256_linear_matches_fp64_and_lean(hip, monkeypatch, M, N, K, epi):
         for r in runs[1:]:
             assert torch.equal(r, runs[0]), "run-to-run difference (phase-schedule race)"
         outs[mode] = runs[0]
-    d = (outs["2"].double() - outs["0"].double()).abs().max().item()
-    assert d <= 8e-3 * ref.abs().max().item(), d
+    # same k order per element and the same epilogue arithmetic: which kernel a batch size selects does not change a result
+    assert torch.equal(outs["2"], outs["0"]), (outs["2"].double() - outs["0"].double()).abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,K", [(4608, 3072, 768), (1152, 1536, 512), (300, 256, 256)])
+@pytest.mark.parametrize("M,N,K", [(4608, 3072, 768), (18432, 3072, 768), (1152, 1536, 512), (300, 256, 256)])
 def test_g256_linear_layernorm_consumer(hip, monkeypatch, M, N, K):
     """The LayerNorm-fold consumer epilogue of the 256 x 256 kernel (fc1 in the frozen encoder: rstd (acc - mean colsum) + bias' from the
     producer's per-64-column {sum, sum of squares} row partials) against the same launch on linear.hip's kernel and against fp64."""
@@ -812,17 +812,20 @@ def test_g256_linear_layernorm_consumer(hip, monkeypatch, M, N, K):
         assert torch.isfinite(out.float()).all()
         assert (out.double() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item() + 3e-5, mode
         outs[mode] = out
-    assert (outs["2"].double() - outs["0"].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()
+    # same k order per element, same epilogue arithmetic (explicit fma in both): the kernel a batch size selects must not change a result
+    assert torch.equal(outs["2"], outs["0"]), (outs["2"].double() - outs["0"].double()).abs().max().item()
 
 
 @pytest.mark.parametrize("Bsz,H,W,Cin,Cout,use_bias", [(2, 96, 96, 256, 256, True), (1, 192, 192, 256, 256, True), (8, 48, 48, 512, 256, False),
-                                                   (3, 100, 100, 128, 512, True), (32, 24, 24, 256, 256, True), (1, 20, 12, 128, 256, True)])
+                                                   (3, 100, 100, 128, 512, True), (32, 24, 24, 256, 256, True), (1, 20, 12, 128, 256, True),
+                                                   (3, 160, 160, 128, 256, True)])      # (300 tiles: one full round here + 44 tiles as a 128-row tail launch)
 def test_g256_conv3x3_matches_fp64_and_lean(hip, monkeypatch, Bsz, H, W, Cin, Cout, use_bias):
     """3x3 convolution forward / dgrad on the 256 x 256 8-phase kernel (im2row LDS-DMA descriptors: tap shifts as scalar offsets, padding
     taps and ragged rows as lanes pushed outside the descriptor) with COUNTR_G256=2: against torch conv2d in fp64 and against the
     128x256 form of linear.hip on the same bf16 maps -- zero padding at every border, tiles that span image boundaries (100 x 100,
     24 x 24 = 2.25 images per tile), a map smaller than one tile (20 x 12: most staged rows are masked), Cin = 128 / 256 / 512
-    (2 / 4 / 8 k-tiles per tap), with and without bias; three runs must agree bit for bit (race screen)."""
+    (2 / 4 / 8 k-tiles per tap), with and without bias; a grid of 1.17 rounds of workgroups, which runs as one full round on this kernel plus
+    a tail launch of the 128-row kernel on the last rows (split rounds); three runs must agree bit for bit (race screen)."""
     x = _mk((Bsz, H, W, Cin), torch.bfloat16, 151)
     w = (_mk((Cout, 3, 3, Cin), torch.float32, 152) * 0.1).to(torch.bfloat16)
     bias = _mk((Cout,), torch.float32, 153) if use_bias else None
@@ -851,4 +854,4 @@ def test_g256_conv3x3_matches_fp64_and_lean(hip, monkeypatch, Bsz, H, W, Cin, Co
         for r in runs[1:]:
             assert torch.equal(r, runs[0]), "run-to-run difference (phase-schedule race)"
         outs[mode] = runs[0]
-    assert (outs["2"].double() - outs["0"].double()).abs().max().item() <= 8e-3 * ref.abs().max().item()
+    assert torch.equal(outs["2"], outs["0"]), (outs["2"].double() - outs["0"].double()).abs().max().item()
