@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("ln_xcopy", C.c_void_p), ("ln_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
         ("rowsum_slabs", C.c_int32),
+        ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
     ]
 
 

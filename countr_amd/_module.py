@@ -45,12 +45,25 @@ class HipModule(nn.Module):
                     eng.pview(n).copy_(p.data.float())
                     p.data = eng.pview(n)
                 self._versions = None
-        vers = sum(p._version for _, p in params)
+        vers = self._version_sums(params)
         if vers != self._versions:  # optimizer.step() / load_state_dict changed values: refresh shadows
-            eng.sync_weights()
+            # a torch optimizer stepping the trainable parameters through autograd moves only THEIR version counters: the frozen part's
+            # shadows -- and the LayerNorm-fold / pre-scaled-q repack of the frozen encoder, ~36 torch matmuls -- are left alone then
+            frozen_same = self._versions is not None and vers[0] == self._versions[0]
+            eng.sync_weights(trainable_only=frozen_same)
             self._versions = vers
         return eng
 
+    def _version_sums(self, params):
+        """(sum of the frozen parameters' version counters, sum of the trainable ones')."""
+        fr = tr = 0
+        for n, p in params:
+            if self._is_trainable(n):
+                tr += p._version
+            else:
+                fr += p._version
+        return (fr, tr)
+
     def mark_weights_synced(self):
         """The engine's fused AdamW keeps the shadows coherent itself."""
-        self._versions = sum(p._version for p in self.parameters())
+        self._versions = self._version_sums(list(self.named_parameters()))

@@ -170,3 +170,25 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { if
 extern "C" void countr_set_error(const char* msg);
 int countr_check_launch(const char* what);
 #define COUNTR_LAUNCH_CHECK(what) return countr_check_launch(what)
+
+// The first workgroups of a GEMM launch (blockIdx.x < npf) warm the cache with a read-only range -- the next launch's weight
+// panel -- and leave: block j of npf reads every npf-th 16-byte x blockDim slice; the values go nowhere (countr_gemm_args.prefetch).
+__device__ __forceinline__ void countr_prefetch_range(const char* p, long long bytes, int j, int npf) {
+  const uint4* __restrict__ s = reinterpret_cast<const uint4*>(p);
+  const long long n = bytes >> 4, stride = (long long)npf * blockDim.x;
+  uint4 acc = {0u, 0u, 0u, 0u};
+  for (long long i = (long long)j * blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * stride < n) { const uint4 v = s[i + u * stride]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+  }
+  asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));
+}
+// workgroups a launch of `tiles` tiles puts IN FRONT of its tile workgroups for the hint (a multiple of 8: workgroup b runs on XCD b % 8,
+// and the tile order is XCD-aware): the idle CUs of a single-round grid, or 32 CU slots for the first microseconds of a bigger one
+static inline int countr_prefetch_blocks(long tiles, const void* p, long long bytes) {
+  if (!p || bytes < 16 || ((uintptr_t)p & 15) || (bytes & 15)) return 0;
+  if (tiles >= 256) return 32;
+  const long spare = ((256 - tiles) / 8) * 8;
+  return (int)(spare < 64 ? spare : 64);
+}

@@ -47,6 +47,7 @@ struct BigArgs {
   int M, N, K;
   int lda, ldw, ldc;   // elements
   int tilesN;
+  const char* pf; long long pf_bytes; int npf;   // workgroups < npf only read this range and leave (cache warm-up hint of countr_gemm_args)
   int launch_tiles;    // tiles this launch covers (the first ones of the problem; the rest may run as a tail launch of linear.hip's kernel)
   int H, Wd, Cin, cpt_log;   // CONV: k-tiles per tap = Cin / 64 = 1 << cpt_log
   const float* stats_in;     // LN consumer (see linear.hip): [M][K/64][2]
@@ -112,13 +113,15 @@ __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
 template <bool CONV, int EPI, bool LN>
 __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < g.npf) { countr_prefetch_range(g.pf, g.pf_bytes, (int)blockIdx.x, g.npf); return; }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
   // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns one contiguous range of the (tile_m, tile_n) space
   int lt;
   {
-    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int bt = (int)blockIdx.x - g.npf;      // (npf % 8 == 0)
+    const int nt = g.launch_tiles, q = nt >> 3, r = nt & 7, x = bt & 7, j = bt >> 3;
     lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
   const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
@@ -525,13 +528,15 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
 }
 
 template <bool CONV, int EPI, bool LN>
-int launch_big(const BigArgs& a, hipStream_t s) {
+int launch_big(const BigArgs& a0, hipStream_t s) {
+  BigArgs a = a0;
+  a.npf = countr_prefetch_blocks(a.launch_tiles, a.pf, a.pf_bytes);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g256_kernel<CONV, EPI, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((g256_kernel<CONV, EPI, LN>), dim3(a.launch_tiles), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((g256_kernel<CONV, EPI, LN>), dim3(a.launch_tiles + a.npf), dim3(512), LDS_BYTES, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(256x256 8-phase)");
 }
 
@@ -578,7 +583,7 @@ int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
   BigArgs g;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = bias;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = a->N / 256;
-  g.launch_tiles = (int)tiles;
+  g.launch_tiles = (int)tiles; g.pf = (const char*)a->prefetch; g.pf_bytes = a->prefetch_bytes;
   g.H = g.Wd = g.Cin = g.cpt_log = 0; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps; g.stamps = nullptr;
 #ifdef G256_STAMP
   g.stamps = (float*)a->C2; g.C2 = nullptr;
@@ -630,7 +635,7 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   BigArgs g;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = nullptr; g.bias = bias;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = (int)tilesN;
-  g.launch_tiles = (int)head;
+  g.launch_tiles = (int)head; g.pf = nullptr; g.pf_bytes = 0;
   g.H = a->H; g.Wd = a->W; g.Cin = a->Cin; g.cpt_log = a->Cin == 128 ? 1 : a->Cin == 256 ? 2 : 3;
   g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f; g.stamps = nullptr;
 #ifdef G256_STAMP

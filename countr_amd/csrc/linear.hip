@@ -48,6 +48,7 @@ struct LinArgs {
   int M, N, K;
   int lda, ldw, ldc, ldres;   // elements
   int res_mod, tilesN;
+  const char* pf; long long pf_bytes; int launch_tiles, npf;   // workgroups < npf only read [pf, pf + pf_bytes) and leave (cache warm-up hint); launch_tiles tile workgroups follow
   int tile_m0;         // first row tile of this launch (a launch may cover the LAST row tiles of a problem only: gemm256.hip's split rounds)
   int H, Wd, Cin;      // CONV (3x3, pad 1, NHWC): A is the map [B, H, Wd, Cin], row m = pixel, k = tap * Cin + c
   // LayerNorm folding (LN template flag).  Producer (EPI_RES): xcopy = bf16 copy of the fp32 output, stats_out[m][N/64][2] = {sum, sum of
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
   constexpr int PA = BMt / (8 * NLW), PB = BNt / (8 * NLW);   // 1-KiB pieces per operand per staging wave per k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  if ((int)blockIdx.x < g.npf) { countr_prefetch_range(g.pf, g.pf_bytes, (int)blockIdx.x, g.npf); return; }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = SPEC && wv >= NCW;
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
   // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns one contiguous range of the (tile_m, tile_n) space
   int lt;
   {
-    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int bt = (int)blockIdx.x - g.npf;      // (npf % 8 == 0: the XCD of tile workgroup bt is bt % 8)
+    const int nt = g.launch_tiles, q = nt >> 3, r = nt & 7, x = bt & 7, j = bt >> 3;
     lt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
   }
   const int tile_q = lt / g.tilesN, tile_n = lt - tile_q * g.tilesN, tile_m = tile_q + g.tile_m0;
@@ -571,7 +574,8 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
 }
 
 template <int WMB, int NLD, int EPI, int STAGES, bool CONV = false, int WNB = 1, bool LN = false, int TM = 2>
-int launch_lin(const LinArgs& a, hipStream_t s) {
+int launch_lin(const LinArgs& a0, hipStream_t s) {
+  LinArgs a = a0;
   constexpr int BMt = 64 * TM * WMB;
   constexpr int ring = STAGES * (BMt + 128 * WNB) * 128, staging = NLD ? 4 * WMB * WNB * 64 * OPITCH : 0;   // the epilogue's staging regions reuse the ring
   constexpr int lds = (ring > staging ? ring : staging) + ((LN && EPI != EPI_RES) ? BMt * 8 : 0);   // + the consumer's row statistics
@@ -581,7 +585,9 @@ int launch_lin(const LinArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), dim3(((a.M + BMt - 1) / BMt - a.tile_m0) * a.tilesN), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
+  a.launch_tiles = ((a.M + BMt - 1) / BMt - a.tile_m0) * a.tilesN;
+  a.npf = countr_prefetch_blocks(a.launch_tiles, a.pf, a.pf_bytes);
+  hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), dim3(a.launch_tiles + a.npf), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(lean linear)");
 }
 
@@ -619,12 +625,14 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   }
   const bool ln_out = a->ln_xcopy != nullptr || a->ln_stats_out != nullptr, ln_in = a->ln_stats != nullptr || a->ln_colsum != nullptr;
   if (ln_out && (epi != EPI_RES || !a->ln_xcopy || !a->ln_stats_out || ((uintptr_t)a->ln_xcopy & 15) || ((uintptr_t)a->ln_stats_out & 7))) return 1;
-  if (ln_in && (epi == EPI_RES || !a->ln_stats || !a->ln_colsum || (((uintptr_t)a->ln_stats | (uintptr_t)a->ln_colsum) & 15) || a->ln_nblk != a->K / 64)) return 1;
+  // (K % 128 == 0: the consumer reads its row partials [K / 64][2] with 16-byte loads, aligned for every row only when K / 64 is even)
+  if (ln_in && (epi == EPI_RES || !a->ln_stats || !a->ln_colsum || (((uintptr_t)a->ln_stats | (uintptr_t)a->ln_colsum) & 15) || a->ln_nblk != a->K / 64 || (a->K % 128))) return 1;
   LinArgs g;
   g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias ? a->bias : zero_bias; g.resid = a->resid;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
   g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.tile_m0 = 0; g.H = g.Wd = g.Cin = 0;
+  g.pf = (const char*)a->prefetch; g.pf_bytes = a->prefetch_bytes; g.launch_tiles = 0; g.npf = 0;
   const long tiles = (long)((a->M + 127) / 128) * g.tilesN;
   int spec_max = 256, big = 1;
   { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
@@ -706,6 +714,7 @@ int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0) {
 #endif
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = 0;
   g.res_mod = 0; g.tilesN = a->N / 128; g.tile_m0 = row0 / 128; g.H = a->H; g.Wd = a->W; g.Cin = a->Cin;
+  g.pf = nullptr; g.pf_bytes = 0; g.launch_tiles = 0; g.npf = 0;
   g.xcopy = nullptr; g.stats_out = nullptr; g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f;
   // 128 x 256 tiles when the width allows (the density head's 256 output channels in ONE workgroup: the im2row operand -- nine taps of
   // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128

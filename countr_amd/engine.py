@@ -231,6 +231,7 @@ class Engine:
         self.reduce_vec4 = os.environ.get("COUNTR_REDUCE_VEC4", "1") != "0"   # 16-byte loads in the deferred-sum kernel
         self._defer = {}             # id(ops) -> (ops, [pending reduction entries]): flushed into countr_reduce_table launches
         self._tables = []
+        self.warm_weights = os.environ.get("COUNTR_WARM", "1") != "0"     # spare workgroups of a GEMM read the next GEMM's (cold) weight panel
         self.defer_reduce = os.environ.get("COUNTR_DEFER_REDUCE", "1") != "0"
         self.splitk_cap = int(os.environ.get("COUNTR_SPLITK_CAP", "64"))     # most fp32 slabs a weight-gradient GEMM is cut into
         self._acc = 0                # accumulate flag baked into the parameter-gradient launches being built (gradient accumulation)
@@ -506,6 +507,39 @@ class Engine:
                    bias=(bias_ptr if bias_ptr is not None else (self._pp(wname[:-6] + "bias") if bias else None)),
                    resid=(resid if isinstance(resid, int) else (resid.data_ptr() if resid is not None else None)),
                    lda=K, ldb=K, ldc=N, ldres=N, M=M, N=N, K=K, res_mod=res_mod, act=act, out_bf16=int(out_bf16))
+
+    def _weight_buffers(self):
+        """[lo, hi) address ranges of the GEMM-operand copies of the parameters (the buffers whose contents are COLD at every use: a
+        step streams ~5 GB through the 256-MB memory-side cache between two uses of a layer's weights)."""
+        ts = [self.Wt] + list(self.Wf.values()) + list(self.Wd.values()) + list(self.WtT.values())
+        return [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in ts]
+
+    def _auto_warm(self, ops):
+        """Cache warm-up hints (countr_gemm_args.prefetch) for a finished launch list: every GEMM whose B operand is a weight panel gets
+        that panel read -- once, at full width, by a few extra workgroups -- by the nearest launch IN FRONT of it that honours the hint
+        (the bf16 (ROW, ROW) kernels of linear.hip / gemm256.hip).  Why: a single-round GEMM that walks a cold [N][K] panel k-slab by
+        k-slab, 128-byte pieces two k-tiles ahead, pays the HBM latency on every k-tile -- the encoder's fc2 took 38.7 us in the step
+        against 28.7 us with the panel resident (tools/bench_chain.py); with the hints fc2 runs at 29.4, proj 16.5 -> 15, qkv 23 ->
+        20.7 us, step 4.83 -> 4.70 ms (A/B inside one gpurun call).  A side-lane warm-up kernel gave the same kernel gains and lost them
+        again to the fork / join gaps and to the GEMM it ran beside (4.80 vs 4.68 ms).  Results never change."""
+        if not self.warm_weights or self.code != BF16 or self._sizing:
+            return
+        bufs = self._weight_buffers()
+        nxt = None
+        for fn, args, a in reversed(ops):
+            if fn is not self.L.countr_gemm or a is None:
+                continue
+            dtype, ma, mb = args[1], args[2], args[3]
+            if dtype == BF16 and ma == OP_ROW and mb == OP_ROW and not a.partial and a.nbatch <= 1 and nxt is not None and not a.prefetch:
+                a.prefetch, a.prefetch_bytes = nxt
+                nxt = None
+            b = a.B
+            if b and a.nbatch <= 1 and any(lo <= b < hi for lo, hi in bufs):
+                n_el = ((a.N - 1) * a.ldb + a.K) if mb == OP_ROW else (((a.K - 1) * a.ldb + a.N) if mb == OP_COL else 0)
+                hi = next(h for lo, h in bufs if lo <= b < h)
+                lo16, end = b - b % 16, min(b + 2 * n_el, hi)
+                if end - lo16 >= 4096:
+                    nxt = (lo16, (end - lo16) // 16 * 16)
 
     def _splitk(self, tiles, ktiles):
         """Split-K factor of a wgrad GEMM: as many slabs as keep the launch within 256 workgroups, i.e. one wave-specialised
@@ -927,6 +961,7 @@ class Engine:
             mark = lambda *a: (None, a, None)
             p.fwd_par = ([mark("xfork"), mark("xlane", 1)] + p.fwd[ex[0]:ex[1]] + [mark("xlane", 0)] + p.fwd[:ex[0]] + [mark("xjoin")]
                          + p.fwd[ex[1]:])
+        self._auto_warm(p.fwd)
         if not train:
             return p
 
@@ -1062,6 +1097,8 @@ class Engine:
                         self._conv_wgrad(ops, dc[i], pl[i - 1], wn, BS, sizes[i], sizes[i], chans[i - 1], chans[i], bias_name=wn[:-6] + "bias")
                         self._conv_fwd(ops, dc[i], self.Wd[wn], None, dpl[i - 1], BS, sizes[i], sizes[i], chans[i], chans[i - 1])
             self._flush_reductions(p)
+            for ops_ in (lists.bwd_head, lists.bwd_rest, lists.bwd_tok):
+                self._auto_warm(ops_)
         self._acc = 0
         return p
 

@@ -192,6 +192,7 @@ class MaeEngine(Engine):
         self._linear(ops, dn, "decoder_pred.weight", pred, rn, F, Dd)
         A("loss", (1,), f32)
         self._shared("mse", L.countr_patch_mse_workspace_floats(B, self.img, self.img, self.patch))
+        self._auto_warm(p.fwd)
         if not train:
             return p
 
@@ -229,6 +230,8 @@ class MaeEngine(Engine):
             ops = lists.bwd_enc[-1]
             self._linear_wgrad(ops, g_t, pk, "patch_embed.proj.weight", rk, D, F, bias_name="patch_embed.proj.bias")
             self._flush_reductions(p)
+            for ops_ in [lists.bwd_dec] + list(lists.bwd_enc):
+                self._auto_warm(ops_)
         self._acc = 0
         return p
 

@@ -45,7 +45,6 @@ class _GraphStep:
         self.sync = self._make_sync(process_group)
         self.world = self.sync.world
         self._ring = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(16)]
-        self._hyper_by_kernel = os.environ.get("COUNTR_HYPER_KERNEL", "1") != "0"
         self._ring_ev = [None] * 16
         self.grad_scale = 1.0 / self.accum
 
@@ -222,13 +221,7 @@ class _GraphStep:
             t = max(eng.group_steps[grp], 1)
             h[i1] = 1.0 - self.betas[0] ** t
             h[i2] = 1.0 - self.betas[1] ** t
-        if self._hyper_by_kernel:
-            # a KERNEL reads the pinned host scalars (zero-copy): an SDMA copy between two graph replays costs ~60 us of idle GPU per
-            # step -- queue hand-over to the copy engine and back (tools/seq_step.sh: gap in front of __amd_rocclr_copyBuffer)
-            _lib.check(eng.L.countr_copy_multi(1, (C.c_void_p * 1)(h.data_ptr()), (C.c_void_p * 1)(eng.hyper.data_ptr()),
-                                               (C.c_int64 * 1)(32), eng._stream()), "copy_multi(hyper)")
-        else:
-            eng.hyper.copy_(h, non_blocking=True)
+        eng.hyper.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._ring_ev[slot] = ev

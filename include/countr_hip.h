@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 2 (round 3: countr_gemm_args grew at its end -- ln_* fields, rowsum_slabs -- so a caller built against version 1 must be rebuilt) */
+int countr_version(void);               /* ABI version, currently 3 (countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint -- so a caller built against an older version must be rebuilt) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -78,7 +78,8 @@ typedef struct countr_gemm_args {
   float alpha;
   float* rowsum_partial; /* optional (bf16 split-K only): fp32 [max(splitk,1)][M] receives sum_k A(m,k) per
                             K split -- the bias gradient of a wgrad GEMM, fused as one extra MFMA per tile    */
-  /* LayerNorm folded into the surrounding nn.Linear layers (frozen encoder, bf16, (ROW, ROW), N % 128 == 0, K % 64 == 0; timm Block:
+  /* LayerNorm folded into the surrounding nn.Linear layers (frozen encoder, bf16, (ROW, ROW), N % 128 == 0, K % 64 == 0 -- K % 128 == 0
+   * for a consumer, whose row partials are read 16 bytes at a time; timm Block:
    * x = x + proj(attn(norm1(x))); x = x + fc2(gelu(fc1(norm2(x)))) -- models_mae_cross.py:144-146).
    * Producer (fp32 output with residual): ln_xcopy receives a bf16 copy of C, ln_stats_out[m][N/64][2] the {sum, sum of squares} of
    * every 64-column block of the fp32 output row.  Consumer (bf16 output): A is that copy, B = gamma o W, bias = b + W beta,
@@ -93,6 +94,14 @@ typedef struct countr_gemm_args {
   int32_t rowsum_slabs; /* slabs the caller sized rowsum_partial for: 0 = max(splitk,1) (the layout above); otherwise it must be
                            countr_gemm_rowsum_slabs() of this launch (the lean convolution weight gradient deals the bias-gradient
                            work over more waves and writes [rowsum_slabs][M]; the sum over ALL slabs is the bias gradient)        */
+  /* Cache warm-up hint (ABI 3): a read-only range -- normally the B operand of the NEXT launch on the stream -- that spare workgroups
+   * of this launch read once and discard (16-byte aligned pointer and size).  Honoured by the bf16 (ROW, ROW) kernels when the grid
+   * leaves CUs idle (fewer than 256 tiles); ignored otherwise.  Never changes a result.  Why: the frozen encoder's weight panels
+   * (blocks.i.attn / mlp, models_mae_cross.py:32-34,141-145) are cold in every step -- ~5 GB stream through the 256-MB memory-side cache
+   * between two uses -- and a single-round GEMM that walks a cold [N][K] panel k-slab by k-slab pays the HBM latency on every k-tile
+   * (fc2: 38.7 us in the step, 28.7 us with the panel resident: tools/bench_chain.py). */
+  const void* prefetch;
+  int64_t prefetch_bytes;
 } countr_gemm_args;
 
 int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream);

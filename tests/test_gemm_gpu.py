@@ -855,3 +855,42 @@ def test_g256_conv3x3_matches_fp64_and_lean(hip, monkeypatch, Bsz, H, W, Cin, Co
             assert torch.equal(r, runs[0]), "run-to-run difference (phase-schedule race)"
         outs[mode] = runs[0]
     assert torch.equal(outs["2"], outs["0"]), (outs["2"].double() - outs["0"].double()).abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4608, 768, 3072, "res"), (4608, 3072, 768, "gelu"), (4608, 2304, 768, "bf16"), (1152, 512, 512, "res"), (40, 128, 128, "bf16")])
+def test_prefetch_hint_changes_nothing(hip, M, N, K, epi):
+    """countr_gemm_args.prefetch (ABI 3): spare workgroups of a single-round launch read a range and leave -- the 128-row kernel, the
+    192 x 256 form and the 256 x 256 kernel (the encoder's fc2 / fc1 / qkv shapes at B = 8: 216 tiles + 40 warm-up workgroups), a small
+    grid (4 tiles) and a one-tile launch; the output is bit-identical to the launch without the hint, the hinted range and the guard
+    rows are untouched, and an unaligned hint is ignored rather than refused (it is a hint)."""
+    A = _mk((M, K), torch.bfloat16, 221)
+    W = (_mk((N, K), torch.float32, 222) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 223)
+    resid = _mk((M, N), torch.float32, 224) if epi == "res" else None
+    nxt = _mk((3 * 1024 * 1024 + 8,), torch.float32, 225)
+    nxt0 = nxt.clone()
+    outs = []
+    for hint in (None, (nxt.data_ptr(), 4 * nxt.numel()), (nxt.data_ptr() + 4, 4096)):
+        out = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.float32 if epi == "res" else torch.bfloat16)
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C, a.bias = A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr()
+        a.resid = resid.data_ptr() if resid is not None else None
+        a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
+        a.M, a.N, a.K = M, N, K
+        a.act = 1 if epi == "gelu" else 0
+        a.out_bf16 = int(epi != "res")
+        a.alpha = 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        if hint is not None:
+            a.prefetch, a.prefetch_bytes = hint
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+        torch.cuda.synchronize()
+        assert torch.isnan(out[M:].float()).all() and torch.isfinite(out[:M].float()).all()
+        outs.append(out[:M].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(nxt, nxt0)
+    ref = A.double() @ W.double().t() + bias.double()
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if resid is not None:
+        ref = ref + resid.double()
+    assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item() + 3e-5

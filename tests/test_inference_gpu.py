@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import countr_ref as R
 from oracle import weights as W
 
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -115,15 +116,36 @@ def test_config5_batch_of_32_windows(precision, fp32_model):
         m.to("cuda").eval()
     imgs = [torch.from_numpy(W.make_wide_inputs(300 + k, 672, 0)[0]).cuda() for k in range(8)]
     empty = torch.zeros(1, 0, device="cuda")
-    calls = []
+    calls, seen = [], []
+
+    def spy(a, b, c):
+        calls.append(a.shape[0])
+        out = orig(a, b, c)
+        if a.shape[0] == 32:
+            seen.append((a.detach().clone(), out.detach().clone()))
+        return out
     orig = m.forward
-    m.forward = lambda a, b, c: (calls.append(a.shape[0]), orig(a, b, c))[1]
+    m.forward = spy
     try:
         dms = inference.density_maps(m, imgs, [empty] * 8, 0)
         assert calls == [32]
         single = [inference.density_map(m, im, empty, 0) for im in imgs]
     finally:
         m.forward = orig
+    # the batch-of-32 forward itself against the ORACLE (not only against the engine's own per-image path): windows 0, 5 (second
+    # window of frame 1), 18 and 31 of the batch, same bars as the single-image tests (fp32: 1e-3 / +-0.5 counts; bf16, shot_num 0: 6e-2 / 6 %)
+    (win, wout), = seen
+    sd = W.make_state_dict("mae_vit_base_patch16", seed=0)
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    for j in (0, 5, 18, 31):
+        ref = R.forward(sd, win[j:j + 1].cpu().numpy(), np.zeros((1, 0), np.float32), 0).numpy()[0]
+        got = wout[j].cpu().numpy()
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        cnt, rc = got.sum() / 60, ref.sum() / 60
+        if precision == "fp32":
+            assert err < 1e-3 and abs(cnt - rc) < 0.5, (j, err, cnt, rc)
+        else:
+            assert err < 6e-2 and abs(cnt - rc) <= 6e-2 * abs(rc), (j, err, cnt, rc)
     for a, b in zip(dms, single):
         if precision == "fp32":      # same kernels, other batch size (tile / split-K choices may differ): rounding-level agreement
             assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()

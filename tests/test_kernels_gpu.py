@@ -552,3 +552,19 @@ def test_copy_multi(hip):
     for s, d in zip(src, dst):
         assert torch.equal(d[4:4 + s.numel()], s) and torch.isnan(d[:4]).all() and torch.isnan(d[4 + s.numel():]).all()
     assert hip.countr_copy_multi(1, vp(*[src[0].data_ptr()] * n), vp(*[dst[0].data_ptr() + 4] * n), (C.c_int64 * n)(*[16] * n), None) != 0   # misaligned
+
+
+def test_copy_multi_zero_fill(hip):
+    """countr_copy_multi with a NULL source zero-fills its destination (the gradient range of a conditional parameter set this rank
+    did not use while another rank did: per-rank shot_num), next to ordinary copies in the same launch."""
+    import ctypes as C
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.randn(5000, device="cuda")
+    b = torch.full((1 << 20,), float("nan"), device="cuda")
+    keep = torch.randn(1000, device="cuda")
+    out = torch.empty(1000, device="cuda")
+    vp, i64 = C.c_void_p * 3, C.c_int64 * 3
+    _lib.check(hip.countr_copy_multi(3, vp(None, keep.data_ptr(), None), vp(a.data_ptr() + 16, out.data_ptr(), b.data_ptr()),
+                                     i64(4 * 4000, 4 * 1000, 4 * (1 << 20)), st), "copy_multi")
+    torch.cuda.synchronize()
+    assert (a[4:4004] == 0).all() and (a[:4] != 0).any() and (a[4004:] != 0).any() and (b == 0).all() and torch.equal(out, keep)

@@ -45,9 +45,11 @@ def load(db):
 
 
 def demangle(names):
+    import shutil
     import subprocess
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(re.sub(r"\.kd$", "", n) for n in names), capture_output=True,
+        out = subprocess.run([tool], input="\n".join(re.sub(r"\.kd$", "", n) for n in names), capture_output=True,
                              text=True, timeout=60).stdout.splitlines()
         if len(out) == len(names):
             return dict(zip(names, out))
@@ -57,9 +59,15 @@ def demangle(names):
 
 
 def main():
+    if sys.argv[1] == "--json":      # re-run the classification / table on a saved groups file (e.g. on a host that has a demangler)
+        saved = json.load(open(sys.argv[2]))
+        groups = collections.defaultdict(dict)
+        for d in saved["groups"]:
+            g = {k: v for k, v in d.items() if k.isupper() or k in ("n", "wg", "us_profiled")}
+            groups[(d.get("mangled", d["kernel"]), d["grid_threads"])] = g
+        return report(sys.argv[3], groups)
     prefix, dbs = sys.argv[1], sys.argv[2:]
     groups = collections.defaultdict(dict)
-    nsteps = None
     for db in dbs:
         rows, dur = load(db)
         for kn, gx, wx, cn, v, n in rows:
@@ -70,13 +78,18 @@ def main():
         for (kn, gx), (avg_ns, n) in dur.items():
             if (kn, gx) in groups:
                 groups[(kn, gx)].setdefault("us_profiled", avg_ns / 1e3)
+    return report(prefix, groups)
+
+
+def report(prefix, groups):
+    nsteps = None
     dm = demangle(sorted({k[0] for k in groups}))
     out = []
     for (kn, gx), g in groups.items():
-        name = re.sub(r"^void ", "", dm[kn])
+        name = re.sub(r"^void ", "", dm[kn]).replace("(anonymous namespace)::", "")
         name = re.sub(r"\(.*$", "", name)
         d = dict(g)
-        d.update(kernel=name, grid_threads=gx, wgs=(gx // g["wg"]) if g.get("wg") else None, family=family(name))
+        d.update(kernel=name, mangled=kn, grid_threads=gx, wgs=(gx // g["wg"]) if g.get("wg") else None, family=family(name))
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             d["traffic_bytes"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
         if d.get("SQ_BUSY_CYCLES"):
