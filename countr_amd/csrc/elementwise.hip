@@ -550,7 +550,7 @@ extern "C" int countr_conv3x3_c3_fwd(const float* in, const float* w, const floa
                                      int dtype, void* stream) {
   if (!in || !w || !bias || !out) { countr_set_error("countr_conv3x3_c3_fwd: null"); return -1; }
   // every block first stages the 64x27 weights into LDS: few, long-lived blocks (COUNTR_C3_BLOCKS overrides the cap for tuning)
-  static const int cap = [] { const char* e = getenv("COUNTR_C3_BLOCKS"); return e ? atoi(e) : 256; }();   // measured at 24 boxes: 2048 blocks 31.2 us, 512 23.6, 256 22.2, 128 38.2
+  constexpr int cap = 256;   // measured at 24 boxes: 2048 blocks 31.2 us, 512 23.6, 256 22.2, 128 38.2
   const int nb = nblocks((int64_t)S * H * W, 32, cap);
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (bf16_t*)out, S, H, W);
   else hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (float*)out, S, H, W);
@@ -559,7 +559,7 @@ extern "C" int countr_conv3x3_c3_fwd(const float* in, const float* w, const floa
 
 extern "C" int countr_conv3x3_c3_wgrad_nblocks(void) {
   // 24 boxes of 64x64 (98304 pixels): 256 blocks 49.0 + 10.5 us (finish), 512: 32.3 + 15.3, 1024: 39.1 + 25.5 -- with the 16-group finish
-  static const int nb = [] { const char* e = getenv("COUNTR_C3_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+  constexpr int nb = 512;
   return nb;
 }
 extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* dw, float* db, float* workspace, int S, int H,
@@ -577,16 +577,13 @@ extern "C" int countr_upsample2x_fwd(const void* in, void* out, int B, int H, in
   if (!in || !out || (C != 1 && C % 8)) { countr_set_error("countr_upsample2x_fwd: C must be 1 or a multiple of 8"); return -1; }
   const int64_t total = (int64_t)B * 4 * H * W * (C == 1 ? 1 : C / 8);
   const int nb = nblocks(total, 256, 8192);
-  static const int quad = [] { const char* e = getenv("COUNTR_UP2_QUAD"); return e ? atoi(e) : 1; }();   // 0: one thread per fine pixel
-  const int nbq = nblocks(total / 4, 256, 8192);
+  const int nbq = nblocks(total / 4, 256, 8192);     // multi-channel maps: one thread per 2x2 block of fine pixels (quad kernel)
   if (dtype == COUNTR_BF16) {
     if (C == 1) hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
-    else if (quad) hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<bf16_t>), dim3(nbq), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
-    else hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<bf16_t>), dim3(nbq), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
   } else {
     if (C == 1) hipLaunchKernelGGL((upsample2x_fwd_kernel<float, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
-    else if (quad) hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<float>), dim3(nbq), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
-    else hipLaunchKernelGGL((upsample2x_fwd_kernel<float, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<float>), dim3(nbq), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
   }
   COUNTR_LAUNCH_CHECK("countr_upsample2x_fwd");
 }

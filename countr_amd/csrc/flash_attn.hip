@@ -1,26 +1,18 @@
-// Fused self-attention forward for gfx950 (bf16 in/out, fp32 softmax + accumulation).
+// Fused self-attention for gfx950: the public forward entry (the kernel is in flash_attn_fwd.hip) and the fused BACKWARD.
 // Reference: Attention.forward, models_crossvit.py:82-94 (== timm Attention): softmax(q k^T * dh^-0.5) v on a
 // packed qkv [B, N, 3, H, dh]; output [B, N, H*dh].  N = 576, dh = 64 (encoder) or 32 (decoder).
-//
-// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows):
-//   * K/V tiles of 64 keys are register-staged into double-buffered LDS (one barrier per tile).
-//   * S^T = K Q^T with v_mfma_f32_16x16x32_bf16 (A = K fragment from LDS, B = Q fragment held in VGPRs), so a
-//     lane holds 4 keys x 1 query row per tile: row max / sum need only two xor-shuffles (lanes l, l^16, l^32, l^48).
-//   * online softmax in exp2 domain: p = exp2(s * c - m), c = scale * log2(e) folded into one FMA.
-//   * O^T += V^T P^T: the P operand is built from the lane's own S^T registers by choosing the MFMA k-slot
-//     order kappa(g, e) = {4g..4g+3, 16+4g..16+4g+3} (sum over keys is order independent) and V^T fragments are
-//     read in the same key order with ds_read_b64_tr_b16 from the row-major V tile: no cross-lane traffic for P.
+// Shared layout facts (both passes of the backward use the forward's operand forms):
+//   * S^T = K Q^T with the streamed tile as the MFMA A operand (ds_read_b128) and the resident fragment as B, so a lane holds
+//     4 keys x 1 query row per tile: row reductions need two xor-steps (lanes l, l^16, l^32, l^48).
+//   * exp2 domain: p = exp2(s * c - m), c = scale * log2(e).
+//   * PV-type accumulations take their second operand from the lane's own registers by choosing the MFMA k-slot order
+//     kappa(g, e) = {4g..4g+3, 16+4g..16+4g+3}; the transposed tile is read with ds_read_b64_tr_b16 in the same key order.
 #include "common.cuh"
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 
 namespace {
 
-// COUNTR_FA_ABL (timing experiments only, results are wrong): 1 = no MFMA, 2 = no exp2 (p = fma), 3 = K/V staged only once,
-// 4 = 3 + no per-tile barrier, 5 = no softmax at all (p = s), 6 = empty kernel, 7 = one K/V tile only
-#ifndef COUNTR_FA_ABL
-#define COUNTR_FA_ABL 0
-#endif
 constexpr int FA_BQ = 128;   // query rows per workgroup
 constexpr int FA_BKV = 64;   // keys per tile
 // Bytes per LDS row of a staged [rows][DH] bf16 tile.  Row pitch = 32 mod 64 bytes makes BOTH fragment reads conflict-free over
@@ -31,276 +23,6 @@ constexpr int FA_BKV = 64;   // keys per tile
 #endif
 constexpr int fa_pitch(int dh) { return dh * 2 + COUNTR_FA_PAD; }
 
-// max over the four lanes {l, l^16, l^32, l^48} on the VALU (gfx950 v_permlane16/32_swap): the ds_bpermute form of
-// __shfl_xor costs an LDS round trip and an lgkmcnt(0) that also drains the K/V fragment reads in flight.
-__device__ __forceinline__ float quad_rows_max(float x) {
-  float t;
-  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1\n\t"
-               "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1"
-               : "+v"(x), "=&v"(t));
-  return x;
-}
-
-// QT = 16-query MFMA tiles per wave (2: 128 query rows per workgroup; 1: 64 rows -> twice the waves in flight, which is what a
-// small launch such as B = 8 x 12 heads needs to hide LDS / barrier latency, at twice the K/V fragment reads per MFMA)
-template <int DH, int BKV, bool RAGGED, int QT>
-__global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                             float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
-  constexpr int KS = DH / 32;          // k-steps over head dim for QK^T
-  constexpr int DT = DH / 16;          // 16-wide tiles of the head dim for O
-  constexpr int PITCH = fa_pitch(DH);   // bytes per LDS row
-  constexpr int TILE = BKV * PITCH;
-  constexpr int KT = BKV / 16;         // 16-key MFMA tiles per staged KV tile
-  constexpr int PS = BKV / 32;         // 32-key PV k-steps
-  constexpr int CPR = DH / 8;          // 16-byte chunks per row
-  constexpr int PASSES = (BKV * CPR) / 256;  // staging passes
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // stage s: K at s*2*TILE, V behind it
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-#if COUNTR_FA_ABL == 6
-  if (N > 0) return;
-#endif
-  constexpr int BQ = 64 * QT;         // query rows per workgroup
-  const int qblocks = (N + BQ - 1) / BQ;
-  // XCD-aware mapping: workgroup id b runs on XCD b % 8 (observed dispatch order; affects speed only).  All query
-  // blocks of one (batch, head) are given ids congruent mod 8 so that its K/V tiles are fetched into ONE XCD's L2
-  // instead of once per query block (PMC: 78 MB -> 21 MB fabric reads per launch at B=8, H=12).
-  int bh, qb;
-  const int nbh = gridDim.x / qblocks;
-  if ((nbh & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    bh = xcd * (nbh >> 3) + j / qblocks;
-    qb = j - (j / qblocks) * qblocks;
-  } else {
-    bh = blockIdx.x / qblocks;
-    qb = blockIdx.x - bh * qblocks;
-  }
-  const int b = bh / H, h = bh - b * H;
-  const int64_t rs = (int64_t)3 * H * DH;  // row stride (elements) of the packed qkv
-  const bf16_t* qp = qkv + (int64_t)b * N * rs + h * DH;
-  const bf16_t* kp = qp + H * DH;
-  const bf16_t* vp = kp + H * DH;
-  const int q0 = qb * BQ + wave * (16 * QT);
-
-  bf16x8_t qf[QT][KS];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int q = q0 + qt * 16 + li;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < N) v = *reinterpret_cast<const uint4*>(qp + (int64_t)q * rs + ks * 32 + g * 8);
-      qf[qt][ks] = __builtin_bit_cast(bf16x8_t, v);
-    }
-  }
-
-  f32x4_t o[DT][QT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4_t{0, 0, 0, 0};
-  float m[QT], l[QT];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
-
-#if COUNTR_FA_ABL == 7
-  const int ntiles = 1;
-#else
-  const int ntiles = (N + BKV - 1) / BKV;
-#endif
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;   // (a plain vector type: HIP's uint4 struct went to scratch here)
-  u32x4_t kreg[PASSES], vreg[PASSES];
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int cidx = tid + 256 * ps;
-      const int key = t * BKV + cidx / CPR, cc = cidx % CPR;
-      if (!RAGGED || key < N) {   // every key exists when N % BKV == 0: no exec-mask branch in the tile loop
-        kreg[ps] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)key * rs + cc * 8);
-        vreg[ps] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)key * rs + cc * 8);
-      } else {
-        kreg[ps] = u32x4_t{0, 0, 0, 0};
-        vreg[ps] = u32x4_t{0, 0, 0, 0};
-      }
-    }
-  };
-  auto lstore = [&](int stage) {
-    char* ks_ = smem + stage * 2 * TILE;
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int cidx = tid + 256 * ps;
-      const int off = (cidx / CPR) * PITCH + (cidx % CPR) * 16;
-      *reinterpret_cast<u32x4_t*>(ks_ + off) = kreg[ps];
-      *reinterpret_cast<u32x4_t*>(ks_ + TILE + off) = vreg[ps];
-    }
-  };
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = (t + 1) < ntiles;
-#if COUNTR_FA_ABL == 3 || COUNTR_FA_ABL == 4
-    if (more && t == 0) gload(t + 1);
-#else
-    if (more) gload(t + 1);
-#endif
-    const char* Ks = smem + (t & 1) * 2 * TILE;
-    const char* Vs = Ks + TILE;
-
-    // ---- S^T[kt][qt] : 16 keys x 16 queries per MFMA tile
-    f32x4_t s[KT][QT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4_t{0, 0, 0, 0};
-
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-#if COUNTR_FA_ABL == 1
-          s[kt][qt][0] += __builtin_bit_cast(float, (int)kf[0] | ((int)qf[qt][ks][0] << 16));
-#else
-          s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
-#endif
-        }
-      }
-
-    if (RAGGED && (t + 1) * BKV > N) {  // ragged last tile: keys >= N do not exist (variant only built for N % BKV != 0)
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (t * BKV + kt * 16 + g * 4 + r >= N) {
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s[kt][qt][r] = -INFINITY;
-          }
-    }
-
-    // ---- online softmax (exp2 domain), P packed straight into PV operands
-    bf16x8_t pf[QT][PS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-#if COUNTR_FA_ABL == 5
-      l[qt] += s[0][qt][0];
-#else
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = quad_rows_max(mx);
-      // deferred rescale: while the running max grows by <= 8 (log2 units) keep the old reference max -- P stays
-      // <= 2^8, exact in the fp32 row sum and well inside bf16 range -- and skip the O / l rescale for this tile.
-      const float mloc = mx * c;
-      float mref = m[qt];
-      if (!__all(mloc - mref <= 8.0f)) {
-        const float mnew = fmaxf(mref, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(mref - mnew);
-        m[qt] = mnew;
-        mref = mnew;
-        l[qt] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          o[dt][qt][0] *= alpha; o[dt][qt][1] *= alpha; o[dt][qt][2] *= alpha; o[dt][qt][3] *= alpha;
-        }
-      }
-      float rsum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#if COUNTR_FA_ABL == 2
-          const float p = __builtin_fmaf(s[kt][qt][r], c, -mref);
-#else
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c, -mref));
-#endif
-          s[kt][qt][r] = p;
-          rsum += p;
-        }
-      l[qt] += rsum;
-#endif
-#pragma unroll
-      for (int ps = 0; ps < PS; ++ps) {
-        const uint4 pk = make_uint4(pack2bf(s[2 * ps][qt][0], s[2 * ps][qt][1]), pack2bf(s[2 * ps][qt][2], s[2 * ps][qt][3]),
-                                    pack2bf(s[2 * ps + 1][qt][0], s[2 * ps + 1][qt][1]),
-                                    pack2bf(s[2 * ps + 1][qt][2], s[2 * ps + 1][qt][3]));
-        pf[qt][ps] = __builtin_bit_cast(bf16x8_t, pk);
-      }
-    }
-
-    // ---- O^T[dt][qt] += V^T P^T  (k-slot order kappa(g,e) = {4g+e, 16+4g+e})
-    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
-
-#pragma unroll
-    for (int ps = 0; ps < PS; ++ps)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const char* a0 = Vs + (ps * 32 + 4 * g + (li >> 2)) * PITCH + (dt * 16 + (li & 3) * 4) * 2;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)a0);
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a0 + 16 * PITCH));
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-        s16x8_t vv;
-        vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
-        vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vv);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-#if COUNTR_FA_ABL == 1
-          o[dt][qt][0] += __builtin_bit_cast(float, (int)vf[0] | ((int)pf[qt][ps][0] << 16));
-#else
-          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ps], o[dt][qt], 0, 0, 0);
-#endif
-        }
-      }
-
-
-#if COUNTR_FA_ABL == 3 || COUNTR_FA_ABL == 4
-    if (more && t == 0) lstore((t + 1) & 1);
-#else
-    if (more) lstore((t + 1) & 1);
-#endif
-#if COUNTR_FA_ABL == 4
-    if (t == 0) __syncthreads();
-#else
-    __syncthreads();
-#endif
-  }
-
-  // ---- epilogue: normalise, stage the wave's [16*QT][DH] bf16 block through LDS (the K/V ring is free after the last barrier)
-  // and store whole rows: 16-byte chunks, 8 (dh 64) or 4 (dh 32) consecutive lanes per 128 / 64-byte row segment, instead of
-  // one 8-byte store per lane and MFMA tile at a row stride.  Lane (li, g) owns query q and channels dt*16 + 4g .. +3.
-  char* ost = smem + wave * (16 * QT) * PITCH;
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    float lt = l[qt];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
-    const int q = q0 + qt * 16 + li;
-    const float inv = 1.f / lt;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      const uint2 pk = make_uint2(pack2bf(o[dt][qt][0] * inv, o[dt][qt][1] * inv), pack2bf(o[dt][qt][2] * inv, o[dt][qt][3] * inv));
-      *reinterpret_cast<uint2*>(ost + (qt * 16 + li) * PITCH + (dt * 16 + g * 4) * 2) = pk;
-    }
-    if (lse && g == 0 && q < N) lse[((int64_t)b * H + h) * N + q] = (m[qt] + log2f(lt)) * 0.6931471805599453f;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < (16 * QT * CPR) / 64; ++j) {
-    const int idx = lane + 64 * j, r = idx / CPR, cc = idx % CPR;
-    const int q = q0 + r;
-    const uint4 v = *reinterpret_cast<const uint4*>(ost + r * PITCH + cc * 16);
-    if (q < N) *reinterpret_cast<uint4*>(out + ((int64_t)b * N + q) * (H * DH) + h * DH + cc * 8) = v;
-  }
-}
-
 }  // namespace
 
 // qkv: bf16 [B, N, 3, H, dh] packed (row stride 3*H*dh); out: bf16 [B, N, H*dh]; lse: optional fp32 [B, H, N]
@@ -310,50 +32,7 @@ int countr_attn_fwd_pipelined(const void* qkv, void* out, float* lse, int B, int
 extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream) {
   if (!qkv || !out || B <= 0 || N <= 0 || H <= 0) { countr_set_error("countr_attn_fwd: bad args"); return -1; }
   if (dh != 32 && dh != 64) { countr_set_error("countr_attn_fwd: head_dim must be 32 or 64"); return -1; }
-  const float c = scale * 1.4426950408889634f;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // COUNTR_ATTN_IMPL=1 selects the first-generation (non-pipelined) kernel below: kept for A/B timing (tools/bench_attn.py)
-  static const int impl = [] { const char* e = getenv("COUNTR_ATTN_IMPL"); return e ? atoi(e) : 2; }();
-  if (impl != 1 || scale <= 0.f) return countr_attn_fwd_pipelined(qkv, out, lse, B, N, H, dh, scale, s);
-  // keys per staged K/V tile: 128 halves the barriers / exposed waits per key (COUNTR_ATTN_BKV overrides)
-  static const int force_bkv = [] { const char* e = getenv("COUNTR_ATTN_BKV"); return e ? atoi(e) : 0; }();
-  const int bkv = force_bkv ? force_bkv : 64;
-  const bool ragged = (N % bkv) != 0;
-  // 64 query rows per workgroup for small dh = 32 launches (measured at B = 8: 17.3 vs 18.3 us); dh = 64 is faster with 128
-  // rows at every batch size (B = 8: 20.4 vs 21.8 us, B = 32: 64.8 vs 69.6 us)
-  static const int force_qt = [] { const char* e = getenv("COUNTR_ATTN_QT"); return e ? atoi(e) : 0; }();
-  const long wg128 = (long)B * H * ((N + 127) / 128);
-  const int qt = force_qt ? force_qt : ((dh == 32 && wg128 < 768) ? 1 : 2);
-  dim3 grid(B * H * ((N + 64 * qt - 1) / (64 * qt))), block(256);
-#define COUNTR_FA_LAUNCH(DHV, BKVV, RG, QTV)                                                                                   \
-  do {                                                                                                                         \
-    constexpr int lds_ = 4 * BKVV * fa_pitch(DHV);                                                                                \
-    if (lds_ > 65536) {                                                                                                        \
-      static const bool once_ = [] {                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel<DHV, BKVV, RG, QTV>),                   \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                           \
-        return true;                                                                                                           \
-      }();                                                                                                                     \
-      (void)once_;                                                                                                             \
-    }                                                                                                                          \
-    hipLaunchKernelGGL((flash_attn_fwd_kernel<DHV, BKVV, RG, QTV>), grid, block, lds_, s, (const bf16_t*)qkv, (bf16_t*)out,    \
-                       lse, N, H, c);                                                                                          \
-  } while (0)
-#define COUNTR_FA_DISPATCH(DHV)                                                                                                \
-  do {                                                                                                                         \
-    if (bkv == 128 && qt == 2) { if (ragged) COUNTR_FA_LAUNCH(DHV, 128, true, 2); else COUNTR_FA_LAUNCH(DHV, 128, false, 2); } \
-    else if (qt == 1) { if (ragged) COUNTR_FA_LAUNCH(DHV, 64, true, 1); else COUNTR_FA_LAUNCH(DHV, 64, false, 1); }            \
-    else { if (ragged) COUNTR_FA_LAUNCH(DHV, 64, true, 2); else COUNTR_FA_LAUNCH(DHV, 64, false, 2); }                         \
-  } while (0)
-  if (dh == 64) COUNTR_FA_DISPATCH(64);
-  else if (dh == 32) COUNTR_FA_DISPATCH(32);
-  else {
-    countr_set_error("countr_attn_fwd: head_dim must be 32 or 64");
-    return -1;
-  }
-#undef COUNTR_FA_DISPATCH
-#undef COUNTR_FA_LAUNCH
-  COUNTR_LAUNCH_CHECK("countr_attn_fwd");
+  return countr_attn_fwd_pipelined(qkv, out, lse, B, N, H, dh, scale, reinterpret_cast<hipStream_t>(stream));
 }
 
 // =====================================================================================================

@@ -96,7 +96,7 @@ template <int OFF> __device__ __forceinline__ bf16x8_t fa_read_tr(uint32_t a) { 
 template <int PENDING> __device__ __forceinline__ void fa_lds_wait(bf16x8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(PENDING)); }
 template <int PENDING> __device__ __forceinline__ void fa_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory"); }
 
-// ABL (timing experiments only, selected by COUNTR_FA_ABL; 1-6 give wrong results): 1 = K/V staged in the prologue only (no loads,
+// ABL (timing experiments only, compiled in by -DCOUNTR_FA_ABL_BUILD=<k>; 1-6 give wrong results): 1 = K/V staged in the prologue only (no loads,
 // LDS stores or barriers in the steps), 2 = 1 + no v_exp, 3 = 1 + no MFMA, 4 = staging and barriers only, 5 = empty kernel,
 // 6 = one tile only (prologue + epilogue), 7 = correct output + s_memtime stamps of wave 0 written to lse (tools/stamp_attn.py),
 // 8 = no fragment reads in the steps (MFMAs on stale registers)
@@ -604,14 +604,12 @@ template <int DH>
 int launch_fa_fwd_pipe(const void* qkv, void* out, float* lse, int B, int N, int H, float c, hipStream_t s) {
   using C = FaCfg<DH, DH == 64>;
   dim3 grid(B * H * ((N + 127) / 128)), block(256);
-  static const int abl = [] { const char* e = getenv("COUNTR_FA_ABL"); return e ? atoi(e) : 0; }();
-  if (DH == 64 && abl && N % 64 == 0) {
-    constexpr int lds64 = FaCfg<64, true>::LDS;
-#define COUNTR_FA_ABL_CASE(A) case A: hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, A>), grid, block, lds64, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c); break;
-    switch (abl) { COUNTR_FA_ABL_CASE(1) COUNTR_FA_ABL_CASE(2) COUNTR_FA_ABL_CASE(3) COUNTR_FA_ABL_CASE(4) COUNTR_FA_ABL_CASE(5) COUNTR_FA_ABL_CASE(6) COUNTR_FA_ABL_CASE(7) COUNTR_FA_ABL_CASE(8) COUNTR_FA_ABL_CASE(9) COUNTR_FA_ABL_CASE(10) default: break; }
-#undef COUNTR_FA_ABL_CASE
+#ifdef COUNTR_FA_ABL_BUILD     // timing experiments (bash tools/exp_file.sh flash_attn_fwd abl<k> -DCOUNTR_FA_ABL_BUILD=<k>): results are wrong
+  if (DH == 64 && N % 64 == 0) {
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, COUNTR_FA_ABL_BUILD>), grid, block, (FaCfg<64, true>::LDS), s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
     COUNTR_LAUNCH_CHECK("countr_attn_fwd (ablation)");
   }
+#endif
   if (c <= 0.f) {   // pre-scaled q (see PRE): built for the encoder shape class only
     if (DH != 64 || N % 64) { countr_set_error("countr_attn_fwd: scale <= 0 (pre-scaled q) needs head_dim 64 and N % 64 == 0"); return -1; }
     hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, 0, true>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, 1.f);

@@ -613,11 +613,13 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   if ((int64_t)(a->M + 2 * a->W + 2 + 256) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
   const long tilesN = a->N / 256, tiles = (long)((a->M + 255) / 256) * tilesN;
-  // split rounds (COUNTR_G256_SPLIT=0: never): full rounds here, at most half a round of tiles behind them on the 128-row kernel
+  // split rounds: full rounds here, at most half a round of tiles behind them on the 128-row kernel
   long head = tiles;
   {
     const long full = (tiles / 256) * 256, rem = tiles - full;
-    if (env_int("COUNTR_G256_SPLIT", 1) && full >= 256 && rem > 0 && rem <= 128 && (full % tilesN) == 0 && mode != 0) head = full;
+    // (rem >= 96: the tail launch -- 2 rem workgroups of the 128-row kernel -- must itself fill most of a round; 96x96 at B = 8 has
+    // rem = 32: 64 tail workgroups cost a whole tile-time on a quarter of the chip, 62 + 31 us against 89 us on the 128-row kernel alone)
+    if (full >= 256 && rem >= 96 && rem <= 128 && (full % tilesN) == 0 && mode != 0) head = full;
   }
   if (mode == 1 && head == tiles) {
     const long rounds = (tiles + 255) / 256;

@@ -634,9 +634,6 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.tile_m0 = 0; g.H = g.Wd = g.Cin = 0;
   g.pf = (const char*)a->prefetch; g.pf_bytes = a->prefetch_bytes; g.launch_tiles = 0; g.npf = 0;
   const long tiles = (long)((a->M + 127) / 128) * g.tilesN;
-  int spec_max = 256, big = 1;
-  { const char* e = getenv("COUNTR_LEAN_SPEC_MAX"); if (e) spec_max = atoi(e); }
-  { const char* e = getenv("COUNTR_LEAN_BIG"); if (e) big = atoi(e); }
 #define LIN_LAUNCH(WMB, NLD, ST)                                                                    \
   {                                                                                                 \
     if (ln_in || ln_out) {                                                                          \
@@ -651,19 +648,17 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   // one workgroup per CU at most: 4 compute + 4 loader waves on a 3-stage ring.  (Measured and dropped: 4- and 5-stage rings and 8 loader
   // waves -- the loaders are not waiting for data, their LDS-DMA instructions ISSUE at ~95 cycles each: 32 KB per k-tile at ~42 B/clk per
   // CU is what bounds this form, profiles/r3_linear_stamps.txt)
-  if (tiles <= spec_max) LIN_LAUNCH(1, 4, 3)
+  if (tiles <= 256) LIN_LAUNCH(1, 4, 3)
   // 192 x 256 tiles (96x64 wave tiles, TM = 3) where they need fewer tile-times than the 256x128 grid: qkv at B = 8 (M = 4608, N = 2304) is
   // 324 workgroups of 256x128 = two rounds of 2 units, or 216 of 192x256 = one round of 3
   {
-    int t3 = 1;
-    { const char* e = getenv("COUNTR_LEAN_T3"); if (e) t3 = atoi(e); }
     const long g256 = (long)((a->M + 255) / 256) * (a->N / 128), g192 = (long)((a->M + 191) / 192) * (a->N / 256);
     // rounds x tile work (in 128x128 units: 2 vs 3) of the two grids on 256 CUs
     const long span256 = ((g256 + 255) / 256) * 2, span192 = ((g192 + 255) / 256) * 3;
     // ... and on big grids (>= 4 rounds) also when it needs up to 10 % more tile-times: its unit is cheaper (86 % of the staged bytes
-    // per MFMA) -- zero-shot inference at 32 windows: 8.42-8.46 -> 8.27-8.37 ms with qkv AND fc1 on this form (COUNTR_LEAN_T3=0: never)
+    // per MFMA) -- zero-shot inference at 32 windows: 8.42-8.46 -> 8.27-8.37 ms with qkv AND fc1 on this form
     const long slack = g256 >= 1024 ? 110 : 100;
-    if (t3 && epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && span192 * 100 <= span256 * slack) {
+    if (epi != EPI_RES && (a->N % 256) == 0 && g256 > 256 && span192 * 100 <= span256 * slack) {
       g.tilesN = a->N / 256;
       if (ln_in) {
         if (epi == EPI_BF16) return launch_lin<1, 4, EPI_BF16, 2, false, 2, true, 3>(g, s);
@@ -673,13 +668,10 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
       return launch_lin<1, 4, EPI_GELU, 2, false, 2, false, 3>(g, s);
     }
   }
-  // bigger grids.  Default (COUNTR_LEAN_BIG=1): 256x128 tiles, 8 compute + 4 loader waves, 144-KB ring -- 2/3 of the staged bytes per
-  // MFMA; =2: 128x128 wave-specialised on a 2-stage ring, two workgroups per CU in 128 VGPRs; =0 (and M % 256 != 0): the plain form,
-  // two workgroups per CU, every wave stages and multiplies.  Finetune step on one box: 5.03 / 4.99 / 5.01 ms for 0 / 1 / 2 (with the
-  // 64-bit-address DMA form of the first version the order was the other way round: the big tile was DMA-issue bound).
-  if (big == 1) LIN_LAUNCH(2, 4, 3)
-  if (big == 2 && !ln_in && !ln_out) LIN_LAUNCH(1, 4, 2)
-  LIN_LAUNCH(1, 0, 2)
+  // bigger grids: 256x128 tiles, 8 compute + 4 loader waves, 144-KB ring -- 2/3 of the staged bytes per MFMA.  (Measured and removed:
+  // 128x128 wave-specialised on a 2-stage ring with two workgroups per CU, and the plain form where every wave stages and multiplies
+  // -- finetune step 5.01 / 5.03 ms against 4.99 on one box, profiles/r3_step_ab.txt.)
+  LIN_LAUNCH(2, 4, 3)
 #undef LIN_LAUNCH
 }
 
@@ -718,10 +710,8 @@ int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0) {
   g.xcopy = nullptr; g.stats_out = nullptr; g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f;
   // 128 x 256 tiles when the width allows (the density head's 256 output channels in ONE workgroup: the im2row operand -- nine taps of
   // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128
-  int form = (a->N % 256) == 0 ? 2 : 1;
-  { const char* e = getenv("COUNTR_LEAN_CONV_FORM"); if (e) form = atoi(e); }
-  if (row0 > 0) form = 2;      // (128-row tiles: row0 is a multiple of 128)
-  if (form == 3 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 2, true, 2, false, 3>(g, s); }   // 192 x 256 (experiment)
-  if (form == 2 && (a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 3, true, 2>(g, s); }
+  // (the 192 x 256 form on the convolutions: faster back to back -- 349 -> 331 us -- and not in the step, where the im2row operand
+  // comes from HBM: measured and removed)
+  if ((a->N % 256) == 0) { g.tilesN = a->N / 256; return launch_lin<1, 4, EPI_BF16, 3, true, 2>(g, s); }
   return launch_lin<2, 4, EPI_BF16, 3, true>(g, s);
 }

@@ -946,7 +946,7 @@ extern "C" int countr_colsum_partials(const float* partial, float* out, int npar
 // maps (24x24: 4 splits, 48x48: 16; bwd 38 -> 21 us, 56 -> 35 us) without multiplying the partials of the big ones
 // (96x96: 32, 192x192: 64)
 static int gn_splits(int HW) {
-  static const int capa = [] { const char* e = getenv("COUNTR_GN_SPLIT_CAP"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : (v > 64 ? 64 : v); }();   // 96x96 backward: 16 splits 69.5 us, 32: 60.3, 64: 65.6
+  constexpr int capa = 32;   // 96x96 backward: 16 splits 69.5 us, 32: 60.3, 64: 65.6
   const int a = HW / 144 < capa ? HW / 144 : capa, b = HW / 576 < 64 ? HW / 576 : 64;
   const int ns = a > b ? a : b;
   return ns < 1 ? 1 : ns;
@@ -958,7 +958,7 @@ extern "C" long long countr_groupnorm_bwd_image_sums_offset(int B, int HW) { ret
 // forward statistics: their partials ({mean, M2} per group) are combined in parallel by gn_stats_finalize_kernel, so the big maps
 // can be cut finer than the backward's (whose finishers walk the splits): 144 pixels per block, at most 128 blocks per image
 static int gn_splits_fwd(int HW) {
-  static const int cap = [] { const char* e = getenv("COUNTR_GN_FWD_SPLITS"); return e ? atoi(e) : 128; }();   // 96x96: 37.9 -> 23.7 us
+  constexpr int cap = 128;   // 96x96: 37.9 -> 23.7 us
   const int ns = HW / 144 < cap ? HW / 144 : cap;
   const int lo = gn_splits(HW);
   return ns > lo ? ns : lo;
@@ -996,10 +996,8 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
   if (dtype == COUNTR_BF16) {
     // threads per block of the reduction pass: 512 (16 pixel slots) keeps more loads in flight per CU than 256 (96x96: 31.6 -> 20.8 us,
     // 48x48 and 24x24: 17.4 -> 11.6 us); 1024 falls off a cliff (step +230 us: 128-VGPR budget)
-    static const int nt_env = [] { const char* e = getenv("COUNTR_GN_BWD_NT"); return e ? atoi(e) : 0; }();
-    const int nt = nt_env ? nt_env : (w1 ? 256 : 512);   // (the fused-head form -- 192x192, x only -- is better off with 256: 41.4 vs 44.4 us)
-    if (nt == 1024) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 1024>), dim3(ns, B), dim3(1024), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
-    else if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    const int nt = w1 ? 256 : 512;   // (the fused-head form -- 192x192, x only -- is better off with 256: 41.4 vs 44.4 us)
+    if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);
@@ -1025,7 +1023,7 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
 
 // bands of pooled rows for the split path (0 = one-kernel path): only for the big maps whose (C/64) x S blocks cannot fill the chip
 static int in_splits(int S, int H, int C, int avgpool) {
-  static const int minh = [] { const char* e = getenv("COUNTR_IN_SPLIT_MINH"); return e ? atoi(e) : 32; }();
+  constexpr int minh = 32;
   if (avgpool || (C / 64) * S >= 128 || H < minh) return 0;
   const int Ho = H / 2;
   int ns = Ho >= 32 ? 16 : 8;

@@ -192,32 +192,25 @@ class Engine:
         # transposed bf16 shadows of the trainable decoder Linear weights: dx = dy W becomes a (ROW, ROW) GEMM on W^T and runs the lean
         # kernel (linear.hip) like the forward -- ~4 us per launch against the (ROW, COL) form on gemm_kernel; written by the shadow
         # launch that follows AdamW.  Frozen-encoder engine only: for the MAE step (every Linear trains) the transposes would cost
-        # what they save.  COUNTR_DGRAD_T=0 restores the (ROW, COL) launches
+        # what they save
         self.WtT = {}
-        if (precision == "bf16" and self.FROZEN_ENCODER and os.environ.get("COUNTR_DGRAD_T", "1") != "0"
-                and os.environ.get("COUNTR_LEAN", "1") != "0"):
+        if precision == "bf16" and self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
             for n in lay.train_names:
                 shp = lay.shapes[n]
                 if n.startswith("decoder_blocks.") and n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
                     self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
-        elif (precision == "bf16" and not self.FROZEN_ENCODER and os.environ.get("COUNTR_DGRAD_T_ALL", "0") == "1"
-                and os.environ.get("COUNTR_LEAN", "1") != "0"):
-            # MAE pretraining (every Linear trains and has an input gradient): all 82 transposes = 222 MB for ViT-B in three shadow
-            # launches behind AdamW.  Measured and OFF: 8.40 / 8.39 ms against 8.12 / 8.14 ms -- the transposes cost more than the
-            # (ROW, ROW) launches save at M = 2304
-            for n in lay.train_names:
-                shp = lay.shapes[n]
-                if n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
-                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
+        # (MAE pretraining -- every Linear trains and has an input gradient: all 82 transposes = 222 MB in three shadow launches behind
+        # AdamW -- was measured and removed: 8.40 / 8.39 ms against 8.12 / 8.14 ms, the transposes cost more than the (ROW, ROW) launches
+        # save at M = 2304)
         self.plans = {}
         self.hyper = torch.zeros(8, device=self.device, dtype=torch.float32)   # {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
         self.step_count = 0
         self.group_steps = [0, 0, 0]    # optimizer steps taken by counter group 0 (always), 1 (exemplar CNN), 2 (shot_token)
         self.opt_seen = set()           # conditional gradient buckets (2, 3) that have had a gradient at least once
         self.gnorm = None               # device fp32 [countr_adamw_gnorm_floats()]: [0] = gradient L2 norm of the last step
-        # frozen-encoder q projection packed pre-scaled for the attention kernel (see _pack_prescaled_q); COUNTR_PRESCALE_Q=0 disables
+        # frozen-encoder q projection packed pre-scaled for the attention kernel (see _pack_prescaled_q)
         self.prescale_q = (self.FROZEN_ENCODER and precision == "bf16" and attention != "unfused" and self.D // self.H == 64
-                           and self.N % 64 == 0 and os.environ.get("COUNTR_PRESCALE_Q", "1") != "0")
+                           and self.N % 64 == 0)
         self.qkv_bias_pre = None
         # frozen encoder, bf16: norm1 / norm2 are folded into the qkv / fc1 layers (gamma into the packed weights, beta into the bias;
         # the proj / fc2 / patch-embed epilogues emit the bf16 operand + 64-column row partials, the qkv / fc1 epilogues apply mean and
@@ -228,22 +221,22 @@ class Engine:
         self._ws = {}
         self._need = {}
         self._sizing = False
-        self.reduce_vec4 = os.environ.get("COUNTR_REDUCE_VEC4", "1") != "0"   # 16-byte loads in the deferred-sum kernel
+        self.reduce_vec4 = True      # 16-byte loads in the deferred-sum kernel
         self._defer = {}             # id(ops) -> (ops, [pending reduction entries]): flushed into countr_reduce_table launches
         self._tables = []
         self.warm_weights = os.environ.get("COUNTR_WARM", "1") != "0"     # spare workgroups of a GEMM read the next GEMM's (cold) weight panel
-        self.defer_reduce = os.environ.get("COUNTR_DEFER_REDUCE", "1") != "0"
-        self.splitk_cap = int(os.environ.get("COUNTR_SPLITK_CAP", "64"))     # most fp32 slabs a weight-gradient GEMM is cut into
+        self.defer_reduce = True     # split-K slabs / bias row sums / LayerNorm block partials are summed by table-driven launches
         self._acc = 0                # accumulate flag baked into the parameter-gradient launches being built (gradient accumulation)
         self.generation = 0
         self._sides = None
-        # fork/join of the independent backward branches (wgrad | dgrad | bias grad): measured a wash (9.62 vs 9.56 ms); COUNTR_PARALLEL_LANES=1
-        self.parallel_lanes = os.environ.get("COUNTR_PARALLEL_LANES", "0") == "1"
+        # (fork / join of the independent backward branches -- wgrad | dgrad | bias grad -- measured a wash, 9.62 vs 9.56 ms, and removed:
+        # the fork / lane / join markers inside the launch lists are ignored by run(); only the exemplar branch's "x" markers fork)
+        self.parallel_lanes = False
         # forward: the exemplar CNN (~20 launches of fewer than 200 workgroups, ~0.25 ms serial) runs on a side lane beside the encoder.
         # Round 1 measured this as a loss (6.45 vs 6.20 ms, four graph launches per step); with the whole step in ONE graph it
-        # gains 50-70 us per step at B = 8 (5.63 -> 5.57 ms, three A/B pairs on one box).  COUNTR_OVERLAP_EXEMPLAR=0 serialises again.
-        self.overlap_exemplar = os.environ.get("COUNTR_OVERLAP_EXEMPLAR", "1") != "0"
-        self.act_splitk = os.environ.get("COUNTR_ACT_SPLITK", "1") != "0"     # split-K + finisher for few-tile, long-K forward GEMMs
+        # gains 50-70 us per step at B = 8 (5.63 -> 5.57 ms, three A/B pairs on one box).
+        self.overlap_exemplar = True
+        self.act_splitk = True       # split-K + finisher for few-tile, long-K forward GEMMs
 
     def _make_layout(self, named_shapes):
         return ParamLayout(named_shapes)
@@ -440,8 +433,7 @@ class Engine:
         # (serial as well when the deferred reductions are off -- _conv_wgrad in bwd_tok and _linear_wgrad behind the marker would then
         # share the 'splitk' / 'rowsum' scratch -- and with COUNTR_PARALLEL_LANES=1, whose nested fork / join inside bwd_tok would take
         # the rest of that list off the side lane)
-        if (m is None or not self.overlap_exemplar or self.code != BF16 or not self.defer_reduce or self.parallel_lanes
-                or os.environ.get("COUNTR_OVERLAP_TOKBWD", "1") == "0"):
+        if m is None or not self.overlap_exemplar or self.code != BF16 or not self.defer_reduce or self.parallel_lanes:
             self.run(lists.bwd_rest)
             self.run(lists.bwd_tok)
             return
@@ -547,7 +539,8 @@ class Engine:
         fp32 slabs to reduce)."""
         # (round 1 gave 129..256-tile wgrads two slabs on the plain kernel -- fc1 wgrad 3072x768, 144 tiles: 26.5 vs 29.1 us; since the
         # wave-specialised loop hides its first-fragment latency one slab wins: 24.5 vs 28.1 us, MAE pretrain step 8.78 -> 8.66 ms)
-        return max(1, min(self.splitk_cap, ktiles, 256 // max(tiles, 1)))
+        # (capping the slabs at 8 / 4 to save partial traffic: step 4.82 -> 4.96 / 5.42 ms -- the split is what fills the chip)
+        return max(1, min(64, ktiles, 256 // max(tiles, 1)))
 
     # linear backward pieces.  dy [M,N] (T), x [M,K] (T)
     def _linear_wgrad(self, ops, dy, x, wname, M, N, K, lddy=None, ldx=None, bias_name=None):
@@ -852,8 +845,8 @@ class Engine:
             # activations and -- training plans -- the bf16 NORMALISED maps (ch*) its backward reads.  A bf16 conv output is rounded at
             # 2^-9 of its value; on channels whose mean is several sigma that moves pixels across the ReLU boundary of the normalised
             # map, and the InstanceNorm backward turned it into cos 0.975 per layer / 0.96 for the CNN's weight gradients against fp32
-            # (tools/diag_exemplar_bf16.py).  COUNTR_IN_XHAT=0: bf16 maps, x-hat recomputed (rounds 1-2)
-            xh = bool(code == BF16 and os.environ.get("COUNTR_IN_XHAT", "1") != "0")
+            # (tools/diag_exemplar_bf16.py)
+            xh = bool(code == BF16)
             p.in_xhat = xh
             c = [A("c%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), f32 if xh else T) for i in range(4)]
             ch = [A("ch%d" % (i + 1), (BS, sizes[i], sizes[i], chans[i]), T) for i in range(4)] if (xh and train) else None

@@ -25,8 +25,7 @@ def mae_trainable(name):
 def mae_enc_parts(depth):
     """Encoder gradient buckets.  Every all-reduce overlaps the backward phase behind it, so only the LAST bucket is exposed: six parts
     (two ViT-B blocks = 57 MB of fp32 gradient each, + the 2.4-MB patch embedding in the last) instead of round 2's thirds (115 MB)."""
-    import os
-    return max(1, min(depth, int(os.environ.get("COUNTR_MAE_BUCKETS", "6"))))
+    return max(1, min(depth, 6))
 
 
 def mae_bucket_fn(depth, parts=None):

@@ -85,7 +85,7 @@ class _GraphStep:
     # unless the host runs that far ahead).  The copy stream itself waits for nothing: with a stream-side wait on the step stream's
     # "consumed" event (one slot, the natural formulation) the H2D copy of batch t+1 no longer overlapped step t on ROCm 7.2 --
     # +0.4 ms of exposed PCIe time per step (tools/host_async.py host: 5.8 ms against 5.4 with either wait removed).
-    STAGING_SLOTS = max(1, int(os.environ.get("COUNTR_STAGING_SLOTS", "3")))
+    STAGING_SLOTS = 3
 
     def _staging_consumed(self):
         if hasattr(self, "_copy_stream"):
@@ -532,8 +532,6 @@ class FinetuneStep(_GraphStep):
     def _load_fused(self, p, imgs, boxes, gt, mask, S):
         """All staging copies of a batch in ONE launch (countr_copy_multi) when every source is a dense fp32 device tensor of the
         destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices)."""
-        if os.environ.get("COUNTR_FUSED_LOAD", "1") == "0":
-            return False
         pairs = [(imgs, p.buf["img"]), (gt, self.gt), (mask, self.mask)]
         if S > 0:
             if boxes.dim() != 5 or boxes.shape[1] != S:

@@ -460,43 +460,6 @@ def test_lean_linear_matches_fp64_and_generic(hip, monkeypatch, M, N, K, epi):
     assert (outs[0].double() - outs[1].double()).abs().max().item() <= (8e-3 if obf else 2e-5) * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("big", ["1", "2"])
-@pytest.mark.parametrize("M,N,K", [(4608, 1536, 256), (2304, 3072, 768)])
-@pytest.mark.parametrize("epi", ["bf16", "gelu_pre", "res"])
-def test_lean_linear_alternative_big_grid_forms(hip, monkeypatch, big, M, N, K, epi):
-    """The two wave-specialised forms for grids of more than 256 tiles that are kept selectable (COUNTR_LEAN_BIG=1: 256x128 tiles with
-    8 compute + 4 loader waves; =2: 128x128 on a 2-stage ring, two workgroups per CU) against fp64."""
-    monkeypatch.setenv("COUNTR_LEAN_BIG", big)
-    A = _mk((M, K), torch.bfloat16, 41)
-    W = (_mk((N, K), torch.float32, 42) * 0.25).to(torch.bfloat16)
-    bias = _mk((N,), torch.float32, 43)
-    obf = epi != "res"
-    resid = None if obf else _mk((M, N), torch.float32, 44)
-    z = A.double() @ W.double().t() + bias.double()
-    ref = torch.nn.functional.gelu(z) if epi.startswith("gelu") else z
-    if resid is not None:
-        ref = ref + resid.double()
-    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if obf else torch.float32)
-    pre = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) if epi == "gelu_pre" else None
-    a = _lib.GemmArgs()
-    a.A, a.B, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
-    a.C2 = pre.data_ptr() if pre is not None else None
-    a.bias = bias.data_ptr()
-    a.resid = resid.data_ptr() if resid is not None else None
-    a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
-    a.M, a.N, a.K = M, N, K
-    a.act = 1 if epi.startswith("gelu") else 0
-    a.out_bf16 = int(obf)
-    a.alpha = 1.0
-    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
-    _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
-    torch.cuda.synchronize()
-    tol = 4e-3 if obf else 2e-5
-    assert (out.double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 3e-5
-    if pre is not None:
-        assert (pre.double() - z).abs().max().item() <= 4e-3 * z.abs().max().item()
-
-
 def test_lean_linear_in_place_residual(hip):
     """proj / fc2 write the residual stream in place (C == resid): every element is read before it is written by the same lane."""
     M, N, K = 4608, 768, 768
@@ -518,8 +481,7 @@ def test_lean_linear_in_place_residual(hip):
 
 @pytest.mark.parametrize("Bsz,H,W,Cin,Cout,use_bias", [(2, 96, 96, 256, 256, True), (8, 48, 48, 512, 256, True), (4, 48, 96, 256, 256, False),
                                                    (32, 24, 24, 64, 256, True), (2, 96, 96, 256, 512, False), (3, 100, 100, 64, 256, True)])
-@pytest.mark.parametrize("form", ["", "3"])      # "3": the 192 x 256 tile (96x64 wave tiles, two-stage ring)
-def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H, W, Cin, Cout, use_bias):
+def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin, Cout, use_bias):
     """The density-head / exemplar 3x3 convolutions on the big maps (forward, and dgrad through the dgrad-form weights) run the lean
     kernel of linear.hip with im2row LDS-DMA addressing (256x128 tiles, 8 compute + 4 loader waves): against torch conv2d in fp64 and
     against gemm_kernel (COUNTR_LEAN_CONV=0) on the same bf16 inputs -- zero padding at every image border, tiles that span image
@@ -533,8 +495,7 @@ def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H, W
     ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double() if use_bias else None, padding=1)
     ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
     outs = []
-    if form:
-        monkeypatch.setenv("COUNTR_LEAN_CONV_FORM", form)
+    monkeypatch.setenv("COUNTR_G256", "0")            # (the 256 x 256 kernel has its own test below)
     for lean in ("1", "0"):
         monkeypatch.setenv("COUNTR_LEAN_CONV", lean)
         out = torch.full((M, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -818,13 +779,13 @@ def test_g256_linear_layernorm_consumer(hip, monkeypatch, M, N, K):
 
 @pytest.mark.parametrize("Bsz,H,W,Cin,Cout,use_bias", [(2, 96, 96, 256, 256, True), (1, 192, 192, 256, 256, True), (8, 48, 48, 512, 256, False),
                                                    (3, 100, 100, 128, 512, True), (32, 24, 24, 256, 256, True), (1, 20, 12, 128, 256, True),
-                                                   (3, 160, 160, 128, 256, True)])      # (300 tiles: one full round here + 44 tiles as a 128-row tail launch)
+                                                   (23, 64, 64, 128, 256, True)])      # (368 tiles: one full round here + 112 tiles as a 128-row tail launch of 224 workgroups)
 def test_g256_conv3x3_matches_fp64_and_lean(hip, monkeypatch, Bsz, H, W, Cin, Cout, use_bias):
     """3x3 convolution forward / dgrad on the 256 x 256 8-phase kernel (im2row LDS-DMA descriptors: tap shifts as scalar offsets, padding
     taps and ragged rows as lanes pushed outside the descriptor) with COUNTR_G256=2: against torch conv2d in fp64 and against the
     128x256 form of linear.hip on the same bf16 maps -- zero padding at every border, tiles that span image boundaries (100 x 100,
     24 x 24 = 2.25 images per tile), a map smaller than one tile (20 x 12: most staged rows are masked), Cin = 128 / 256 / 512
-    (2 / 4 / 8 k-tiles per tap), with and without bias; a grid of 1.17 rounds of workgroups, which runs as one full round on this kernel plus
+    (2 / 4 / 8 k-tiles per tap), with and without bias; a grid of 1.44 rounds of workgroups, which runs as one full round on this kernel plus
     a tail launch of the 128-row kernel on the last rows (split rounds); three runs must agree bit for bit (race screen)."""
     x = _mk((Bsz, H, W, Cin), torch.bfloat16, 151)
     w = (_mk((Cout, 3, 3, Cin), torch.float32, 152) * 0.1).to(torch.bfloat16)

@@ -49,7 +49,7 @@ def test_mae_layout_buckets_cover_all_trainable_parameters():
     shapes = [(n, s) for n, s, _ in W.schema_mae()]
     from countr_amd.mae_engine import mae_enc_parts
     assert mae_enc_parts(12) == 6 and mae_enc_parts(2) == 2
-    old = mae_bucket_fn(12, parts=3)                       # round 2's thirds, still selectable (COUNTR_MAE_BUCKETS=3)
+    old = mae_bucket_fn(12, parts=3)                       # round 2's thirds (the function still takes a part count)
     assert [old("blocks.%d.attn.qkv.weight" % i) for i in range(12)] == [3] * 4 + [2] * 4 + [1] * 4 and old("patch_embed.proj.weight") == 3
     mae_bucket = mae_bucket_fn(12)
     NB = 7                                                  # decoder side + six encoder groups of two blocks

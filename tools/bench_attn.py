@@ -1,11 +1,10 @@
 """Micro-benchmark of countr_attn_fwd at the encoder / decoder shapes (bf16).  Prints us and TF/s; checks vs fp64.
 
-python tools/bench_attn.py            # both implementations (COUNTR_ATTN_IMPL=1 first generation, 2 pipelined), one subprocess each
-python tools/bench_attn.py --one      # the implementation selected by COUNTR_ATTN_IMPL in this process
+python tools/bench_attn.py            # (COUNTR_LIB=<variant .so> times an experimental build: bash tools/exp_file.sh flash_attn_fwd <tag> ...)
 The timed loop rotates over several qkv buffers (each launch reads a buffer that was not touched by the previous launch) so the
 figure is closer to what the kernel sees inside a step than 50 launches on one cache-hot tensor.
 """
-import ctypes as C, os, subprocess, sys
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -47,9 +46,4 @@ def one():
 
 
 if __name__ == "__main__":
-    if "--one" in sys.argv:
-        one()
-    else:
-        for impl in ("1", "2"):
-            print("== COUNTR_ATTN_IMPL=%s" % impl, flush=True)
-            subprocess.call([sys.executable, os.path.abspath(__file__), "--one"], env=dict(os.environ, COUNTR_ATTN_IMPL=impl))
+    one()

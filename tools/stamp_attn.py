@@ -1,6 +1,6 @@
-"""s_memtime anatomy of the pipelined attention forward (COUNTR_FA_ABL=7 build path): per-workgroup cycle counters of wave 0."""
+"""s_memtime anatomy of the pipelined attention forward: per-workgroup cycle counters of wave 0.  Needs the stamp build:
+bash tools/exp_file.sh flash_attn_fwd abl7 -DCOUNTR_FA_ABL_BUILD=7; run with COUNTR_LIB=tools/_abl/libcountr_abl7.so."""
 import ctypes as C, os, sys
-os.environ["COUNTR_FA_ABL"] = "7"; os.environ["COUNTR_ATTN_IMPL"] = "2"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from countr_amd import _lib
