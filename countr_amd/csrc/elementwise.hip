@@ -380,6 +380,28 @@ __global__ __launch_bounds__(256) void conv_shadows_kernel(const ConvShadowTable
   const float* __restrict__ src = t.src[e];
   T* __restrict__ wf = reinterpret_cast<T*>(t.wf[e]);
   T* __restrict__ wd = reinterpret_cast<T*>(t.wd[e]);
+  if (taps == 1) {
+    // a Linear weight [Co][Ci] -> its transpose [Ci][Co] (+ the plain cast when wf is given): 64 x 64 tiles, 256-byte source runs and
+    // 128-byte destination runs (the 32 x 8 tiles below read 32-byte runs: these 8.4 M elements were 2/3 of the launch's time)
+    __shared__ float tt[64][65];
+    const int tci = (Ci + 63) / 64, nt = ((Co + 63) / 64) * tci;
+    for (int tl = blockIdx.x; tl < nt; tl += gridDim.x) {
+      const int co0 = (tl / tci) * 64, ci0 = (tl % tci) * 64;
+      __syncthreads();
+      for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63, co = co0 + r, ci = ci0 + c;
+        const float v = (co < Co && ci < Ci) ? src[(int64_t)co * Ci + ci] : 0.f;
+        tt[r][c] = v;
+        if (wf && co < Co && ci < Ci) stf<T>(wf + (int64_t)co * Ci + ci, v);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63, ci = ci0 + r, co = co0 + c;
+        if (co < Co && ci < Ci) stf<T>(wd + (int64_t)ci * Co + co, tt[c][r]);
+      }
+    }
+    return;
+  }
   const int run = CS_CI * taps;                   // floats per co row of the tile (taps <= 9)
   for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
     const int co0 = (tl / tiles_ci) * 32, ci0 = (tl % tiles_ci) * CS_CI;

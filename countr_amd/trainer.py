@@ -26,6 +26,7 @@ class _GraphStep:
         self._touched = set()          # conditional buckets that received a gradient in the current accumulation window
         self.per_rank = False          # FinetuneStep(per_rank_shot=True): every rank draws its own shot_num (reference semantics)
         self._touched_any = set()      # ... then: conditional buckets that received a gradient on ANY rank in this window
+        self._pending = None           # staging copies of load() not launched yet: (src ptrs, dst ptrs, sizes, tensors kept alive)
         self.eng = model._engine()
         self.B = batch
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -200,6 +201,26 @@ class _GraphStep:
                 return
         self.graphs[gk] = g
 
+    def _flush_pending(self, extra=None):
+        """Launch the staging copies load() deferred -- together with `extra` = (src, dst, bytes), the AdamW scalars read by the kernel
+        straight from pinned host memory -- as ONE countr_copy_multi: the separate SDMA copy of the scalars between two graph replays
+        cost a queue hand-over (~25 us of idle GPU per step, tools/seq_step.sh)."""
+        pend, self._pending = self._pending, None
+        pairs = list(zip(*pend[:3])) if pend is not None else []
+        if extra is not None:
+            pairs.append(extra)
+        if not pairs:
+            return
+        n = len(pairs)
+        vp = C.c_void_p * n
+        _lib.check(self.eng.L.countr_copy_multi(n, vp(*[a for a, _b, _c in pairs]), vp(*[b for _a, b, _c in pairs]),
+                                                (C.c_int64 * n)(*[c for _a, _b, c in pairs]), self.eng._stream()), "copy_multi")
+        if pend is not None:
+            self._staging_consumed()
+            for t in pend[3]:
+                if t.is_cuda:
+                    t.record_stream(self.stream)
+
     def _upload_hyper(self, skip=()):
         """Step-dependent AdamW scalars go through a small device buffer so that graph replay sees new values.  Bias corrections
         are per counter group (torch.optim.AdamW counts steps per parameter): group 0 steps always, group 1 (exemplar CNN, bucket
@@ -221,7 +242,10 @@ class _GraphStep:
             t = max(eng.group_steps[grp], 1)
             h[i1] = 1.0 - self.betas[0] ** t
             h[i2] = 1.0 - self.betas[1] ** t
-        eng.hyper.copy_(h, non_blocking=True)
+        if self._pending is not None:
+            self._flush_pending(extra=(h.data_ptr(), eng.hyper.data_ptr(), 32))
+        else:
+            eng.hyper.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._ring_ev[slot] = ev
@@ -362,6 +386,10 @@ class _GraphStep:
             if eng.M is None:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
+            # the staging copies of load() travel with the AdamW scalars (_upload_hyper) when those are uploaded IN FRONT of the phases:
+            # the last micro-step of a window in the two whole-step-graph forms; otherwise they are launched here
+            if not (last and self.use_graph and (not self.sync.comm or self.sync.capturable)):
+                self._flush_pending()
             phases = self._phases(key)
             # this step's forward overwrites the plan's activation buffers (also when it is a graph replay): a pending autograd
             # backward of an earlier module forward with the same (batch, shot_num) must refuse (models_mae_cross._DecoderFn)
@@ -513,25 +541,29 @@ class FinetuneStep(_GraphStep):
 
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
-        """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream."""
+        """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream.  Dense fp32 device tensors of
+        the buffers' shapes are copied by ONE launch that step() issues together with the AdamW scalars (the sources are kept alive
+        until then); anything else is copied here, tensor by tensor."""
         cur = torch.cuda.current_stream(self.eng.device)
         self.stream.wait_stream(cur)           # producers of the inputs ran on the caller's stream
         src = (imgs, boxes, gt, mask)
         imgs, boxes, gt, mask = self._to_device(src)
         with torch.cuda.stream(self.stream):
             p = self.eng.plan(self.B, S, True)
-            if not self._load_fused(p, imgs, boxes, gt, mask, S):
+            self._pending = None
+            if not self._load_fused(p, imgs, boxes, gt, mask, S, keep=src):
                 self.eng._load_inputs(p, imgs, boxes, S)
                 self.gt.copy_(gt, non_blocking=True)
                 self.mask.copy_(mask, non_blocking=True)
-            self._staging_consumed()
-        for t in src:                          # their memory must not be recycled before our copies have run
-            if t.is_cuda:
-                t.record_stream(self.stream)
+                self._staging_consumed()
+                for t in src:                          # their memory must not be recycled before our copies have run
+                    if t.is_cuda:
+                        t.record_stream(self.stream)
 
-    def _load_fused(self, p, imgs, boxes, gt, mask, S):
+    def _load_fused(self, p, imgs, boxes, gt, mask, S, keep=()):
         """All staging copies of a batch in ONE launch (countr_copy_multi) when every source is a dense fp32 device tensor of the
-        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices)."""
+        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices).  The
+        launch is deferred to step() (_flush_pending)."""
         pairs = [(imgs, p.buf["img"]), (gt, self.gt), (mask, self.mask)]
         if S > 0:
             if boxes.dim() != 5 or boxes.shape[1] != S:
@@ -541,11 +573,8 @@ class FinetuneStep(_GraphStep):
             if (not torch.is_tensor(src) or not src.is_cuda or src.dtype != dst.dtype or not src.is_contiguous() or src.numel() != dst.numel()
                     or (src.numel() * src.element_size()) % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16):
                 return False
-        n = len(pairs)
-        vp = C.c_void_p * n
-        _lib.check(self.eng.L.countr_copy_multi(n, vp(*[s_.data_ptr() for s_, _ in pairs]), vp(*[d.data_ptr() for _, d in pairs]),
-                                                (C.c_int64 * n)(*[s_.numel() * s_.element_size() for s_, _ in pairs]), self.eng._stream()),
-                   "copy_multi")
+        self._pending = ([s_.data_ptr() for s_, _ in pairs], [d.data_ptr() for _, d in pairs], [s_.numel() * s_.element_size() for s_, _ in pairs],
+                         [s_ for s_, _ in pairs] + [t for t in keep if torch.is_tensor(t)])
         return True
 
     def step(self, S, lr=None, shots_all=None):
