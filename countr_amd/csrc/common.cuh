@@ -171,6 +171,27 @@ extern "C" void countr_set_error(const char* msg);
 int countr_check_launch(const char* what);
 #define COUNTR_LAUNCH_CHECK(what) return countr_check_launch(what)
 
+// K order of the 3x3 convolutions' implicit GEMMs in linear.hip / gemm256.hip (K = 9 taps x Cin, k-tile = 64 channels of one tap):
+// 1 = channel-chunk-major -- k-tile t is tap t % 9 of chunk t / 9, so nine consecutive k-tiles read the SAME 128-byte pieces of the
+// map's pixels (shifted by a row / a pixel): the working set of an XCD's 32 workgroups over those nine k-tiles is ~1.1 MB and stays in
+// its 4-MB L2; tap-major (0) walks the whole 4.4-MB footprint once per tap and re-fetched the 192x192 map 4.9 x per launch from the
+// memory side (profiles/r4_conv_pmc.txt).  Both kernels use the same order (their results agree bit for bit).
+#ifndef COUNTR_CONV_CHUNK_MAJOR
+#define COUNTR_CONV_CHUNK_MAJOR 1
+#endif
+// (tap, channel offset) of k-tile t for Cin = 64 << cpt_log; t / 9 as (t * 57) >> 9 is exact for t < 80 (Cin <= 512: t <= 73)
+__device__ __forceinline__ void countr_conv_ktile(int t, int Cin, int& tap, int& cb) {
+#if COUNTR_CONV_CHUNK_MAJOR
+  const int c = (t * 57) >> 9;
+  tap = t - 9 * c;
+  cb = c << 6;
+#else
+  const int k0 = t << 6;
+  tap = k0 / Cin;
+  cb = k0 - tap * Cin;
+#endif
+}
+
 // The first workgroups of a GEMM launch (blockIdx.x < npf) warm the cache with a read-only range -- the next launch's weight
 // panel -- and leave: block j of npf reads every npf-th 16-byte x blockDim slice; the values go nowhere (countr_gemm_args.prefetch).
 __device__ __forceinline__ void countr_prefetch_range(const char* p, long long bytes, int j, int npf) {

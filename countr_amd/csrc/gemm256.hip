@@ -206,7 +206,8 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
     char* dst = dma_dst + (kind ? B_BASE : 0) + (2 * u + buf) * UNIT;
     if constexpr (kind == 0) {
       if constexpr (CONV) {
-        const int tap = t >> g.cpt_log, cb = (t - (tap << g.cpt_log)) << 6;
+        int tap, cb;
+        countr_conv_ktile(t, g.Cin, tap, cb);
         const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
         const uint32_t so = (uint32_t)(cshift + ((int64_t)((ty - 1) * g.Wd + (tx - 1)) * g.Cin + cb) * 2);
 #pragma unroll
@@ -227,9 +228,11 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
       }
     } else {
       const uint32_t vo = voffB | kill;
+      uint32_t kb = (uint32_t)t * 128u;            // byte offset of k-tile t inside a W row ([tap][Cin] for a convolution)
+      if constexpr (CONV) { int tap, cb; countr_conv_ktile(t, g.Cin, tap, cb); kb = (uint32_t)(tap * g.Cin + cb) * 2u; }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + j * 8192), 16, vo, t * 128 + (4 * j + u) * passB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + j * 8192), 16, vo, kb + (4 * j + u) * passB, 0, 0);
     }
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;

@@ -605,8 +605,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     // (A channel-chunk-outer / tap-inner walk of the convolutions' k-tiles was tried for L2 locality and removed in round 2: FETCH_SIZE
     // 122 vs 115 MB x 2 per launch and 376 vs 373 us -- no effect; fabric traffic is 1.6 x the algorithmic input either way,
     // profiles/r2_gemm_conv192_pmc.txt.)
+    // ... round 4: with the faster kernels of linear.hip / gemm256.hip it does pay in the step (4.62 -> 4.58 ms), and this kernel follows
+    // their order on unsplit convolutions so that a sample's result does not depend on which kernel its batch size selects
+    // (common.cuh: COUNTR_CONV_CHUNK_MAJOR)
+    const bool chunk_major = COUNTR_CONV_CHUNK_MAJOR && MA == COUNTR_OP_IM2ROW && kstart == 0 && kend == g.K && g.K == 9 * g.Cin && ntiles <= 79;
     auto ktile = [&](int t) {
-      int tt = t + kskew; if (tt >= ntiles) tt -= ntiles; return kstart + tt * BK;
+      int tt = t + kskew; if (tt >= ntiles) tt -= ntiles;
+      if (chunk_major) { const int c = (tt * 57) >> 9; return (tt - 9 * c) * g.Cin + c * BK; }
+      return kstart + tt * BK;
     };
     constexpr int NLW = SPEC ? NLD : NW;   // waves that stage tiles
     DmaLoader<MA, BMt, NLW> la;

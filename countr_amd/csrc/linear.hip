@@ -186,10 +186,13 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
     if (t >= 2) return;
 #endif
     char* dst = smem + slot * STAGE_BYTES + cw * 1024;
+    uint32_t kb = (uint32_t)t * 128u;              // byte offset of k-tile t inside a W row
     if constexpr (CONV) {
       // k-tile t = 64 channels of one tap (64 | Cin): scalar offset = tap shift + channel block, per-lane pixel offset, and one bit
       // test per piece for the zero padding (offset 2^31 is out of the descriptor's range: the DMA writes zeros)
-      const int k0 = t * 64, tap = k0 / g.Cin, cb = k0 - tap * g.Cin;
+      int tap, cb;
+      countr_conv_ktile(t, g.Cin, tap, cb);
+      kb = (uint32_t)(tap * g.Cin + cb) * 2u;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
       const uint32_t so = (uint32_t)(cshift + ((int64_t)(dy * g.Wd + dx) * g.Cin + cb) * 2);
       const uint32_t bit = 1u << tap;
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + A_BYTES + i * NLW * 1024), 16, voffB, t * 128 + i * passB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + A_BYTES + i * NLW * 1024), 16, voffB, kb + i * passB, 0, 0);
   };
 
   // loader waves start the ring before anything else; the memory clobber keeps the prefetch loads below BEHIND these in issue order
