@@ -1,4 +1,4 @@
-"""s_memtime anatomy of the lean linear kernel's wave-specialised loop (build: bash tools/exp_lin.sh stamp -DLIN_STAMP; run with
+"""s_memtime anatomy of the lean linear kernel's wave-specialised loop (build: bash tools/exp_file.sh linear stamp -DLIN_STAMP; run with
 COUNTR_LIB=tools/_abl/libcountr_stamp.so).  Per k-tile means over all workgroups: loaders {load wait, barrier, DMA issue}, compute waves
 {barrier, everything else}, plus the shader clock during the loop (s_memtime / s_memrealtime)."""
 import ctypes as C, os, sys
