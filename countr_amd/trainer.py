@@ -36,7 +36,7 @@ class _GraphStep:
         # all work of the step (input copies, graph replays, collectives' producers) runs on ONE dedicated non-default
         # stream; sources are record_stream()'ed so the caching allocator cannot recycle them under a pending copy.
         # (Captured regions contain kernels only: a hipMemsetAsync node + float atomics gave wrong sums under graph
-        # replay on ROCm 7.2 -- tools/dbg_ft3.py -- so the loss reduction is a deterministic two-stage kernel pair.)
+        # replay on ROCm 7.2 (round 1) -- so the loss reduction is a deterministic two-stage kernel pair.)
         self.stream = torch.cuda.Stream(device=self.eng.device)
         self._gen = self.eng.generation
         self.sums = {}
