@@ -557,28 +557,23 @@ class Engine:
         q.alpha, q.nbatch, q.nb1 = 1.0, 1, 1
         tiles = int(self.L.countr_gemm_tiles(C.byref(q), self.code, OP_COL, OP_COL))     # 128x128, or 128x256 on the lean kernel (conv_wgrad.hip)
         sk = self._splitk(tiles, -(-M // bk))
-        defer = self.defer_reduce
-        part = self._shared(("skp." + self._role(wname)) if defer else "splitk", sk * N * K)
+        part = self._shared("skp." + self._role(wname), sk * N * K)
         fuse_bias = bias_name is not None and self.code == BF16
-        rs = self._shared(("rsp." + self._role(wname)) if defer else "rowsum", 64 * 4096) if fuse_bias else None
-        if defer:
-            self._claim(part.data_ptr())
+        rs = self._shared("rsp." + self._role(wname), 64 * 4096) if fuse_bias else None
+        self._claim(part.data_ptr())
         kw.update(partial=part.data_ptr(), splitk=sk)
         rslabs = sk
         if fuse_bias:
             q.splitk = sk
-            n = int(self.L.countr_gemm_rowsum_slabs(C.byref(q), self.code, OP_COL, OP_COL)) if defer else sk
+            n = int(self.L.countr_gemm_rowsum_slabs(C.byref(q), self.code, OP_COL, OP_COL))
             if n * N <= 64 * 4096:
                 rslabs = n
-            kw.update(rowsum_partial=rs.data_ptr(), rowsum_slabs=(rslabs if defer else 0))
+            kw.update(rowsum_partial=rs.data_ptr(), rowsum_slabs=rslabs)
         self._gemm(ops, self.code, OP_COL, OP_COL, **kw)
-        if defer:
-            self._reduce_later(ops, part.data_ptr(), part.data_ptr(), self._gp(wname), sk, N * K, N * K)
-            if fuse_bias:
-                self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), rslabs, N, N)
-        else:
-            self._op(ops, self.L.countr_splitk_reduce, part.data_ptr(), self._gp(wname), sk, N, K, 0, self._acc,
-                     rs.data_ptr() if fuse_bias else None, self._gp(bias_name) if fuse_bias else None)
+        # slab sums are deferred to the list's table-driven launches (countr_reduce_table)
+        self._reduce_later(ops, part.data_ptr(), part.data_ptr(), self._gp(wname), sk, N * K, N * K)
+        if fuse_bias:
+            self._reduce_later(ops, part.data_ptr(), rs.data_ptr(), self._gp(bias_name), rslabs, N, N)
         if bias_name is not None and not fuse_bias:
             self._bias_grad(ops, dy, bias_name, M, N)
 
@@ -621,20 +616,15 @@ class Engine:
 
     def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate, dx_t=None):
         """dx_t (bf16 mode): also emit the updated residual gradient as the bf16 operand of the next backward GEMM."""
-        if self.defer_reduce:    # per-block {dgamma, dbeta} partials stay in this LayerNorm's own workspace until the list's table launch
-            nb = self.L.countr_layernorm_bwd_nblocks()
-            ws = self._shared("lnw." + self._role(name), nb * 2 * D)
-            self._claim(ws.data_ptr())
-            self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
-                     rstd.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), rows, D,
-                     int(dy.dtype == torch.bfloat16), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
-            self._reduce_later(ops, ws.data_ptr(), ws.data_ptr(), self._gp(name + ".weight"), nb, 2 * D, D)
-            self._reduce_later(ops, ws.data_ptr(), ws.data_ptr() + 4 * D, self._gp(name + ".bias"), nb, 2 * D, D)
-            return dx if self.code == F32 else dx_t
-        ws = self._shared("lnbwd", 256 * 2 * 2048)
+        # per-block {dgamma, dbeta} partials stay in this LayerNorm's own workspace until the list's table launch
+        nb = self.L.countr_layernorm_bwd_nblocks()
+        ws = self._shared("lnw." + self._role(name), nb * 2 * D)
+        self._claim(ws.data_ptr())
         self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
-                 rstd.data_ptr(), dx.data_ptr(), self._gp(name + ".weight"), self._gp(name + ".bias"), ws.data_ptr(), rows, D,
-                 int(dy.dtype == torch.bfloat16), int(accumulate), self._acc, dx_t.data_ptr() if dx_t is not None else None)
+                 rstd.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), rows, D,
+                 int(dy.dtype == torch.bfloat16), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
+        self._reduce_later(ops, ws.data_ptr(), ws.data_ptr(), self._gp(name + ".weight"), nb, 2 * D, D)
+        self._reduce_later(ops, ws.data_ptr(), ws.data_ptr() + 4 * D, self._gp(name + ".bias"), nb, 2 * D, D)
         return dx if self.code == F32 else dx_t
 
     # unfused self-attention forward on a packed qkv [rows, 3*Dm]
@@ -928,6 +918,8 @@ class Engine:
         gn_ws = self._shared("gn", max(int(L.countr_groupnorm_bwd_image_sums_offset(B, h * h)) for h in hs) + B * 3 * 256)
         o1 = A("o1", (B, hs[3] * hs[3]), f32)
         out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
+        # (GroupNorm-apply + ReLU + bilinear x2 as ONE kernel was built in round 4: 75 us for the three stages against 78.5 for the two-
+        # kernel chain -- the nine transformed loads per coarse pixel cost what the saved round trip of the activated map gains -- removed)
         hact_tmp = self._shared("hact_tmp", B * hs[2] * hs[2] * 256, T)
         for i in range(4):
             hn = "decode_head%d" % i
