@@ -60,9 +60,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // Backward: dx (+)= rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)); per-block partial dgamma / dbeta.
 // Grid = NB blocks of LNB_WAVES waves (8: two resident waves per SIMD hide the row-to-row latency; 4 measured 15 vs ~10 us);
-// wave w of block b walks rows (b*LNB_WAVES+w), +LNB_WAVES*NB, ...
+// wave w of block b walks rows (b*LNB_WAVES+w), +LNB_WAVES*NB, ... TWO rows per trip (round 4): the loads of both are in flight before
+// the first wave reduction, so 4608 rows on 2048 waves are 1.25 memory round trips instead of 2.25 (the MAE step has 42 of these
+// launches).  MAXV = 4-element column groups per lane (D <= 256 MAXV) is a template parameter: with the arrays sized for D = 2048 a
+// wave held ~170 VGPRs whatever D was.
 constexpr int LNB_WAVES = 8;
-template <typename TI>
+template <typename TI, int MAXV>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
@@ -71,51 +74,64 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
   extern __shared__ __attribute__((aligned(16))) char smem_ln[];
   float* sm = reinterpret_cast<float*>(smem_ln);  // [LNB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int MAXV = 8;
   float dg[MAXV][4], db[MAXV][4];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
-  for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
-    const float mu = mean[row], rs = rstd[row];
-    const TI* dyr = dy + (int64_t)row * D;
-    const float* xr = x + (int64_t)row * D;
-    float xh[MAXV][4], gy[MAXV][4], od[MAXV][4];
-    float s1 = 0.f, s2 = 0.f;
-    float* dxr = dx + (int64_t)row * D;
+  const int rstride = gridDim.x * LNB_WAVES;
+  for (int row0 = blockIdx.x * LNB_WAVES + wave; row0 < rows; row0 += 2 * rstride) {
+    float xh[2][MAXV][4], gy[2][MAXV][4], od[2][MAXV][4];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2];
+    bool have[2];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = i * 256 + lane * 4;
-      if (c < D) {
-        float d[4], xv[4], g[4];
-        ld4<TI>(dyr + c, d);
-        ld4<float>(xr + c, xv);
-        ld4<float>(gamma + c, g);
-        // the residual gradient to accumulate into is requested with the row's other loads, not after the two wave reductions
-        if (accumulate) ld4<float>(dxr + c, od[i]); else { od[i][0] = od[i][1] = od[i][2] = od[i][3] = 0.f; }
+    for (int r = 0; r < 2; ++r) {
+      const int row = row0 + r * rstride;
+      have[r] = row < rows;            // wave-uniform
+      if (!have[r]) continue;
+      const float mu = mean[row];
+      rsv[r] = rstd[row];
+      const TI* dyr = dy + (int64_t)row * D;
+      const float* xr = x + (int64_t)row * D;
+      const float* dxr = dx + (int64_t)row * D;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][e] = (xv[e] - mu) * rs;
-          gy[i][e] = d[e] * g[e];
-          s1 += gy[i][e];
-          s2 += gy[i][e] * xh[i][e];
-          dg[i][e] += d[e] * xh[i][e];
-          db[i][e] += d[e];
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+          float d[4], xv[4], g[4];
+          ld4<TI>(dyr + c, d);
+          ld4<float>(xr + c, xv);
+          ld4<float>(gamma + c, g);
+          // the residual gradient to accumulate into is requested with the row's other loads, not after the two wave reductions
+          if (accumulate) ld4<float>(dxr + c, od[r][i]); else { od[r][i][0] = od[r][i][1] = od[r][i][2] = od[r][i][3] = 0.f; }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[r][i][e] = (xv[e] - mu) * rsv[r];
+            gy[r][i][e] = d[e] * g[e];
+            s1[r] += gy[r][i][e];
+            s2[r] += gy[r][i][e] * xh[r][i][e];
+            dg[i][e] += d[e] * xh[r][i][e];
+            db[i][e] += d[e];
+          }
         }
       }
     }
-    s1 = wave_sum(s1) / D;
-    s2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = i * 256 + lane * 4;
-      if (c < D) {
-        float o[4];
+    for (int r = 0; r < 2; ++r) {
+      if (!have[r]) continue;
+      const int row = row0 + r * rstride;
+      const float m1 = wave_sum(s1[r]) / D, m2 = wave_sum(s2[r]) / D;
+      float* dxr = dx + (int64_t)row * D;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = od[i][e] + rs * (gy[i][e] - s1 - xh[i][e] * s2);
-        st4<float>(dxr + c, o);
-        if (dx_bf16) st4<bf16_t>(dx_bf16 + (int64_t)row * D + c, o);   // GEMM-operand copy of the updated residual gradient
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = od[r][i][e] + rsv[r] * (gy[r][i][e] - m1 - xh[r][i][e] * m2);
+          st4<float>(dxr + c, o);
+          if (dx_bf16) st4<bf16_t>(dx_bf16 + (int64_t)row * D + c, o);   // GEMM-operand copy of the updated residual gradient
+        }
       }
     }
   }
@@ -916,16 +932,25 @@ extern "C" int countr_layernorm_bwd(const void* dy, const float* x, const float*
                                     float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int D,
                                     int dy_bf16, int accumulate_dx, int accumulate_dgb, void* dx_bf16, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace || D % 4 || D > 2048) { countr_set_error("countr_layernorm_bwd: bad args"); return -1; }
-  const int nb = 256;
+  const int nb = countr_layernorm_bwd_nblocks();
   const size_t lds = (size_t)LNB_WAVES * 2 * D * sizeof(float);
-  static bool attr_set = false;   // D > 1024 needs more than the default 64 KiB of dynamic LDS
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
-    attr_set = true;
+#define COUNTR_LNB_LAUNCH(TI, MV)                                                                                                          \
+  {                                                                                                                                        \
+    static bool attr_set = false;   /* D > 1024 needs more than the default 64 KiB of dynamic LDS */                                       \
+    if (!attr_set) {                                                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel<TI, MV>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                LNB_WAVES * 2 * 256 * MV * 4);                                                                             \
+      attr_set = true;                                                                                                                     \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, MV>), dim3(nb), dim3(64 * LNB_WAVES), lds, STREAM(stream), (const TI*)dy, x, gamma, mean,  \
+                       rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);                                                     \
   }
-  if (dy_bf16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(64 * LNB_WAVES), lds, STREAM(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(64 * LNB_WAVES), lds, STREAM(stream), (const float*)dy, x, gamma, mean, rstd, dx, (bf16_t*)dx_bf16, workspace, rows, D, accumulate_dx);
+#define COUNTR_LNB_BY_D(TI)                                                        \
+  if (D <= 512) COUNTR_LNB_LAUNCH(TI, 2) else if (D <= 768) COUNTR_LNB_LAUNCH(TI, 3) \
+  else if (D <= 1024) COUNTR_LNB_LAUNCH(TI, 4) else COUNTR_LNB_LAUNCH(TI, 8)
+  if (dy_bf16) { COUNTR_LNB_BY_D(bf16_t) } else { COUNTR_LNB_BY_D(float) }
+#undef COUNTR_LNB_BY_D
+#undef COUNTR_LNB_LAUNCH
   // workspace rows are {dgamma[D], dbeta[D]} per block; adjacent outputs (the flat gradient buffer) finish in one launch
   if (dgamma && dbeta == dgamma + D) {
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, STREAM(stream), workspace, dgamma, nb, 2 * D, (int64_t)2 * D, accumulate_dgb);

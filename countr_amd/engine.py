@@ -191,17 +191,22 @@ class Engine:
             self.Wd[n] = torch.zeros(numel, device=self.device, dtype=self.tdt)
         # transposed bf16 shadows of the trainable decoder Linear weights: dx = dy W becomes a (ROW, ROW) GEMM on W^T and runs the lean
         # kernel (linear.hip) like the forward -- ~4 us per launch against the (ROW, COL) form on gemm_kernel; written by the shadow
-        # launch that follows AdamW.  Frozen-encoder engine only: for the MAE step (every Linear trains) the transposes would cost
-        # what they save
+        # launch that follows AdamW
         self.WtT = {}
         if precision == "bf16" and self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
             for n in lay.train_names:
                 shp = lay.shapes[n]
                 if n.startswith("decoder_blocks.") and n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
                     self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
-        # (MAE pretraining -- every Linear trains and has an input gradient: all 82 transposes = 222 MB in three shadow launches behind
-        # AdamW -- was measured and removed: 8.40 / 8.39 ms against 8.12 / 8.14 ms, the transposes cost more than the (ROW, ROW) launches
-        # save at M = 2304)
+        # MAE pretraining (every Linear trains and has an input gradient): all 82 transposes = 222 MB, refreshed in three shadow launches
+        # behind AdamW.  Round 3 measured this as a loss at 8 images (8.40 against 8.12 ms: the transposes cost 376 us, more than the
+        # (ROW, ROW) launches saved at M = 2304); with round 4's 64x64-tile transposes and the warm-up hints -- which only the (ROW, ROW)
+        # kernels honour -- it is neutral at 8 images (7.82 vs 7.80 ms) and a gain at config 4's 16: 10.79 -> 10.55 ms (two A/B pairs)
+        elif precision == "bf16" and not self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
+            for n in lay.train_names:
+                shp = lay.shapes[n]
+                if n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
+                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
         self.plans = {}
         self.hyper = torch.zeros(8, device=self.device, dtype=torch.float32)   # {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
         self.step_count = 0
