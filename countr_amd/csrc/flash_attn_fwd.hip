@@ -32,6 +32,9 @@
 #ifndef COUNTR_FA_NOPIN
 #define COUNTR_FA_NOPIN 0   // experiments: 1 = no end-of-slot sched_barrier in the pipelined step, 2 = one every fourth slot, 3 = none at all
 #endif
+#ifndef COUNTR_FA_PRIO
+#define COUNTR_FA_PRIO 0
+#endif
 #include <stdlib.h>
 #include <utility>
 
@@ -152,6 +155,13 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   if (ABL == 5 && N > 0) return;
   uint64_t tk0 = 0, tkc = 0, tks = 0, tkb = 0, tkp = 0;
   if (ABL == 7) tk0 = __builtin_readcyclecounter();
+#if COUNTR_FA_PRIO   // experiment (round-3 verdict, 3e): static priority by wave slot -- the two waves of a SIMD alternate instead of contending
+  {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(4, 0, 4)" : "=s"(hw));    // HW_ID.wave_id: the slot of this wave on its SIMD
+    if (hw & 1) __builtin_amdgcn_s_setprio(COUNTR_FA_PRIO);
+  }
+#endif
 
   // ---- Q^T fragments (MFMA B operand): lane (ql, hh) holds channels 16 ks + 8 hh .. +7 of query q0 + ql
   bf16x8_t qf[KS];

@@ -187,7 +187,7 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   if (modeB == COUNTR_OP_COL && (a->N % epc)) { countr_set_error("countr_gemm: N must be a multiple of the chunk for COL B"); return -1; }
   if ((modeA == COUNTR_OP_IM2ROW || modeB == COUNTR_OP_IM2COL) && (a->Cin % 64 || a->H <= 0 || a->W <= 0)) { countr_set_error("countr_gemm: conv modes need Cin % 64 == 0"); return -1; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_ROW && modeB == COUNTR_OP_ROW && a->act <= COUNTR_ACT_GELU) {
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_ROW && modeB == COUNTR_OP_ROW) {   // (GELU_BWD: the lean kernel only)
     const int rb = countr_big_linear(a, s);    // chip-filling grids of 256 x 256 tiles (fc1): the 8-phase kernel of gemm256.hip
     if (rb != 1) return rb;
     const int rc = countr_lean_linear(a, s);   // full-tile nn.Linear forward shapes: the lean kernel of linear.hip

@@ -36,7 +36,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr_t;
 typedef const __attribute__((address_space(1))) void* glb_vptr_t;
 typedef __attribute__((address_space(3))) const char* lds_cptr_t;
 
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RES = 2 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RES = 2, EPI_GBWD = 3 };   // GBWD: out = acc * GELU'(C2), C2 = saved bf16 pre-activation (fc2 input gradient)
 
 struct LinArgs {
   const char* A;       // [M, lda] bf16
@@ -527,6 +527,14 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
           p[2] = f32x2_t{v1[0] + bcol[4], v1[1] + bcol[5]}; p[3] = f32x2_t{v1[2] + bcol[6], v1[3] + bcol[7]};
         }
         const int64_t o = ((int64_t)m * g.ldc + sn0 + ccol) * 2;
+        if constexpr (EPI == EPI_GBWD) {   // autograd of GELU fused into the fc2 input gradient: the same derivative as countr_gelu_bwd, applied to the fp32 sum
+          const u32x4_t h = *reinterpret_cast<const u32x4_t*>(g.C2 + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p[e][0] *= gelu_fast_grad(__uint_as_float(h[e] << 16));
+            p[e][1] *= gelu_fast_grad(__uint_as_float(h[e] & 0xffff0000u));
+          }
+        }
         if constexpr (EPI == EPI_GELU) {
           if (g.C2) *reinterpret_cast<u32x4_t*>(g.C2 + o) = u32x4_t{pack2bf(p[0][0], p[0][1]), pack2bf(p[1][0], p[1][1]), pack2bf(p[2][0], p[2][1]), pack2bf(p[3][0], p[3][1])};
 #pragma unroll
@@ -618,6 +626,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
     if (a->act == COUNTR_ACT_NONE && !a->C2) epi = EPI_BF16;
 #endif
     else if (a->act == COUNTR_ACT_GELU) epi = EPI_GELU;
+    else if (a->act == COUNTR_ACT_GELU_BWD && a->C2 && !a->ln_stats && !a->ln_colsum && !a->ln_xcopy && !a->ln_stats_out) epi = EPI_GBWD;
     else return 1;
   } else {
 #ifndef LIN_STAMP
@@ -646,6 +655,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
     }                                                                                               \
     if (epi == EPI_BF16) return launch_lin<WMB, NLD, EPI_BF16, ST>(g, s);                           \
     if (epi == EPI_GELU) return launch_lin<WMB, NLD, EPI_GELU, ST>(g, s);                           \
+    if (epi == EPI_GBWD) return launch_lin<WMB, NLD, EPI_GBWD, ST>(g, s);                           \
     return launch_lin<WMB, NLD, EPI_RES, ST>(g, s);                                                 \
   }
   // one workgroup per CU at most: 4 compute + 4 loader waves on a 3-stage ring.  (Measured and dropped: 4- and 5-stage rings and 8 loader
@@ -668,6 +678,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
         return launch_lin<1, 4, EPI_GELU, 2, false, 2, true, 3>(g, s);
       }
       if (epi == EPI_BF16) return launch_lin<1, 4, EPI_BF16, 2, false, 2, false, 3>(g, s);
+      if (epi == EPI_GBWD) return launch_lin<1, 4, EPI_GBWD, 2, false, 2, false, 3>(g, s);
       return launch_lin<1, 4, EPI_GELU, 2, false, 2, false, 3>(g, s);
     }
   }

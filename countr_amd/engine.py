@@ -19,7 +19,7 @@ import re
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL, ACT_NONE, ACT_GELU, GemmArgs
+from ._lib import F32, BF16, OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL, ACT_NONE, ACT_GELU, ACT_GELU_BWD, GemmArgs
 
 ALIGN = 64  # elements; every tensor starts on a 256-byte boundary of the flat buffers
 
@@ -586,26 +586,34 @@ class Engine:
         ws = self._shared("colsum", 256 * 4096)
         self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, self._acc)
 
-    def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None):
-        """dx[M,K] = dy[M,N] W[N,K] (+ resid)."""
+    def _linear_dgrad(self, ops, dy, wname, dx, M, N, K, resid=None, out_bf16=None, gelu_pre=None):
+        """dx[M,K] = dy[M,N] W[N,K] (+ resid).  gelu_pre (the saved pre-activation h of x = GELU(h), layout of dx): dx *= GELU'(h) --
+        in the GEMM's epilogue where the lean kernel serves the launch (bf16, transposed shadow), otherwise as a separate pass.
+        (Measured, profiles/r4_gelu_bwd_fuse_ab.txt: the derivative costs the GEMM's epilogue 6.6-10.9 us -- 2 transcendentals + 15 VALU per
+        element with the matrix pipes idle -- against 8-12 us for the separate bandwidth-bound pass: 20 launches fewer, ~1 us each saved.)"""
         out_bf16 = (dx.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
         if wname in self.WtT:      # W^T [K][N]: (ROW, ROW), the lean kernel
+            fuse = gelu_pre is not None and self.code == BF16 and out_bf16 and resid is None
             self._gemm(ops, self.code, OP_ROW, OP_ROW, A=dy.data_ptr(), B=self.WtT[wname].data_ptr(), C=dx.data_ptr(),
                        resid=(resid.data_ptr() if resid is not None else None), lda=N, ldb=N, ldc=K, ldres=K, M=M, N=K, K=N,
-                       out_bf16=int(out_bf16))
+                       out_bf16=int(out_bf16), **({"act": ACT_GELU_BWD, "C2": gelu_pre.data_ptr()} if fuse else {}))
+            if gelu_pre is not None and not fuse:
+                self._op(ops, self.L.countr_gelu_bwd, dx.data_ptr(), gelu_pre.data_ptr(), dx.data_ptr(), M * K, self.code)
             return
         self._gemm(ops, self.code, OP_ROW, OP_COL, A=dy.data_ptr(), B=self._wp(wname), C=dx.data_ptr(),
                    resid=(resid.data_ptr() if resid is not None else None), lda=N, ldb=K, ldc=K, ldres=K, M=M, N=K, K=N,
                    out_bf16=int(out_bf16))
+        if gelu_pre is not None:
+            self._op(ops, self.L.countr_gelu_bwd, dx.data_ptr(), gelu_pre.data_ptr(), dx.data_ptr(), M * K, self.code)
 
-    def _linear_bwd(self, ops, dy, x, wname, M, N, K, dx=None, resid=None, dx_bf16=None):
+    def _linear_bwd(self, ops, dy, x, wname, M, N, K, dx=None, resid=None, dx_bf16=None, gelu_pre=None):
         """bias grad | weight grad | input grad of one nn.Linear: three independent branches."""
         self._fork(ops)
         self._lane(ops, 2)
         self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=wname[:-6] + "bias")
         if dx is not None:
             self._lane(ops, 0)
-            self._linear_dgrad(ops, dy, wname, dx, M, N, K, resid=resid, out_bf16=dx_bf16)
+            self._linear_dgrad(ops, dy, wname, dx, M, N, K, resid=resid, out_bf16=dx_bf16, gelu_pre=gelu_pre)
         self._join(ops)
 
     def _cast(self, ops, src_f32, dst_t, n):
@@ -1032,8 +1040,7 @@ class Engine:
                 b = "decoder_blocks.%d" % i
                 d = blk[i]
                 # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))  (g_t = bf16/fp32 operand view of gx, emitted by the LN backward)
-                self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh)
-                self._op(ops, L.countr_gelu_bwd, dh.data_ptr(), d["hpre"].data_ptr(), dh.data_ptr(), rows * 4 * Dd, code)
+                self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh, gelu_pre=d["hpre"])
                 self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t)
                 g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=gxT)
                 # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))

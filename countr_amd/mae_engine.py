@@ -97,8 +97,7 @@ class MaeEngine(Engine):
         L, code = self.L, self.code
         rows = B * N
         gx = s["gx"]
-        self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dm, 4 * Dm, dx=s["dh"])
-        self._op(ops, L.countr_gelu_bwd, s["dh"].data_ptr(), d["hpre"].data_ptr(), s["dh"].data_ptr(), rows * 4 * Dm, code)
+        self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dm, 4 * Dm, dx=s["dh"], gelu_pre=d["hpre"])
         self._linear_bwd(ops, s["dh"], d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dm, Dm, dx=s["dn_t"])
         g_t = self._layernorm_bwd(ops, s["dn_t"], d["x1"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dm, accumulate=True, dx_t=s["gxT"])
         self._linear_bwd(ops, g_t, d["att"], b + ".attn.proj.weight", rows, Dm, Dm, dx=s["dproj_in"])

@@ -110,6 +110,54 @@ def test_gemm_gelu_backward_epilogue(hip, dt):
     assert hip.countr_gemm(C.byref(a), 0 if dt == torch.float32 else 1, 0, 1, _stream()) != 0
 
 
+@pytest.mark.parametrize("shape", [(800, 3072, 768), (3152, 2048, 512), (4608, 2048, 512), (1000, 1024, 256)])
+def test_gelu_backward_epilogue_on_the_lean_kernel(hip, shape, monkeypatch):
+    """The fc2 input gradient with the transposed weight shadow ((ROW, ROW), bf16): dx = (dy @ Wt^T) * GELU'(pre) in the epilogue of
+    linear.hip's three tile forms (one round of 128 x 128, 192 x 256, 256 x 128) == the generic kernel's fused form bit for bit (same
+    accumulation order, same derivative), and within bf16 rounding of fp64 autograd (reference: Mlp.forward, models_crossvit.py:61-67)."""
+    M, N, K = shape                   # dy [M, K], Wt [N, K] (= fc2.weight^T), out / pre [M, N]
+    dy = _mk((M, K), torch.bfloat16, 21)
+    Wt = _mk((N, K), torch.bfloat16, 22)
+    pre = (_mk((M, N), torch.float32, 23) * 3).to(torch.bfloat16)
+    keep = pre.clone()
+
+    def run(lean):
+        monkeypatch.setenv("COUNTR_LEAN", "1" if lean else "0")
+        monkeypatch.setenv("COUNTR_G256", "1" if lean else "0")
+        out = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C, a.C2 = dy.data_ptr(), Wt.data_ptr(), out.data_ptr(), pre.data_ptr()
+        a.lda, a.ldb, a.ldc = K, K, N
+        a.M, a.N, a.K = M, N, K
+        a.act = _lib.ACT_GELU_BWD
+        a.out_bf16 = 1
+        a.alpha = 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+        torch.cuda.synchronize()
+        return out
+    lean, generic = run(True), run(False)
+    assert torch.equal(pre, keep)
+    x = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(dy.double() @ Wt.double().t())
+    assert (lean.double() - x.grad).abs().max().item() <= 2e-2 * x.grad.abs().max().item()
+    assert (lean.double() - generic.double()).abs().max().item() <= 1e-2 * x.grad.abs().max().item()
+    # ... and against the two launches it replaces (GEMM -> bf16, then countr_gelu_bwd): one bf16 rounding apart
+    monkeypatch.setenv("COUNTR_LEAN", "1")
+    two = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C = dy.data_ptr(), Wt.data_ptr(), two.data_ptr()
+    a.lda, a.ldb, a.ldc = K, K, N
+    a.M, a.N, a.K = M, N, K
+    a.out_bf16 = 1
+    a.alpha = 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+    _lib.check(hip.countr_gelu_bwd(two.data_ptr(), pre.data_ptr(), two.data_ptr(), M * N, 1, _stream()), "gelu_bwd")
+    torch.cuda.synchronize()
+    assert (lean.double() - two.double()).abs().max().item() <= 1.2e-2 * x.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_batched_and_splitk(hip, dt):
     # batched: q k^T per (b, h) read straight out of a packed qkv [B, N, 3, H, dh]
