@@ -84,6 +84,10 @@ __device__ __forceinline__ float row16_sum(float x) {
   x += dpp_mov<0x140>(x);   // row_mirror
   return x;
 }
+// sum of four squares with the contractions written out: the LayerNorm producers of linear.hip and gemm256.hip must agree bit for bit
+__device__ __forceinline__ float countr_sq4(float a, float b, float c, float d) {
+  return __builtin_fmaf(a, a, b * b) + __builtin_fmaf(c, c, d * d);
+}
 __device__ __forceinline__ float row16_max(float x) {
   x = fmaxf(x, dpp_mov<0xB1>(x));
   x = fmaxf(x, dpp_mov<0x4E>(x));

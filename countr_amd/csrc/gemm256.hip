@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((address_space(3))) void* lds_vptr_t;
 typedef __attribute__((address_space(3))) const char* lds_cptr_t;
 
-enum { EPI_BF16 = 0, EPI_GELU = 1 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RES = 2 };   // RES: fp32 out = acc + bias + resid (+ the LayerNorm producer's bf16 copy and row partials)
 
 struct BigArgs {
   const char* A;       // [M, lda] bf16, or CONV: NHWC map [B, H, Wd, Cin]
@@ -44,6 +44,10 @@ struct BigArgs {
   char* C;             // bf16 [M, ldc]
   char* C2;            // EPI_GELU: optional bf16 pre-activation copy
   const float* bias;   // [N]
+  const float* resid;  // EPI_RES: fp32 [*, ldres], row m % res_mod when res_mod > 0
+  char* xcopy;         // EPI_RES, LayerNorm producer (optional): bf16 copy of the fp32 output [M, ldc]
+  float* stats_out;    // ... and [M][N/64][2] = {sum, sum of squares} of the output row over each 64-column block
+  int ldres, res_mod;
   int M, N, K;
   int lda, ldw, ldc;   // elements
   int tilesN;
@@ -517,6 +521,27 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
         pp[0] = f32x2_t{v0[0] + bcol[0], v0[1] + bcol[1]}; pp[1] = f32x2_t{v0[2] + bcol[2], v0[3] + bcol[3]};
         pp[2] = f32x2_t{v1[0] + bcol[4], v1[1] + bcol[5]}; pp[3] = f32x2_t{v1[2] + bcol[6], v1[3] + bcol[7]};
       }
+      if constexpr (EPI == EPI_RES) {
+        // same operations in the same order as linear.hip's EPI_RES epilogue ((acc + bias) + resid; row partials as a balanced tree over
+        // 4-column leaves in column order): a row's result does not depend on which of the two kernels its batch size selects
+        const float* rp = g.resid + (int64_t)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldres + sn0 + ccol;
+        const f4_t r0 = *reinterpret_cast<const f4_t*>(rp), r1 = *reinterpret_cast<const f4_t*>(rp + 4);
+        f4_t a = v0 + f4_t{bcol[0], bcol[1], bcol[2], bcol[3]}, b = v1 + f4_t{bcol[4], bcol[5], bcol[6], bcol[7]};
+        a += r0; b += r1;
+        float* cp = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + sn0 + ccol;
+        *reinterpret_cast<f4_t*>(cp) = a;
+        *reinterpret_cast<f4_t*>(cp + 4) = b;
+        if (g.xcopy) {
+          *reinterpret_cast<u32x4_t*>(g.xcopy + ((int64_t)m * g.ldc + sn0 + ccol) * 2) = u32x4_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+          float s1 = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+          float s2 = countr_sq4(a[0], a[1], a[2], a[3]) + countr_sq4(b[0], b[1], b[2], b[3]);
+          s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);     // lanes l ^ 1
+          s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);     // lanes l ^ 2
+          s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);   // the other quad of the row's 8 lanes (row_half_mirror)
+          if ((lane & 7) == 0) *reinterpret_cast<float2*>(g.stats_out + ((int64_t)m * (g.N >> 6) + (sn0 >> 6)) * 2) = make_float2(s1, s2);
+        }
+        continue;
+      }
       const int64_t o = ((int64_t)m * g.ldc + sn0 + ccol) * 2;
       if constexpr (EPI == EPI_GELU) {
         if (g.C2) *reinterpret_cast<u32x4_t*>(g.C2 + o) = u32x4_t{pack2bf(pp[0][0], pp[0][1]), pack2bf(pp[1][0], pp[1][1]), pack2bf(pp[2][0], pp[2][1]), pack2bf(pp[3][0], pp[3][1])};
@@ -553,24 +578,31 @@ int env_int(const char* name, int dflt) { const char* e = getenv(name); return e
 
 }  // namespace
 
-// nn.Linear forward (bf16 out, optional GELU / pre-activation copy / LayerNorm-fold consumer) on 256 x 256 tiles.  Returns 1 when the
+// nn.Linear forward (bf16 out with optional GELU / pre-activation copy / LayerNorm-fold consumer, or fp32 out = acc + bias + residual with the
+// optional LayerNorm producer outputs: attn.proj / mlp.fc2 of the encoder at 32 windows -- inference 8.00 -> 7.88 ms) on 256 x 256 tiles.  Returns 1 when the
 // launch does not qualify or the 128-row forms of linear.hip are expected to be faster (the caller then tries those).
 int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
   const int mode = env_int("COUNTR_G256", 1);      // 0: never; 1: where it is expected to win; 2: wherever it qualifies (tests)
   if (mode == 0) return 1;
-  if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial || a->resid || !a->out_bf16) return 1;
+  if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial) return 1;
   if (a->M < 1 || (a->N % 256) || (a->K % 128) || a->K < 256 || a->N > 8192) return 1;
+  const bool res = !a->out_bf16;      // fp32 out = acc + bias + residual (proj / fc2), optionally a LayerNorm producer
+  if (res) {
+    if (!a->resid || a->act != COUNTR_ACT_NONE || a->C2 || (a->ldc % 4) || (a->ldres % 4) || ((uintptr_t)a->resid & 15)) return 1;
+    if ((a->ln_xcopy != nullptr) != (a->ln_stats_out != nullptr) || ((uintptr_t)a->ln_xcopy & 15) || ((uintptr_t)a->ln_stats_out & 7)) return 1;
+    if (a->ln_stats || a->ln_colsum) return 1;
+  } else if (a->resid || a->ln_xcopy || a->ln_stats_out) return 1;
   if ((a->lda % 8) || (a->ldb % 8) || (a->ldc % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2) & 15)) return 1;
   if ((int64_t)256 * a->lda * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll || (int64_t)256 * a->ldb * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
-  if (a->ln_xcopy || a->ln_stats_out) return 1;
   const bool ln_in = a->ln_stats != nullptr || a->ln_colsum != nullptr;
   if (ln_in && (!a->ln_stats || !a->ln_colsum || (((uintptr_t)a->ln_stats | (uintptr_t)a->ln_colsum) & 15) || a->ln_nblk != a->K / 64 || a->K > 768)) return 1;
   int epi;
+  if (res) epi = EPI_RES;
 #ifdef G256_STAMP
-  if (a->act == COUNTR_ACT_NONE) epi = EPI_BF16;      // stamp builds: C2 carries the stamp buffer
+  else if (a->act == COUNTR_ACT_NONE) epi = EPI_BF16;      // stamp builds: C2 carries the stamp buffer
 #else
-  if (a->act == COUNTR_ACT_NONE && !a->C2) epi = EPI_BF16;
+  else if (a->act == COUNTR_ACT_NONE && !a->C2) epi = EPI_BF16;
 #endif
   else if (a->act == COUNTR_ACT_GELU) epi = EPI_GELU;
   else return 1;
@@ -587,10 +619,12 @@ int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = bias;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = a->N / 256;
   g.launch_tiles = (int)tiles; g.pf = (const char*)a->prefetch; g.pf_bytes = a->prefetch_bytes;
+  g.resid = a->resid; g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.ldres = (int)a->ldres; g.res_mod = a->res_mod;
   g.H = g.Wd = g.Cin = g.cpt_log = 0; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps; g.stamps = nullptr;
 #ifdef G256_STAMP
   g.stamps = (float*)a->C2; g.C2 = nullptr;
 #endif
+  if (epi == EPI_RES) return launch_big<false, EPI_RES, false>(g, s);
   if (ln_in) return epi == EPI_BF16 ? launch_big<false, EPI_BF16, true>(g, s) : launch_big<false, EPI_GELU, true>(g, s);
   return epi == EPI_BF16 ? launch_big<false, EPI_BF16, false>(g, s) : launch_big<false, EPI_GELU, false>(g, s);
 }
@@ -641,6 +675,7 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = nullptr; g.bias = bias;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = 0; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = (int)tilesN;
   g.launch_tiles = (int)head; g.pf = nullptr; g.pf_bytes = 0;
+  g.resid = nullptr; g.xcopy = nullptr; g.stats_out = nullptr; g.ldres = 0; g.res_mod = 0;
   g.H = a->H; g.Wd = a->W; g.Cin = a->Cin; g.cpt_log = a->Cin == 128 ? 1 : a->Cin == 256 ? 2 : 3;
   g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f; g.stamps = nullptr;
 #ifdef G256_STAMP

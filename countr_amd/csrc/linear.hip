@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
         if constexpr (LNOUT) {   // bf16 copy for the next GEMM's A operand + this 64-column block's row partials (16 lanes = one row)
           *reinterpret_cast<uint2*>(g.xcopy + ((int64_t)m * g.ldc + sn0 + ccol) * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
           const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
-          const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+          const float s2 = row16_sum(countr_sq4(v[0], v[1], v[2], v[3]));
           if ((lane & 15) == 0) *reinterpret_cast<float2*>(g.stats_out + ((int64_t)m * (g.N >> 6) + (sn0 >> 6)) * 2) = make_float2(s1, s2);
         }
       }

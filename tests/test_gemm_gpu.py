@@ -791,6 +791,59 @@ def test_g256_linear_matches_fp64_and_lean(hip, monkeypatch, M, N, K, epi):
     assert torch.equal(outs["2"], outs["0"]), (outs["2"].double() - outs["0"].double()).abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,res_mod", [(18432, 768, 768, 0), (18432, 768, 3072, 0), (1000, 512, 384, 0), (1152, 256, 256, 576), (40, 768, 256, 0)])
+@pytest.mark.parametrize("producer", [True, False])
+def test_g256_linear_residual_and_layernorm_producer(hip, monkeypatch, M, N, K, res_mod, producer):
+    """The residual epilogue of the 256 x 256 kernel (attn.proj / mlp.fc2 of the encoder at 32 windows: fp32 out = acc + bias + residual,
+    optionally with the LayerNorm producer's bf16 copy and per-64-column {sum, sum of squares} row partials): against fp64 and --
+    output, copy and partials BIT FOR BIT -- against linear.hip's kernel (COUNTR_G256=0), ragged M and a row-modulo residual included.
+    Reference: Block.forward x = x + attn(norm1(x)); x = x + mlp(norm2(x)) (timm 0.4.9, models_mae_cross.py:32-34)."""
+    A = _mk((M, K), torch.bfloat16, 141)
+    W = (_mk((N, K), torch.float32, 142) * 0.25).to(torch.bfloat16)
+    bias = _mk((N,), torch.float32, 143)
+    resid = _mk((res_mod if res_mod else M, N), torch.float32, 144) * 3.0
+    rr = resid.double().repeat(M // res_mod, 1) if res_mod else resid.double()
+    ref = A.double() @ W.double().t() + bias.double() + rr
+    got = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("COUNTR_G256", mode)
+        runs = []
+        for rep in range(3 if mode == "2" else 1):
+            out = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.float32)
+            xcopy = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            stats = torch.full((M + 8, N // 64, 2), float("nan"), device="cuda", dtype=torch.float32)
+            a = _lib.GemmArgs()
+            a.A, a.B, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+            a.bias, a.resid = bias.data_ptr(), resid.data_ptr()
+            a.lda, a.ldb, a.ldc, a.ldres = K, K, N, N
+            a.res_mod = res_mod
+            a.M, a.N, a.K = M, N, K
+            a.out_bf16 = 0
+            a.alpha = 1.0
+            a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+            if producer:
+                a.ln_xcopy, a.ln_stats_out = xcopy.data_ptr(), stats.data_ptr()
+            _lib.check(hip.countr_gemm(C.byref(a), 1, 0, 0, _stream()), "gemm")
+            torch.cuda.synchronize()
+            assert torch.isnan(out[M:]).all() and torch.isnan(xcopy[M:].float()).all() and torch.isnan(stats[M:]).all()
+            assert (out[:M].double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+            if producer:
+                o = out[:M].double()
+                want = torch.stack([o.view(M, N // 64, 64).sum(-1), (o * o).view(M, N // 64, 64).sum(-1)], dim=-1)
+                assert (stats[:M].double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+                assert torch.equal(xcopy[:M], out[:M].to(torch.bfloat16))
+            else:
+                assert torch.isnan(xcopy.float()).all() and torch.isnan(stats).all()
+            runs.append((out[:M].clone(), xcopy[:M].clone(), stats[:M].clone()))
+        for r in runs[1:]:
+            assert torch.equal(r[0], runs[0][0]), "run-to-run difference (phase-schedule race)"
+        got[mode] = runs[0]
+    assert torch.equal(got["2"][0], got["0"][0]), (got["2"][0].double() - got["0"][0].double()).abs().max().item()
+    if producer:
+        assert torch.equal(got["2"][1], got["0"][1])
+        assert torch.equal(got["2"][2], got["0"][2]), (got["2"][2].double() - got["0"][2].double()).abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(4608, 3072, 768), (18432, 3072, 768), (1152, 1536, 512), (300, 256, 256)])
 def test_g256_linear_layernorm_consumer(hip, monkeypatch, M, N, K):
     """The LayerNorm-fold consumer epilogue of the 256 x 256 kernel (fc1 in the frozen encoder: rstd (acc - mean colsum) + bias' from the
