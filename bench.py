@@ -356,8 +356,16 @@ def other_workloads(args, dev, steps=10, warmup=3):
 
     def child(*extra):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--precision", args.precision] + list(extra)
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        # a plain single-process run: nothing of the parent's launcher may leak in.  (torch.distributed.run also exports
+        # TORCHELASTIC_USE_AGENT_STORE: with it a child that initialises a process group waits for the AGENT's store on a port nobody
+        # serves -- the one-rank RCCL launch of tests/test_ddp_gpu.py hung here until its timeout.)
+        drop = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE",
+                "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "COUNTR_BENCH_INIT_PG", "COUNTR_FORCE_COMM", "COUNTR_GRAPH_COMM")
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC"))}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        except subprocess.TimeoutExpired:
+            return {"error": "child process timed out after 300 s"}
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": (r.stderr or r.stdout)[-400:]}

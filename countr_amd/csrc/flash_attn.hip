@@ -39,38 +39,38 @@ extern "C" int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, in
 // Fused attention backward (autograd of Attention.forward, models_crossvit.py:84-91) without materialising P.
 //   P_ij = exp2(s_ij * c - lse2_i),  dV_j = sum_i P_ij dO_i,  dP_ij = dO_i . V_j,  delta_i = dO_i . O_i,
 //   dS_ij = P_ij (dP_ij - delta_i),  dQ_i = scale * sum_j dS_ij K_j,  dK_j = scale * sum_i dS_ij Q_i.
-// One template, two passes (no atomics, deterministic):
+// One template, two passes in ONE launch (no atomics, deterministic):
 //   MODE 0 (dQ)    : a workgroup owns 128 query rows (Q, dO fragments resident in VGPRs), streams K/V tiles through LDS;
-//                    also emits delta[b,h,i] for the second pass.
-//   MODE 1 (dK,dV) : a workgroup owns 128 keys (K, V fragments resident), streams Q/dO tiles (+ lse, delta) through LDS.
+//                    delta of its own rows from the resident dO and O.
+//   MODE 1 (dK,dV) : a workgroup owns 128 keys (K, V fragments resident), streams Q/dO tiles (+ lse, and delta = dO . O computed from the
+//                    O tile while staging) through LDS.
 // Both passes use the forward kernel's layouts: "S-type" products X[streamed][resident] = T R^T with the streamed tile as
 // the MFMA A operand (ds_read_b128) and the resident fragment as B; "PV-type" accumulations acc^T += T^T Y with T^T read by
 // ds_read_b64_tr_b16 in the k-slot order kappa(g,e) = {4g+e, 16+4g+e}, so Y (P or dS) is packed from the lane's own registers.
 // =====================================================================================================
 namespace {
 
+// bid / nblk: this pass's workgroup index and count (the launch holds both passes: flash_attn_bwd_kernel below)
 template <int DH, int MODE, bool RAGGED>
-__global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
-                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
-                                                             float scale) {
+__device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int nblk, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H,
+                                            float scale) {
   constexpr int KS = DH / 32, DT = DH / 16, PITCH = fa_pitch(DH), TILE = FA_BKV * PITCH, CPR = DH / 8;
   constexpr int PASSES = (FA_BKV * CPR) / 256;
   constexpr int STAGE = 2 * TILE + 512;  // two streamed tiles + (MODE 1) 64 lse2 + 64 delta floats
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const float c = scale * 1.4426950408889634f;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int rblocks = (N + FA_BQ - 1) / FA_BQ;
   int bh, rb;
-  const int nbh = gridDim.x / rblocks;
-  if ((nbh & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int nbh = nblk / rblocks;
+  if ((nbh & 7) == 0) {   // (nblk is then a multiple of 8: bid & 7 is the XCD in both halves of the launch)
+    const int xcd = bid & 7, j = bid >> 3;
     bh = xcd * (nbh >> 3) + j / rblocks;
     rb = j - (j / rblocks) * rblocks;
   } else {
-    bh = blockIdx.x / rblocks;
-    rb = blockIdx.x - bh * rblocks;
+    bh = bid / rblocks;
+    rb = bid - bh * rblocks;
   }
   const int b = bh / H, h = bh - b * H;
   const int64_t rs = (int64_t)3 * H * DH, ro = (int64_t)H * DH;
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
   const bf16_t* dop = dout + (int64_t)b * N * ro + h * DH;
   const bf16_t* op = outp + (int64_t)b * N * ro + h * DH;
   const float* lsep = lse + (int64_t)bh * N;
-  float* delp = delta + (int64_t)bh * N;
   const int r0 = rb * FA_BQ + wave * 32;  // first resident row (query for MODE 0, key for MODE 1) of this wave
 
   // ---- resident fragments: R1 (Q | K) and R2 (dO | V), MFMA B-operand layout: lane (li, g) holds row r0 + rt*16 + li
@@ -116,7 +115,6 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
       dot += __shfl_xor(dot, 32, 64);
       dl[rt] = dot;
       lse2[rt] = (r < N) ? lsep[r] * 1.4426950408889634f : 0.f;
-      if (g == 0 && r < N) delp[r] = dot;
     }
   }
 
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
   const bf16_t* t2p = (MODE == 0) ? vp : dop;
   const int64_t t2s = (MODE == 0) ? rs : ro;
   const int ntiles = (N + FA_BKV - 1) / FA_BKV;
-  uint4 t1reg[PASSES], t2reg[PASSES];
+  uint4 t1reg[PASSES], t2reg[PASSES], oreg[MODE == 1 ? PASSES : 1];
   float streg = 0.f;
   auto gload = [&](int t) {
 #pragma unroll
@@ -141,15 +139,16 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
       const int row = t * FA_BKV + cidx / CPR, cc = cidx % CPR;
       t1reg[ps] = make_uint4(0, 0, 0, 0);
       t2reg[ps] = make_uint4(0, 0, 0, 0);
+      if constexpr (MODE == 1) oreg[ps] = make_uint4(0, 0, 0, 0);
       if (row < N) {
         t1reg[ps] = *reinterpret_cast<const uint4*>(t1p + (int64_t)row * rs + cc * 8);
         t2reg[ps] = *reinterpret_cast<const uint4*>(t2p + (int64_t)row * t2s + cc * 8);
+        if constexpr (MODE == 1) oreg[ps] = *reinterpret_cast<const uint4*>(op + (int64_t)row * ro + cc * 8);
       }
     }
-    if (MODE == 1 && tid < 128) {
-      const int row = t * FA_BKV + (tid & 63);
-      streg = 0.f;
-      if (row < N) streg = (tid < 64) ? lsep[row] * 1.4426950408889634f : delp[row];
+    if (MODE == 1 && tid < 64) {
+      const int row = t * FA_BKV + tid;
+      streg = (row < N) ? lsep[row] * 1.4426950408889634f : 0.f;
     }
   };
   auto lstore = [&](int stage) {
@@ -160,8 +159,22 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
       const int off = (cidx / CPR) * PITCH + (cidx % CPR) * 16;
       *reinterpret_cast<uint4*>(base + off) = t1reg[ps];
       *reinterpret_cast<uint4*>(base + TILE + off) = t2reg[ps];
+      if constexpr (MODE == 1) {   // delta of the streamed rows: dO . O, the row's CPR chunk holders are consecutive lanes
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(&t2reg[ps]);
+        const uint32_t* ow = reinterpret_cast<const uint32_t*>(&oreg[ps]);
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dot = __builtin_fmaf(__uint_as_float(dw[e] << 16), __uint_as_float(ow[e] << 16), dot);
+          dot = __builtin_fmaf(__uint_as_float(dw[e] & 0xffff0000u), __uint_as_float(ow[e] & 0xffff0000u), dot);
+        }
+        dot += dpp_mov<0xB1>(dot);                          // lanes l ^ 1
+        dot += dpp_mov<0x4E>(dot);                          // lanes l ^ 2
+        if (CPR == 8) dot += dpp_mov<0x141>(dot);           // the other quad of the row's 8 lanes
+        if ((cidx % CPR) == 0) reinterpret_cast<float*>(base + 2 * TILE)[64 + cidx / CPR] = dot;
+      }
     }
-    if (MODE == 1 && tid < 128) reinterpret_cast<float*>(base + 2 * TILE)[tid] = streg;
+    if (MODE == 1 && tid < 64) reinterpret_cast<float*>(base + 2 * TILE)[tid] = streg;
   };
 
   gload(0);
@@ -290,30 +303,38 @@ __global__ __launch_bounds__(256) void flash_attn_bwd_kernel(const bf16_t* __res
   }
 }
 
+// ONE launch for both passes: the first half of the grid runs the dK / dV pass (the longer one: two accumulators), the second half the dQ
+// pass.  The dK / dV pass recomputes delta for the rows it streams (an extra read of the O tile), so the passes do not depend on
+// each other: at N = 288 (MAE encoder, 8 images) a pass is 288 workgroups of five short tiles -- two back-to-back launches were two
+// latency-bound rounds on half of the chip's slots.
+template <int DH, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void flash_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int half = gridDim.x >> 1;
+  if ((int)blockIdx.x < half) fa_bwd_body<DH, 1, RAGGED>(smem, blockIdx.x, half, qkv, outp, dout, lse, dqkv, N, H, scale);
+  else fa_bwd_body<DH, 0, RAGGED>(smem, blockIdx.x - half, half, qkv, outp, dout, lse, dqkv, N, H, scale);
+}
+
 template <int DH>
 int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int N,
                     int H, float scale, hipStream_t s) {
   const int rblocks = (N + FA_BQ - 1) / FA_BQ;
-  dim3 grid(B * H * rblocks), block(256);
+  dim3 grid(2 * B * H * rblocks), block(256);
   const size_t lds = 2 * (2 * FA_BKV * fa_pitch(DH) + 512);
-  if (N % FA_BKV) {
-    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
-                       lse, delta, (bf16_t*)dqkv, N, H, scale);
-    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 1, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
-                       lse, delta, (bf16_t*)dqkv, N, H, scale);
-  } else {
-    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 0, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
-                       lse, delta, (bf16_t*)dqkv, N, H, scale);
-    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, 1, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
-                       lse, delta, (bf16_t*)dqkv, N, H, scale);
-  }
+  (void)delta;   // (the passes no longer exchange delta through memory; the argument stays in the ABI)
+  if (N % FA_BKV)
+    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
+  else
+    hipLaunchKernelGGL((flash_attn_bwd_kernel<DH, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
   COUNTR_LAUNCH_CHECK("countr_attn_bwd");
 }
 
 }  // namespace
 
 // Backward of countr_attn_fwd.  qkv, out, lse as given to / produced by the forward; dout bf16 [B, N, H*dh];
-// delta: fp32 workspace [B, H, N]; dqkv: bf16 [B, N, 3, H, dh] (fully overwritten).
+// delta: fp32 [B, H, N], unused since both passes compute it (kept in the ABI); dqkv: bf16 [B, N, 3, H, dh] (fully overwritten).
 extern "C" int countr_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                                int B, int N, int H, int dh, float scale, void* stream) {
   if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0) { countr_set_error("countr_attn_bwd: bad args"); return -1; }

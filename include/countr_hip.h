@@ -197,7 +197,7 @@ int countr_instnorm_relu_pool_bwd(const void* x, const void* dyp, const float* s
 int countr_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, float scale, void* stream);
 
 /* Backward of countr_attn_fwd (autograd of models_crossvit.py:84-91), two fused passes, no P materialised, no atomics.
- * out/lse: the forward's outputs; dout bf16 [B, N, H*dh]; delta: fp32 workspace [B, H, N]; dqkv bf16 [B, N, 3, H, dh]. */
+ * out/lse: the forward's outputs; dout bf16 [B, N, H*dh]; delta: fp32 [B, H, N] (must be non-NULL; not touched since both passes of the one launch compute it); dqkv bf16 [B, N, 3, H, dh]. */
 int countr_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                     int B, int N, int H, int dh, float scale, void* stream);
 
