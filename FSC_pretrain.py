@@ -105,22 +105,24 @@ def main(args):
         if loader is not None:
             loader.sampler.set_epoch(epoch)                                             # :236-237
         it_data = iter(loader) if loader is not None else None
-        for it in range(n_iter):
-            if it % args.accum_iter == 0:                                               # :258-259 (per accumulation window)
-                lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
-            if it_data is not None:
-                imgs = next(it_data)     # host tensor: load() stages it over PCIe on a copy stream while the previous step computes
-            else:
-                imgs = torch.rand(args.batch_size, 3, 384, 384, device=device, generator=g)
-            step.load(imgs)
-            loss = step.step(lr=lr)
-            if (it + 1) % args.log_every == 0 or it + 1 == n_iter:
-                lv = misc.all_reduce_mean(float(loss.item()))                           # the only host sync (:265, :310)
-                if not np.isfinite(lv):
-                    raise SystemExit("Loss is %s, stopping training" % lv)              # :292-294
-                losses.append(lv)
-                if misc.is_main_process():
-                    print(json.dumps({"epoch": epoch, "it": it + 1, "loss": lv, "lr": lr}))
+        with torch.cuda.stream(step.stream):      # one stream for the loop's device work and the step (no cross-queue hand-over per step)
+            for it in range(n_iter):
+                if it % args.accum_iter == 0:                                               # :258-259 (per accumulation window)
+                    lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
+                if it_data is not None:
+                    imgs = next(it_data)     # host tensor: load() stages it over PCIe on a copy stream while the previous step computes
+                else:
+                    imgs = torch.rand(args.batch_size, 3, 384, 384, device=device, generator=g)
+                step.load(imgs)
+                loss = step.step(lr=lr)
+                if (it + 1) % args.log_every == 0 or it + 1 == n_iter:
+                    lv = misc.all_reduce_mean(float(loss.item()))                           # the only host sync (:265, :310)
+                    if not np.isfinite(lv):
+                        raise SystemExit("Loss is %s, stopping training" % lv)              # :292-294
+                    losses.append(lv)
+                    if misc.is_main_process():
+                        print(json.dumps({"epoch": epoch, "it": it + 1, "loss": lv, "lr": lr}))
+        torch.cuda.current_stream(device).wait_stream(step.stream)
         opt_state = step.optimizer_state()
         if args.output_dir and (epoch % 100 == 0 or epoch + 1 == args.epochs):         # :327-329
             misc.save_model(args, epoch, model, opt_state, suffix="pretraining_%d" % epoch)

@@ -249,8 +249,9 @@ def time_pretrain(args, world, rank, dev, batch, steps, warmup):
     imgs = torch.rand(batch, 3, 384, 384, device=dev)
 
     def one():
-        step.load(imgs)          # draws a fresh masking permutation (torch.rand + argsort) every step, as the reference
-        return step.step()
+        with torch.cuda.stream(step.stream):     # the loop runs on the step's stream (see the finetune loop below)
+            step.load(imgs)          # draws a fresh masking permutation (torch.rand + argsort) every step, as the reference
+            return step.step()
     for _ in range(max(warmup, 2)):
         one()
     torch.cuda.synchronize()
@@ -456,9 +457,12 @@ def main():
 
     def one(k, S):
         imgs, boxes, gt, _ = batches[k % NB]
-        mask = torch.empty(384, 384, device=dev).bernoulli_(0.8, generator=mgen)
-        step.load(imgs, boxes, gt, mask, S)
-        return step.step(S)
+        # the loop's own device work (the per-iteration mask draw) runs on the step's stream, as everything does on ONE stream in the
+        # reference's loop: from another stream every step pays two cross-queue hand-overs (inputs ready -> step, step done -> caller)
+        with torch.cuda.stream(step.stream):
+            mask = torch.empty(384, 384, device=dev).bernoulli_(0.8, generator=mgen)
+            step.load(imgs, boxes, gt, mask, S)
+            return step.step(S)
 
     def timed(shots):
         torch.cuda.synchronize()
