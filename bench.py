@@ -151,6 +151,8 @@ def family_breakdown(model, step, batch, passes=5):
     def fam(fn, args):
         if fn is L.countr_gemm:
             return "conv" if (args[2] == 2 or args[3] == 3) else "linear"      # OP_IM2ROW A operand / OP_IM2COL B operand
+        if fn is L.countr_gemm_group:                                          # a block's nn.Linear weight gradients in one launch
+            return "linear"
         if any(fn is f for f in conv_fns):
             return "conv"
         if any(fn is f for f in attn_fns):
@@ -199,7 +201,14 @@ def family_breakdown(model, step, batch, passes=5):
     # operand per column tile, fp32 partials are NOT algorithmic: they show up as traffic above this figure)
     alg = {"linear": 0, "conv": 0}
     nl = {"linear": 0, "conv": 0}
+    flat = []
     for fn, args, keep in seq:
+        if fn is L.countr_gemm_group and keep is not None:     # (items, n, dtype, modeA, modeB): n launches of one kind
+            flat += [(L.countr_gemm, (None, args[2], args[3], args[4]), keep[i]) for i in range(args[1])]
+            nl["linear"] -= args[1] - 1                        # ... counted as ONE launch
+        else:
+            flat.append((fn, args, keep))
+    for fn, args, keep in flat:
         if fn is not L.countr_gemm or keep is None:
             continue
         f = fam(fn, args)

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
@@ -66,6 +66,8 @@ def _declare(L):
     L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
     L.countr_gemm_rowsum_slabs.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
     L.countr_gemm_tiles.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
+    L.countr_gemm_group.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, i32, vp]
+    L.countr_gemm_group_tiles.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, i32]
     L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.countr_reduce_table.argtypes = [vp, i32, i32, vp]
     for name, sig in _SIGS.items():

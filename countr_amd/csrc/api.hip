@@ -25,7 +25,7 @@ int countr_check_launch(const char* what) {
 }
 
 extern "C" const char* countr_last_error(void) { return g_err; }
-extern "C" int countr_version(void) { return 3; }   // 2: countr_gemm_args grew (ln_* fields, rowsum_slabs); 3: prefetch hint
+extern "C" int countr_version(void) { return 4; }   // 2: countr_gemm_args grew (ln_* fields, rowsum_slabs); 3: prefetch hint; 4: countr_gemm_group
 
 extern "C" int countr_init(int device) {
   int n = 0;

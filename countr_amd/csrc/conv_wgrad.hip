@@ -69,8 +69,15 @@ template <int PENDING> __device__ __forceinline__ void frag_wait(Frag (&f)[4]) {
 
 // LIN: the same kernel as the weight gradient of an nn.Linear, dW[n][k] = sum_r dy[r][n] x[r][k] (the (COL, COL) split-K launches): the
 // contraction index is the token row, again the slow dimension of both operands -- no taps, no padding, nothing else differs.
+// joint (z, tile) order of a launch, one contiguous range per XCD (workgroup b runs on XCD b % 8)
+__device__ __forceinline__ int cwg_virtual_index() {
+  const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xc = blockIdx.x & 7, j = blockIdx.x >> 3;
+  return (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + j;
+}
+
+// v: this workgroup's index among the g.tiles * g.Z (tile, slab) pairs of the problem g
 template <int WNB, bool LIN>
-__global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel(const CwgArgs g) {
+__device__ __forceinline__ void cwg_body(const CwgArgs& g, const int v) {
   constexpr int STAGES = 3, NCW = 4 * WNB, NLW = 4, SUBN = 2 * WNB;
   constexpr int A_BYTES = 64 * 256, STAGE_BYTES = A_BYTES * (1 + WNB);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,13 +86,7 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wv >= NCW;
   const int cw = loader ? wv - NCW : wv;
-  // joint (z, tile) order, one contiguous range per XCD (workgroup b runs on XCD b % 8)
-  int z, lt;
-  {
-    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xc = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int v = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + j;
-    z = v / g.tiles; lt = v - z * g.tiles;
-  }
+  const int z = v / g.tiles, lt = v - z * g.tiles;
   const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
   const int m0 = tile_m * 128, n0 = tile_n * (128 * WNB);
   const int tap = LIN ? 4 : n0 / g.Cin, ci0 = LIN ? n0 : n0 - tap * g.Cin;
@@ -264,6 +265,40 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
 }
 
 template <int WNB, bool LIN>
+__global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel(const CwgArgs g) {
+  cwg_body<WNB, LIN>(g, cwg_virtual_index());
+}
+
+// Several nn.Linear weight gradients in ONE launch (countr_gemm_group): the workgroups of problem i are [start[i], start[i + 1]) of the
+// XCD-ordered index.  Why: the four weight gradients of a transformer block are 16-72 tiles each -- alone each needs 3-16 split-K slabs
+// to fill the chip (fp32 partials written and summed again); together they fill it with one or two.
+struct CwgGroup {
+  CwgArgs it[4];
+  int start[5];
+};
+template <int WNB>
+__global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_group_kernel(const CwgGroup grp) {
+  const int v = cwg_virtual_index();
+  int p = 0;
+  if (v >= grp.start[1]) p = 1;
+  if (v >= grp.start[2]) p = 2;
+  if (v >= grp.start[3]) p = 3;
+  cwg_body<WNB, true>(grp.it[p], v - grp.start[p]);
+}
+
+template <int WNB>
+int launch_cwg_group(const CwgGroup& g, hipStream_t s) {
+  constexpr int lds = 3 * 64 * 256 * (1 + WNB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg_group_kernel<WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((cwg_group_kernel<WNB>), dim3(g.start[4]), dim3(256 * WNB + 256), lds, s, g);
+  COUNTR_LAUNCH_CHECK("countr_gemm_group(lean linear wgrad)");
+}
+
+template <int WNB, bool LIN>
 int launch_cwg(const CwgArgs& a, hipStream_t s) {
   constexpr int lds = 3 * 64 * 256 * (1 + WNB);
   static bool attr_set = false;
@@ -326,17 +361,57 @@ int countr_lean_wgrad_tiles(const countr_gemm_args* a, int lin) {
   return (a->M / 128) * (a->N / (128 * form));
 }
 
-// Returns 1 when the launch does not qualify (gemm_kernel then runs it), otherwise the launch status.
-int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s) {
-  const int form = cwg_form(a, lin != 0);
-  if (!form) return 1;
-  CwgArgs g;
+static void cwg_fill(CwgArgs& g, const countr_gemm_args* a, bool lin, int form) {
   g.dy = (const char*)a->A; g.x = (const char*)a->B; g.part = a->partial; g.rowsum = a->rowsum_partial;
   g.Cout = a->M; g.Cin = lin ? 0 : a->Cin; g.H = lin ? 0 : a->H; g.Wd = lin ? 0 : a->W; g.N = a->N;
   g.lda = lin ? (int)a->lda : a->M; g.ldb = lin ? (int)a->ldb : a->Cin;
   g.tilesN = a->N / (128 * form); g.tiles = (a->M / 128) * g.tilesN;
   g.nkt = a->K / 64; g.Z = a->splitk > 1 ? a->splitk : 1;
   g.per = (g.nkt + g.Z - 1) / g.Z;
+}
+
+// Tile width (in 128-column units) a group of n (COL, COL) split-K launches runs at in ONE launch, or 0 when it does not qualify (the
+// caller then launches them one by one): 2 to 4 nn.Linear weight gradients, each qualifying on its own; 256-column tiles when every
+// problem has the columns for them.  (The accumulation order of an output element does not depend on the tile width.)
+int countr_lean_wgrad_group_form(const countr_gemm_args* items, int n) {
+  if (n < 2 || n > 4) return 0;
+  int form = 2;
+  for (int i = 0; i < n; ++i) {
+    countr_gemm_args b = items[i];
+    if (!b.partial) b.partial = reinterpret_cast<float*>(16);   // (sizing calls come before the workspaces exist)
+    if (b.rowsum_partial) b.rowsum_slabs = (b.splitk > 1 ? b.splitk : 1) * (b.N / 128);
+    if (!cwg_form(&b, true)) return 0;
+    if (b.N % 256) form = 1;
+  }
+  { const char* e = getenv("COUNTR_LEAN_WGRAD_FORM"); if (e && atoi(e) == 1) form = 1; }
+  return form;
+}
+
+// Returns 1 when the group does not qualify, otherwise the launch status.
+int countr_lean_wgrad_group(const countr_gemm_args* items, int n, hipStream_t s) {
+  const int form = countr_lean_wgrad_group_form(items, n);
+  if (!form) return 1;
+  CwgGroup grp;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) {
+    const countr_gemm_args* a = &items[i < n ? i : n - 1];
+    cwg_fill(grp.it[i], a, true, form);
+    grp.start[i] = i < n ? total : 0x7fffffff;      // (workgroup v runs the LAST problem whose start is <= v: entries past the group never match)
+    if (i < n) {
+      if (a->rowsum_partial && a->rowsum_slabs != grp.it[i].Z * (a->N / 128)) return 1;   // caller sized another layout
+      total += grp.it[i].tiles * grp.it[i].Z;
+    }
+  }
+  grp.start[4] = total;     // the grid
+  return form == 2 ? launch_cwg_group<2>(grp, s) : launch_cwg_group<1>(grp, s);
+}
+
+// Returns 1 when the launch does not qualify (gemm_kernel then runs it), otherwise the launch status.
+int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s) {
+  const int form = cwg_form(a, lin != 0);
+  if (!form) return 1;
+  CwgArgs g;
+  cwg_fill(g, a, lin != 0, form);
   if (lin) return form == 2 ? launch_cwg<2, true>(g, s) : launch_cwg<1, true>(g, s);
   return form == 2 ? launch_cwg<2, false>(g, s) : launch_cwg<1, false>(g, s);
 }

@@ -166,6 +166,43 @@ extern "C" int countr_gemm_tiles(const countr_gemm_args* a, int dtype, int modeA
   return ((a->M + 127) / 128) * ((a->N + 127) / 128);
 }
 
+int countr_lean_wgrad_group_form(const countr_gemm_args* items, int n);         // conv_wgrad.hip: 0 = the group does not qualify
+int countr_lean_wgrad_group(const countr_gemm_args* items, int n, hipStream_t s);
+
+// Tiles per split-K slab of the ONE launch countr_gemm_group would run for these n launches (what a caller divides the CU count by to pick
+// a common splitk), or 0 when the group runs as n separate launches (then countr_gemm_tiles per launch applies).
+extern "C" int countr_gemm_group_tiles(const countr_gemm_args* items, int n, int dtype, int modeA, int modeB) {
+  if (!items || dtype != COUNTR_BF16 || modeA != COUNTR_OP_COL || modeB != COUNTR_OP_COL) return 0;
+  const int form = countr_lean_wgrad_group_form(items, n);
+  if (!form) return 0;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (items[i].M / 128) * (items[i].N / (128 * form));
+  return tiles;
+}
+
+// n independent launches of one kind, as countr_gemm would run them one after the other -- in ONE kernel launch where a grouped form
+// exists (bf16 (COL, COL) split-K launches: the weight gradients of a transformer block's nn.Linear layers, conv_wgrad.hip), otherwise
+// one by one.  Results equal those of the separate launches bit for bit (same splitk per launch: same accumulation order).
+extern "C" int countr_gemm_group(const countr_gemm_args* items, int n, int dtype, int modeA, int modeB, void* stream) {
+  if (!items || n < 1 || n > 4) { countr_set_error("countr_gemm_group: 1 to 4 launches"); return -1; }
+  if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_COL && n > 1) {
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+      const countr_gemm_args* a = &items[i];
+      ok = a->A && a->B && a->partial && a->M > 0 && a->N > 0 && a->K > 0 && (a->M % 8) == 0 && (a->N % 8) == 0 && (!a->rowsum_partial || a->partial);
+    }
+    if (ok) {
+      const int rc = countr_lean_wgrad_group(items, n, reinterpret_cast<hipStream_t>(stream));
+      if (rc != 1) return rc;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = countr_gemm(&items[i], dtype, modeA, modeB, stream);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 extern "C" int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, int modeA, int modeB) {
   if (!a) return 0;
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && (modeB == COUNTR_OP_IM2COL || modeB == COUNTR_OP_COL))

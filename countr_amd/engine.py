@@ -241,6 +241,7 @@ class Engine:
         # Round 1 measured this as a loss (6.45 vs 6.20 ms, four graph launches per step); with the whole step in ONE graph it
         # gains 50-70 us per step at B = 8 (5.63 -> 5.57 ms, three A/B pairs on one box).
         self.overlap_exemplar = True
+        self.group_wgrads = os.environ.get("COUNTR_GROUP_WGRADS", "1") != "0"   # a block's Linear weight gradients in one launch (A/B switch)
         self.act_splitk = True       # split-K + finisher for few-tile, long-K forward GEMMs
 
     def _make_layout(self, named_shapes):
@@ -582,6 +583,48 @@ class Engine:
         if bias_name is not None and not fuse_bias:
             self._bias_grad(ops, dy, bias_name, M, N)
 
+    def _linear_wgrad_group(self, ops, items):
+        """The weight (+ bias) gradients of several nn.Linear layers -- items: (dy, x, wname, M, N, K, bias_name), all final by now -- in
+        ONE launch (countr_gemm_group) with a COMMON split-K factor chosen for the group's tile count: the four weight gradients of a
+        transformer block are 16-72 tiles each and needed 3-16 slabs apiece to fill the chip; together one or two.  With one slab and
+        no accumulation window the kernel writes the gradient itself (no slab sum).  fp32 mode, or a group the library would run as
+        separate launches anyway: the per-layer path."""
+        n = len(items)
+        arr = (GemmArgs * n)() if 2 <= n <= 4 and self.code == BF16 and self.group_wgrads else None
+        tiles = 0
+        if arr is not None:
+            for q, (dy, x, wname, M, N, K, _b) in zip(arr, items):
+                q.A, q.B, q.lda, q.ldb, q.ldc, q.M, q.N, q.K = dy.data_ptr(), x.data_ptr(), N, K, K, N, K, M
+                q.alpha, q.nbatch, q.nb1, q.splitk = 1.0, 1, 1, 1
+            tiles = int(self.L.countr_gemm_group_tiles(arr, n, self.code, OP_COL, OP_COL))
+        if tiles <= 0:
+            for (dy, x, wname, M, N, K, bias_name) in items:
+                self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=bias_name)
+            return
+        sk = self._splitk(tiles, -(-max(it[3] for it in items) // 64))
+        direct = sk == 1 and not self._acc
+        later = []
+        # (workspaces per position in the group: _role() maps mlp.fc1 and mlp.fc2 to ONE name, fine for launches that follow each other)
+        for i, (q, (dy, x, wname, M, N, K, bias_name)) in enumerate(zip(arr, items)):     # every claim before the launch, every deferred sum behind it
+            q.splitk = sk
+            if direct:
+                q.partial = self._gp(wname)
+            else:
+                part = self._shared("skg%d." % i + self._role(wname), sk * N * K)
+                self._claim(part.data_ptr())
+                q.partial = part.data_ptr()
+                later.append((part.data_ptr(), part.data_ptr(), self._gp(wname), sk, N * K, N * K))
+            if bias_name is not None:
+                rs = self._shared("rsg%d." % i + self._role(wname), 64 * 4096)
+                rslabs = int(self.L.countr_gemm_rowsum_slabs(C.byref(q), self.code, OP_COL, OP_COL))
+                assert rslabs * N <= 64 * 4096, (wname, rslabs, N)
+                self._claim(rs.data_ptr())
+                q.rowsum_partial, q.rowsum_slabs = rs.data_ptr(), rslabs
+                later.append((rs.data_ptr(), rs.data_ptr(), self._gp(bias_name), rslabs, N, N))
+        ops.append((self.L.countr_gemm_group, (arr, n, self.code, OP_COL, OP_COL), arr))
+        for e in later:
+            self._reduce_later(ops, *e)
+
     def _bias_grad(self, ops, dy, bname, M, N):
         ws = self._shared("colsum", 256 * 4096)
         self._op(ops, self.L.countr_colsum, dy.data_ptr(), self._gp(bname), ws.data_ptr(), M, N, self.code, self._acc)
@@ -606,11 +649,15 @@ class Engine:
         if gelu_pre is not None:
             self._op(ops, self.L.countr_gelu_bwd, dx.data_ptr(), gelu_pre.data_ptr(), dx.data_ptr(), M * K, self.code)
 
-    def _linear_bwd(self, ops, dy, x, wname, M, N, K, dx=None, resid=None, dx_bf16=None, gelu_pre=None):
-        """bias grad | weight grad | input grad of one nn.Linear: three independent branches."""
+    def _linear_bwd(self, ops, dy, x, wname, M, N, K, dx=None, resid=None, dx_bf16=None, gelu_pre=None, group=None):
+        """bias grad | weight grad | input grad of one nn.Linear: three independent branches.  group (a list): the weight / bias
+        gradient is not launched here but handed to the caller's _linear_wgrad_group (dy and x must stay untouched until then)."""
         self._fork(ops)
         self._lane(ops, 2)
-        self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=wname[:-6] + "bias")
+        if group is not None:
+            group.append((dy, x, wname, M, N, K, wname[:-6] + "bias"))
+        else:
+            self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=wname[:-6] + "bias")
         if dx is not None:
             self._lane(ops, 0)
             self._linear_dgrad(ops, dy, wname, dx, M, N, K, resid=resid, out_bf16=dx_bf16, gelu_pre=gelu_pre)
@@ -1019,6 +1066,16 @@ class Engine:
                     self._join(ops)
             gx = A("gx", (rows, Dd), f32)
             gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
+            # grouped weight gradients (bf16): a block's Linear weight gradients run as two launches, each just before the LayerNorm
+            # backward that would overwrite one of their operands -- so the operand view of the residual gradient alternates between
+            # two buffers (the version a deferred launch still reads stays intact while the next one is written)
+            grouped = code == BF16 and self.group_wgrads
+            gxT_alt = [gxT, A("gxT2", (rows, Dd), T)] if grouped else [gxT, gxT]
+            gsel = [0]
+
+            def next_gxT():
+                gsel[0] ^= 1
+                return gxT_alt[gsel[0]]
             g_t = self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False, dx_t=gxT)
 
             ops = lists.bwd_rest
@@ -1040,33 +1097,39 @@ class Engine:
                 b = "decoder_blocks.%d" % i
                 d = blk[i]
                 # ---- mlp: x3 = x2 + fc2(gelu(fc1(LN2(x2))))  (g_t = bf16/fp32 operand view of gx, emitted by the LN backward)
-                self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh, gelu_pre=d["hpre"])
-                self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t)
-                g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=gxT)
+                grp = [] if grouped else None
+                self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dd, 4 * Dd, dx=dh, gelu_pre=d["hpre"], group=grp)
+                self._linear_bwd(ops, dh, d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dd, Dd, dx=dn_t, group=grp)
+                g_t = self._layernorm_bwd(ops, dn_t, d["x2"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dd, accumulate=True, dx_t=next_gxT())
                 # ---- cross attention: x2 = x1 + proj(xattn(wq(LN1(x1)), wk(y), wv(y)))
-                self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in)
+                self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in, group=grp)
                 dk, dv, dkT, dvT = dk_b[i], dv_b[i], dkT_b[i], dvT_b[i]
                 self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
                          dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code,
                          dkT.data_ptr() if dkT is not None else None, dvT.data_ptr() if dvT is not None else None)
                 if i == 0:
                     ops.append((None, ("tokready",), None))   # every block's dK / dV is final: the exemplar-token backward may start (run_backward_rest_and_tok)
-                self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t)
-                g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=gxT)
+                self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t, group=grp)
+                if grouped:      # fc2, fc1, attn.proj, attn.wq: the next LayerNorm backward overwrites fc2's dy
+                    self._linear_wgrad_group(ops, grp)
+                    grp = []
+                g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=next_gxT())
                 dk_t, dv_t = (dk, dv) if dkT is None else (dkT, dvT)    # bf16 copies come out of the cross-attention backward
                 for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
                     self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
                     tok_dgrads.append((g_kv, b + ".attn.%s.weight" % nm))
                 # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
-                self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in)
+                self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in, group=grp)
                 if d["lse"] is not None:
                     dlt = self._shared("attn_delta", B * Hd * N)
                     self._op(ops, L.countr_attn_bwd, d["qkv"].data_ptr(), d["att"].data_ptr(), dproj_in.data_ptr(), d["lse"].data_ptr(),
                              dlt.data_ptr(), dqkv.data_ptr(), B, N, Hd, Dd // Hd, (Dd // Hd) ** -0.5)
                 else:
                     self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
-                self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t)
-                g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=gxT)
+                self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t, group=grp)
+                if grouped:      # selfattn.proj, selfattn.qkv
+                    self._linear_wgrad_group(ops, grp)
+                g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=next_gxT())
             # ---- decoder_embed (no dgrad: the encoder is frozen)
             self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
             # ---- exemplar tokens: dy_tok = sum over blocks of dK Wk + dV Wv

@@ -97,23 +97,31 @@ class MaeEngine(Engine):
         L, code = self.L, self.code
         rows = B * N
         gx = s["gx"]
-        self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dm, 4 * Dm, dx=s["dh"], gelu_pre=d["hpre"])
-        self._linear_bwd(ops, s["dh"], d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dm, Dm, dx=s["dn_t"])
-        g_t = self._layernorm_bwd(ops, s["dn_t"], d["x1"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dm, accumulate=True, dx_t=s["gxT"])
-        self._linear_bwd(ops, g_t, d["att"], b + ".attn.proj.weight", rows, Dm, Dm, dx=s["dproj_in"])
+        # bf16: the four weight gradients of the block run as ONE launch (Engine._linear_wgrad_group) just before the last LayerNorm
+        # backward; until then the operand view of the residual gradient they read (g_t on entry, in gxT) must survive the first
+        # LayerNorm backward, which therefore writes its view into gxT2
+        grp = [] if s.get("gxT2") is not None else None
+        self._linear_bwd(ops, g_t, d["hact"], b + ".mlp.fc2.weight", rows, Dm, 4 * Dm, dx=s["dh"], gelu_pre=d["hpre"], group=grp)
+        self._linear_bwd(ops, s["dh"], d["n2"], b + ".mlp.fc1.weight", rows, 4 * Dm, Dm, dx=s["dn_t"], group=grp)
+        g_t = self._layernorm_bwd(ops, s["dn_t"], d["x1"], b + ".norm2", d["m2"], d["r2"], gx, rows, Dm, accumulate=True,
+                                  dx_t=s["gxT2"] if grp is not None else s["gxT"])
+        self._linear_bwd(ops, g_t, d["att"], b + ".attn.proj.weight", rows, Dm, Dm, dx=s["dproj_in"], group=grp)
         if d["lse"] is not None:
             dlt = self._shared("attn_delta", B * heads * N)
             self._op(ops, L.countr_attn_bwd, d["qkv"].data_ptr(), d["att"].data_ptr(), s["dproj_in"].data_ptr(), d["lse"].data_ptr(),
                      dlt.data_ptr(), s["dqkv"].data_ptr(), B, N, heads, Dm // heads, (Dm // heads) ** -0.5)
         else:
             self._attention_bwd(ops, d["qkv"], d["probs"], s["dproj_in"], s["dqkv"], B, heads, Dm, N=N)
-        self._linear_bwd(ops, s["dqkv"], d["n1"], b + ".attn.qkv.weight", rows, 3 * Dm, Dm, dx=s["dn_t"])
+        self._linear_bwd(ops, s["dqkv"], d["n1"], b + ".attn.qkv.weight", rows, 3 * Dm, Dm, dx=s["dn_t"], group=grp)
+        if grp is not None:
+            self._linear_wgrad_group(ops, grp)
         return self._layernorm_bwd(ops, s["dn_t"], d["xin"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dm, accumulate=True, dx_t=s["gxT"])
 
     def _bwd_scratch(self, p, tag, rows, Dm):
         T, f32 = self.tdt, torch.float32
         A = lambda k, shape, dt: self._alloc(p, tag + k, shape, dt)
         return {"gx": A(".gx", (rows, Dm), f32), "gxT": A(".gxT", (rows, Dm), T) if self.code == BF16 else None,
+                "gxT2": A(".gxT2", (rows, Dm), T) if (self.code == BF16 and self.group_wgrads) else None,
                 "dh": A(".dh", (rows, 4 * Dm), T), "dn_t": A(".dn_t", (rows, Dm), T), "dproj_in": A(".dproj_in", (rows, Dm), T),
                 "dqkv": A(".dqkv", (rows, 3 * Dm), T)}
 

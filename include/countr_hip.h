@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 3 (countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint -- so a caller built against an older version must be rebuilt) */
+int countr_version(void);               /* ABI version, currently 4 (countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -114,6 +114,16 @@ int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, int modeA, in
  * unset): a split-K caller picks splitk ~ CUs / tiles.  128 x 128 tiles everywhere except the lean convolution weight gradient on
  * maps with Cin % 256 == 0 (128 x 256). */
 int countr_gemm_tiles(const countr_gemm_args* a, int dtype, int modeA, int modeB);
+
+/* n (1..4) independent launches of one (dtype, modeA, modeB) kind, with the results of n countr_gemm calls bit for bit, in ONE kernel
+ * launch where a grouped form exists: bf16 (COL, COL) split-K launches, i.e. the weight gradients dW = dy^T x of a transformer block's
+ * nn.Linear layers (autograd of Mlp / Attention / CrossAttention, models_crossvit.py:46-128; timm Block, models_mae_cross.py:32-34).
+ * Why: those are 16-72 output tiles each -- alone each needs 3-16 split-K slabs to fill 256 CUs (fp32 partials written, then summed
+ * again); together they fill the chip with one or two.  Otherwise the launches run one after the other.
+ * countr_gemm_group_tiles: output tiles per split-K slab of that ONE launch (the caller picks a common splitk ~ CUs / tiles), or 0 when
+ * the launches would run separately (then countr_gemm_tiles applies per launch). */
+int countr_gemm_group(const countr_gemm_args* items, int n, int dtype, int modeA, int modeB, void* stream);
+int countr_gemm_group_tiles(const countr_gemm_args* items, int n, int dtype, int modeA, int modeB);
 
 /* out[M,N] (+)= sum_z partial[z][M][N]; optional permute for conv weights:
  * perm_taps > 0: partial is [Cout][taps][Cin] (OHWI) and out is torch OIHW [Cout][Cin][taps].

@@ -663,6 +663,58 @@ def test_lean_linear_wgrad_matches_fp64_and_generic(hip, monkeypatch, R, N, K, l
     assert (res[0] - res[1]).abs().max().item() <= 4e-5 * ref_w.abs().max().item() + 1e-9
 
 
+@pytest.mark.parametrize("R,shapes,sk", [
+    (2304, [(768, 3072), (3072, 768), (768, 768), (2304, 768)], 1),        # MAE encoder block at 8 images: fc2, fc1, proj, qkv = 216 tiles of 128x256
+    (4608, [(512, 2048), (2048, 512), (512, 512), (512, 512)], 2),         # finetune decoder block: fc2, fc1, proj, wq = 96 tiles x 2 slabs
+    (1152, [(512, 2048), (1536, 512)], 3),                                 # two launches, three slabs
+    (2304, [(768, 3072), (384, 384), (768, 768)], 1),                      # a 384-column problem: the whole group on 128x128 tiles
+])
+def test_grouped_linear_wgrads_equal_the_separate_launches(hip, R, shapes, sk):
+    """countr_gemm_group: the weight (+ bias) gradients of a block's nn.Linear layers in ONE launch == the same launches through
+    countr_gemm one by one, bit for bit (partials and row-sum partials), and == fp64.  Reference: autograd of Mlp / Attention /
+    CrossAttention (models_crossvit.py:46-128)."""
+    n = len(shapes)
+    dys = [_mk((R, N), torch.bfloat16, 91 + i) for i, (N, K) in enumerate(shapes)]
+    xs = [_mk((R, K), torch.bfloat16, 95 + i) for i, (N, K) in enumerate(shapes)]
+
+    def make():
+        arr = (_lib.GemmArgs * n)()
+        keep = []
+        for i, (N, K) in enumerate(shapes):
+            a = arr[i]
+            a.A, a.B = dys[i].data_ptr(), xs[i].data_ptr()
+            a.lda, a.ldb, a.ldc = N, K, K
+            a.M, a.N, a.K = N, K, R
+            a.alpha = 1.0
+            a.nbatch = 1; a.nb1 = 1; a.splitk = sk
+            slabs = hip.countr_gemm_rowsum_slabs(C.byref(a), 1, 1, 1)
+            part = torch.full((sk, N, K), float("nan"), device="cuda", dtype=torch.float32)
+            rs = torch.full((slabs, N), float("nan"), device="cuda", dtype=torch.float32)
+            a.partial, a.rowsum_partial, a.rowsum_slabs = part.data_ptr(), rs.data_ptr(), slabs
+            keep.append((part, rs))
+        return arr, keep
+    arr, grouped = make()
+    tiles = hip.countr_gemm_group_tiles(arr, n, 1, 1, 1)
+    wide = all(K % 256 == 0 for _, K in shapes)
+    assert tiles == sum((N // 128) * (K // (256 if wide else 128)) for N, K in shapes)
+    _lib.check(hip.countr_gemm_group(arr, n, 1, 1, 1, _stream()), "group")
+    arr2, separate = make()
+    for i in range(n):
+        _lib.check(hip.countr_gemm(C.byref(arr2[i]), 1, 1, 1, _stream()), "wgrad")
+    torch.cuda.synchronize()
+    for i, (N, K) in enumerate(shapes):
+        ref_w = dys[i].double().t() @ xs[i].double()
+        ref_b = dys[i].double().sum(0)
+        assert torch.isfinite(grouped[i][0]).all() and torch.isfinite(grouped[i][1]).all()
+        assert (grouped[i][0].double().sum(0) - ref_w).abs().max().item() <= 2e-5 * ref_w.abs().max().item() + 1e-9, i
+        assert (grouped[i][1].double().sum(0) - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item() + 1e-9, i
+        assert torch.equal(grouped[i][0], separate[i][0]), i
+        assert torch.equal(grouped[i][1], separate[i][1]), i
+    # what does not qualify runs one by one: fp32 launches, a single launch
+    assert hip.countr_gemm_group_tiles(arr, n, 0, 1, 1) == 0 and hip.countr_gemm_group_tiles(arr, 1, 1, 1, 1) == 0
+    assert hip.countr_gemm_group(arr, 5, 1, 1, 1, _stream()) != 0
+
+
 @pytest.mark.parametrize("M,N2", [(4608, 1536), (576, 1536), (14976, 1536), (4608, 2304), (4400, 2304)])   # N2 = 2304 at B = 8: the 192x256 form
 @pytest.mark.parametrize("act", [0, 1])
 def test_lean_linear_layernorm_folding(hip, M, N2, act):

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), "include/countr_hip.h declares %s but libcountr_hip.so does not export it" % s
-    assert L.countr_version() == _lib.ABI_VERSION == 3
+    assert L.countr_version() == _lib.ABI_VERSION == 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU error path")

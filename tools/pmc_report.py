@@ -14,6 +14,8 @@ def family(name):
     m = re.match(r".*g256_kernel<(true|false)", name)
     if m:
         return "conv" if m.group(1) == "true" else "linear"
+    if "cwg_group_kernel" in name:      # a block's nn.Linear weight gradients in one launch
+        return "linear"
     m = re.match(r".*cwg_kernel<\d+, (true|false)", name)
     if m:
         return "linear" if m.group(1) == "true" else "conv"
