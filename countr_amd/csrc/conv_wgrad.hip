@@ -272,17 +272,18 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
 // Several nn.Linear weight gradients in ONE launch (countr_gemm_group): the workgroups of problem i are [start[i], start[i + 1]) of the
 // XCD-ordered index.  Why: the four weight gradients of a transformer block are 16-72 tiles each -- alone each needs 3-16 split-K slabs
 // to fill the chip (fp32 partials written and summed again); together they fill it with one or two.
+constexpr int CWG_GROUP_MAX = 8;
 struct CwgGroup {
-  CwgArgs it[4];
-  int start[5];
+  CwgArgs it[CWG_GROUP_MAX];
+  int start[CWG_GROUP_MAX + 1];
 };
 template <int WNB>
 __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_group_kernel(const CwgGroup grp) {
   const int v = cwg_virtual_index();
   int p = 0;
-  if (v >= grp.start[1]) p = 1;
-  if (v >= grp.start[2]) p = 2;
-  if (v >= grp.start[3]) p = 3;
+#pragma unroll
+  for (int i = 1; i < CWG_GROUP_MAX; ++i)
+    if (v >= grp.start[i]) p = i;
   cwg_body<WNB, true>(grp.it[p], v - grp.start[p]);
 }
 
@@ -294,7 +295,7 @@ int launch_cwg_group(const CwgGroup& g, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg_group_kernel<WNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((cwg_group_kernel<WNB>), dim3(g.start[4]), dim3(256 * WNB + 256), lds, s, g);
+  hipLaunchKernelGGL((cwg_group_kernel<WNB>), dim3(g.start[CWG_GROUP_MAX]), dim3(256 * WNB + 256), lds, s, g);
   COUNTR_LAUNCH_CHECK("countr_gemm_group(lean linear wgrad)");
 }
 
@@ -371,10 +372,10 @@ static void cwg_fill(CwgArgs& g, const countr_gemm_args* a, bool lin, int form) 
 }
 
 // Tile width (in 128-column units) a group of n (COL, COL) split-K launches runs at in ONE launch, or 0 when it does not qualify (the
-// caller then launches them one by one): 2 to 4 nn.Linear weight gradients, each qualifying on its own; 256-column tiles when every
+// caller then launches them one by one): 2 to 8 nn.Linear weight gradients, each qualifying on its own; 256-column tiles when every
 // problem has the columns for them.  (The accumulation order of an output element does not depend on the tile width.)
 int countr_lean_wgrad_group_form(const countr_gemm_args* items, int n) {
-  if (n < 2 || n > 4) return 0;
+  if (n < 2 || n > CWG_GROUP_MAX) return 0;
   int form = 2;
   for (int i = 0; i < n; ++i) {
     countr_gemm_args b = items[i];
@@ -393,7 +394,7 @@ int countr_lean_wgrad_group(const countr_gemm_args* items, int n, hipStream_t s)
   if (!form) return 1;
   CwgGroup grp;
   int total = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < CWG_GROUP_MAX; ++i) {
     const countr_gemm_args* a = &items[i < n ? i : n - 1];
     cwg_fill(grp.it[i], a, true, form);
     grp.start[i] = i < n ? total : 0x7fffffff;      // (workgroup v runs the LAST problem whose start is <= v: entries past the group never match)
@@ -402,7 +403,7 @@ int countr_lean_wgrad_group(const countr_gemm_args* items, int n, hipStream_t s)
       total += grp.it[i].tiles * grp.it[i].Z;
     }
   }
-  grp.start[4] = total;     // the grid
+  grp.start[CWG_GROUP_MAX] = total;     // the grid
   return form == 2 ? launch_cwg_group<2>(grp, s) : launch_cwg_group<1>(grp, s);
 }
 

@@ -590,7 +590,7 @@ class Engine:
         no accumulation window the kernel writes the gradient itself (no slab sum).  fp32 mode, or a group the library would run as
         separate launches anyway: the per-layer path."""
         n = len(items)
-        arr = (GemmArgs * n)() if 2 <= n <= 4 and self.code == BF16 and self.group_wgrads else None
+        arr = (GemmArgs * n)() if 2 <= n <= 8 and self.code == BF16 and self.group_wgrads else None
         tiles = 0
         if arr is not None:
             for q, (dy, x, wname, M, N, K, _b) in zip(arr, items):
@@ -1066,15 +1066,15 @@ class Engine:
                     self._join(ops)
             gx = A("gx", (rows, Dd), f32)
             gxT = A("gxT", (rows, Dd), T) if code == BF16 else None
-            # grouped weight gradients (bf16): a block's Linear weight gradients run as two launches, each just before the LayerNorm
-            # backward that would overwrite one of their operands -- so the operand view of the residual gradient alternates between
-            # two buffers (the version a deferred launch still reads stays intact while the next one is written)
+            # grouped weight gradients (bf16): the six Linear weight gradients of a block (and decoder_embed's with the last block's) run
+            # as ONE launch behind the block's last LayerNorm backward -- so the operand view of the residual gradient cycles through
+            # four buffers (the three versions the deferred launch still reads stay intact while the next one is written)
             grouped = code == BF16 and self.group_wgrads
-            gxT_alt = [gxT, A("gxT2", (rows, Dd), T)] if grouped else [gxT, gxT]
+            gxT_alt = [gxT] + [A("gxT%d" % k, (rows, Dd), T) for k in (2, 3, 4)] if grouped else [gxT] * 4
             gsel = [0]
 
             def next_gxT():
-                gsel[0] ^= 1
+                gsel[0] = (gsel[0] + 1) % 4
                 return gxT_alt[gsel[0]]
             g_t = self._layernorm_bwd(ops, ddn, xs[-1], "decoder_norm", mN, rN, gx, rows, Dd, accumulate=False, dx_t=gxT)
 
@@ -1110,9 +1110,6 @@ class Engine:
                 if i == 0:
                     ops.append((None, ("tokready",), None))   # every block's dK / dV is final: the exemplar-token backward may start (run_backward_rest_and_tok)
                 self._linear_bwd(ops, dq, d["n1"], b + ".attn.wq.weight", rows, Dd, Dd, dx=dn_t, group=grp)
-                if grouped:      # fc2, fc1, attn.proj, attn.wq: the next LayerNorm backward overwrites fc2's dy
-                    self._linear_wgrad_group(ops, grp)
-                    grp = []
                 g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=next_gxT())
                 dk_t, dv_t = (dk, dv) if dkT is None else (dkT, dvT)    # bf16 copies come out of the cross-attention backward
                 for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
@@ -1127,11 +1124,11 @@ class Engine:
                 else:
                     self._attention_bwd(ops, d["qkv"], d["probs"], dproj_in, dqkv, B, Hd, Dd)
                 self._linear_bwd(ops, dqkv, d["n0"], b + ".selfattn.qkv.weight", rows, 3 * Dd, Dd, dx=dn_t, group=grp)
-                if grouped:      # selfattn.proj, selfattn.qkv
-                    self._linear_wgrad_group(ops, grp)
                 g_t = self._layernorm_bwd(ops, dn_t, d["xin"], b + ".norm0", d["m0"], d["r0"], gx, rows, Dd, accumulate=True, dx_t=next_gxT())
-            # ---- decoder_embed (no dgrad: the encoder is frozen)
-            self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D)
+                if i == 0:   # ---- decoder_embed (no dgrad: the encoder is frozen)
+                    self._linear_bwd(ops, g_t, latent, "decoder_embed.weight", rows, Dd, D, group=grp)
+                if grouped:      # fc2, fc1, attn.proj, attn.wq, selfattn.proj, selfattn.qkv (, decoder_embed)
+                    self._linear_wgrad_group(ops, grp)
             # ---- exemplar tokens: dy_tok = sum over blocks of dK Wk + dV Wv
             ops = lists.bwd_tok
             for j, (g_kv, wn) in enumerate(tok_dgrads):

@@ -668,6 +668,7 @@ def test_lean_linear_wgrad_matches_fp64_and_generic(hip, monkeypatch, R, N, K, l
     (4608, [(512, 2048), (2048, 512), (512, 512), (512, 512)], 2),         # finetune decoder block: fc2, fc1, proj, wq = 96 tiles x 2 slabs
     (1152, [(512, 2048), (1536, 512)], 3),                                 # two launches, three slabs
     (2304, [(768, 3072), (384, 384), (768, 768)], 1),                      # a 384-column problem: the whole group on 128x128 tiles
+    (4608, [(512, 2048), (2048, 512), (512, 512), (512, 512), (512, 512), (1536, 512), (512, 768)], 2),   # a whole decoder block + decoder_embed: 7 launches
 ])
 def test_grouped_linear_wgrads_equal_the_separate_launches(hip, R, shapes, sk):
     """countr_gemm_group: the weight (+ bias) gradients of a block's nn.Linear layers in ONE launch == the same launches through
@@ -712,7 +713,7 @@ def test_grouped_linear_wgrads_equal_the_separate_launches(hip, R, shapes, sk):
         assert torch.equal(grouped[i][1], separate[i][1]), i
     # what does not qualify runs one by one: fp32 launches, a single launch
     assert hip.countr_gemm_group_tiles(arr, n, 0, 1, 1) == 0 and hip.countr_gemm_group_tiles(arr, 1, 1, 1, 1) == 0
-    assert hip.countr_gemm_group(arr, 5, 1, 1, 1, _stream()) != 0
+    assert hip.countr_gemm_group(arr, 9, 1, 1, 1, _stream()) != 0
 
 
 @pytest.mark.parametrize("M,N2", [(4608, 1536), (576, 1536), (14976, 1536), (4608, 2304), (4400, 2304)])   # N2 = 2304 at B = 8: the 192x256 form
