@@ -678,7 +678,9 @@ class Engine:
         """dx_t (bf16 mode): also emit the updated residual gradient as the bf16 operand of the next backward GEMM."""
         # per-block {dgamma, dbeta} partials stay in this LayerNorm's own workspace until the list's table launch
         nb = self.L.countr_layernorm_bwd_nblocks()
-        ws = self._shared("lnw." + self._role(name), nb * 2 * D)
+        # (one workspace per LayerNorm, ~1 MB: with a name shared by role every LayerNorm backward forced the pending sums out -- seven
+        # table launches per step where the list's end and the grouped weight gradients' buffer reuse need two)
+        ws = self._shared("lnw." + name, nb * 2 * D)
         self._claim(ws.data_ptr())
         self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
                  rstd.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), rows, D,
@@ -778,9 +780,10 @@ class Engine:
         tiles = int(self.L.countr_gemm_tiles(C.byref(q), self.code, OP_COL, OP_IM2COL))   # 128x128, or 128x256 on the lean kernel
         sk = self._splitk(tiles, -(-Kp // bk))
         defer = self.defer_reduce
-        part = self._shared(("skp." + self._role(wname)) if defer else "splitk", sk * Cout * 9 * Cin)
+        cw_key = wname     # one partial buffer per convolution (<= 130 MB each): with a buffer per ROLE every weight gradient forced the pending sums out
+        part = self._shared(("skp." + cw_key) if defer else "splitk", sk * Cout * 9 * Cin)
         fuse_bias = bias_name is not None and self.code == BF16
-        rs = self._shared(("rsp." + self._role(wname)) if defer else "rowsum", 64 * 4096) if fuse_bias else None
+        rs = self._shared(("rsp." + cw_key) if defer else "rowsum", 64 * 4096) if fuse_bias else None
         if defer:
             self._claim(part.data_ptr())
         kw = dict(A=dy.data_ptr(), B=x.data_ptr(), partial=part.data_ptr(), lda=Cout, ldc=9 * Cin, M=Cout, N=9 * Cin, K=Kp, H=H, W=W,
