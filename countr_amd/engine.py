@@ -602,6 +602,10 @@ class Engine:
                 self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=bias_name)
             return
         sk = self._splitk(tiles, -(-max(it[3] for it in items) // 64))
+        if any(b_ is not None and sk * (K // 128) * N > 64 * 4096 for (_dy, _x, _w, _M, N, K, b_) in items):   # bias-gradient slabs beyond their workspace
+            for (dy, x, wname, M, N, K, bias_name) in items:
+                self._linear_wgrad(ops, dy, x, wname, M, N, K, bias_name=bias_name)
+            return
         direct = sk == 1 and not self._acc
         later = []
         # (workspaces per position in the group: _role() maps mlp.fc1 and mlp.fc2 to ONE name, fine for launches that follow each other)
