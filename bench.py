@@ -315,8 +315,8 @@ def time_infer(args, world, rank, dev, steps, warmup):
     empty = [torch.zeros(1, 0, device=dev)] * len(frames)
 
     def one():
-        dms = inference.density_maps(model, frames, empty, 0, max_batch=32)
-        return torch.stack([d.sum() for d in dms]) / 60
+        _dms, sums = inference.density_maps(model, frames, empty, 0, max_batch=32, return_sums=True)
+        return torch.stack(sums) / 60
     for _ in range(max(warmup, 2)):
         one()
     torch.cuda.synchronize()

@@ -116,6 +116,9 @@ _SIGS = {
     "countr_masked_mse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "countr_adamw_gnorm_floats": [],
     "countr_splitk_finish": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "countr_window_gather": [_vp, _vp, _vp, _i, _i, _vp, _vp],
+    "countr_window_blend": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "countr_window_blend_blocks": [_i, _i],
     "countr_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp],
 }
 _RESTYPES = {"countr_xattn_bwd_workspace_floats": C.c_int64, "countr_groupnorm_bwd_image_sums_offset": C.c_int64}

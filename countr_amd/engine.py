@@ -1184,6 +1184,13 @@ class Engine:
             p.fwd_gen = getattr(p, "fwd_gen", 0) + 1   # the activations a backward of this plan will read belong to THIS forward
         return p.buf["out"]
 
+    def forward_loaded(self, B, shot_num):
+        """The inference forward of plan (B, shot_num) on inputs that are already IN the plan's buffers (p.buf["img"], p.buf["boxes"]:
+        countr_amd.inference writes the sliding windows there directly).  Returns the output buffer [B, H, W]."""
+        p = self.plan(B, int(shot_num), False)
+        self.run(p.fwd_par)
+        return p.buf["out"]
+
     def backward(self, B, shot_num, dout):
         """Decoder-side backward for the last train-mode forward of plan (B, shot_num); fills self.G."""
         p = self.plan(B, int(shot_num), True)

@@ -63,7 +63,73 @@ def blend_windows_batched(outputs, starts, width, height=384):
 
 
 @torch.no_grad()
-def density_maps(model, images, boxes, shot_num, max_batch=32):
+def _native_maps(model, images, boxes, shot_num, max_batch, want_sums):
+    """density_maps through the two window kernels of the C ABI (countr_window_gather / countr_window_blend: windows cut straight into
+    the engine's input batch, stitched + summed by one launch per image width) when the call fits ONE forward: fp32 device images of
+    the model's height whose windows number <= max_batch.  Returns None when it does not apply (the torch path below then runs)."""
+    import ctypes as C
+    from . import _lib
+    if not images or not hasattr(model, "_engine"):
+        return None
+    h = images[0].shape[-2]
+    plan = [(i, s) for i, im in enumerate(images) for s in window_starts(im.shape[-1])]
+    if (not plan or len(plan) > min(max_batch, 64) or h != getattr(model, "img_size", 384)
+            or any((not im.is_cuda) or im.dtype != torch.float32 or im.dim() != 4 or im.shape[0] != 1 or im.shape[1] != 3 or im.shape[-2] != h
+                   or not im.is_contiguous() for im in images)):
+        return None
+    dev = images[0].device
+    L = _lib.lib()
+    eng = model._engine()
+    nb = _bucket(len(plan), max_batch)
+    p = eng.plan(nb, shot_num, False)
+    img = p.buf["img"]
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    nw = len(plan)
+    frames = (C.c_void_p * nw)(*[images[i].data_ptr() for i, _s in plan])
+    widths = (C.c_int * nw)(*[images[i].shape[-1] for i, _s in plan])
+    starts = (C.c_int * nw)(*[s0 for _i, s0 in plan])
+    _lib.check(L.countr_window_gather(frames, widths, starts, nw, h, img.data_ptr(), st), "countr_window_gather")
+    if nb > nw:
+        img[nw:].zero_()                       # padding rows only need defined values
+    if shot_num > 0:
+        bx = p.buf["boxes"].view(nb, shot_num, 3, 64, 64)
+        for j, (i, _s) in enumerate(plan):
+            bx[j].copy_(boxes[i][0, :shot_num])
+        if nb > nw:
+            bx[nw:].zero_()
+    out = eng.forward_loaded(nb, shot_num)      # [nb, h, 384], valid until the next forward of this plan
+    res, sums = [None] * len(images), [None] * len(images)
+    row = 0
+    i = 0
+    while i < len(images):                      # runs of consecutive images of one width: one blend launch each
+        w = images[i].shape[-1]
+        j = i
+        while j + 1 < len(images) and images[j + 1].shape[-1] == w:
+            j += 1
+        n = j - i + 1
+        stw = window_starts(w)
+        if not stw:
+            for k in range(i, j + 1):
+                res[k] = torch.zeros(h, w, device=dev)          # narrower than a window: the reference's loop never runs
+                sums[k] = torch.zeros((), device=dev)
+        else:
+            dm = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+            sm = torch.empty(n, device=dev, dtype=torch.float32) if want_sums else None
+            ws = torch.empty(n * int(L.countr_window_blend_blocks(h, w)), device=dev, dtype=torch.float32) if want_sums else None
+            arr = (C.c_int * len(stw))(*stw)
+            _lib.check(L.countr_window_blend(out[row:].data_ptr(), n, len(stw), arr, h, w, dm.data_ptr(), sm.data_ptr() if want_sums else None,
+                                             ws.data_ptr() if want_sums else None, st), "countr_window_blend")
+            for k in range(n):
+                res[i + k] = dm[k]
+                if want_sums:
+                    sums[i + k] = sm[k]
+            row += n * len(stw)
+        i = j + 1
+    return (res, sums) if want_sums else res
+
+
+@torch.no_grad()
+def density_maps(model, images, boxes, shot_num, max_batch=32, return_sums=False):
     """Stitched densities of SEVERAL images in as few forwards as possible: images = [[1, 3, 384, w_i], ...], boxes = per image
     [1, >= shot_num, 3, 64, 64] (anything when shot_num == 0) -> [[384, w_i], ...].  Every 384-px window of every image is an
     independent forward of the reference (FSC_test_cross(few-shot).py:326-349, demo_zero.py:49-72), so the windows of all images
@@ -71,6 +137,9 @@ def density_maps(model, images, boxes, shot_num, max_batch=32):
     Images of equal width (video frames) are cut into windows and blended together: one strided copy per window position and one
     blend pass for the whole group instead of one per image (the per-image torch launches were ~10 % of the 8-frame call)."""
     shot_num = int(shot_num)
+    native = _native_maps(model, images, boxes, shot_num, max_batch, return_sums)
+    if native is not None:
+        return native
     dev = images[0].device
     h = images[0].shape[-2]
     plan = [(i, s) for i, im in enumerate(images) for s in window_starts(im.shape[-1])]
@@ -128,7 +197,7 @@ def density_maps(model, images, boxes, shot_num, max_batch=32):
                 res[i0 + k] = dm[k]
         else:
             res[i0] = blend_windows(outs[k0:k0 + len(starts)], starts, w, h)
-    return res
+    return (res, [d.sum() for d in res]) if return_sums else res
 
 
 @torch.no_grad()

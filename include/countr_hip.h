@@ -301,6 +301,19 @@ int countr_patch_mse_workspace_floats(int B, int H, int W, int patch);
 int countr_patch_mse(const float* pred, const float* imgs, void* dpred, float* loss, float* workspace, int B, int H, int W,
                      int patch, int norm_pix, float grad_scale, int dpred_dtype, void* stream);
 
+/* ---- sliding-window test path (FSC_test_cross(few-shot).py:326-349, demo_zero.py:49-72): images of height H = 384 are covered by
+ * 384-px windows (stride 128, the last snapped to w - 384), every window is one forward, densities are stitched column by column --
+ * a column a previous window already covered becomes old / 2 + new / 2, in window order.
+ * countr_window_gather: window j (0 <= j < nw <= 64) = columns [starts[j], starts[j] + 384) of the fp32 image frames[j] [3, H, widths[j]]
+ *   (frames / widths / starts: HOST arrays, read at call time) -> wins fp32 [nw, 3, H, 384], normally the engine's input batch.
+ * countr_window_blend: outs fp32 [n * nwin, H, 384] (image-major: the nwin windows of image 0, then of image 1, ...) of n images of ONE
+ *   width W with the window starts starts[nwin] (HOST array, increasing, <= 16) -> dm fp32 [n, H, W]; sums (optional) fp32 [n] = sum
+ *   of each stitched map (the predicted count x 60), deterministic two-pass sum through workspace fp32 [n * countr_window_blend_blocks(H, W)].
+ * Both equal the reference's tensor slicing / blending bit for bit (x / 2 is exact in fp32). */
+int countr_window_gather(const void* const* frames, const int* widths, const int* starts, int nw, int H, float* wins, void* stream);
+int countr_window_blend(const float* outs, int n, int nwin, const int* starts, int H, int W, float* dm, float* sums, float* workspace, void* stream);
+int countr_window_blend_blocks(int H, int W);
+
 #ifdef __cplusplus
 }
 #endif

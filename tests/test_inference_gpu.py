@@ -124,14 +124,23 @@ def test_config5_batch_of_32_windows(precision, fp32_model):
         if a.shape[0] == 32:
             seen.append((a.detach().clone(), out.detach().clone()))
         return out
-    orig = m.forward
+    orig, native = m.forward, inference._native_maps
     m.forward = spy
+    inference._native_maps = lambda *a, **k: None        # the torch path goes through model.forward (what the spy records) ...
     try:
-        dms = inference.density_maps(m, imgs, [empty] * 8, 0)
+        dms_torch = inference.density_maps(m, imgs, [empty] * 8, 0)
         assert calls == [32]
         single = [inference.density_map(m, im, empty, 0) for im in imgs]
     finally:
         m.forward = orig
+        inference._native_maps = native
+    # ... and the default path cuts the windows straight into the engine's input batch and stitches with countr_window_gather /
+    # countr_window_blend: the same maps bit for bit, the per-image sums of the blend kernel = the maps' sums
+    dms, sums = inference.density_maps(m, imgs, [empty] * 8, 0, return_sums=True)
+    assert inference._native_maps(m, imgs, [empty] * 8, 0, 32, False) is not None
+    for a, b, s_ in zip(dms, dms_torch, sums):
+        assert torch.equal(a, b)
+        assert abs(s_.item() - a.double().sum().item()) <= 1e-5 * a.abs().double().sum().item() + 1e-6
     # the batch-of-32 forward itself against the ORACLE (not only against the engine's own per-image path): windows 0, 5 (second
     # window of frame 1), 18 and 31 of the batch, same bars as the single-image tests (fp32: 1e-3 / +-0.5 counts; bf16, shot_num 0: 6e-2 / 6 %)
     (win, wout), = seen

@@ -568,3 +568,44 @@ def test_copy_multi_zero_fill(hip):
                                      i64(4 * 4000, 4 * 1000, 4 * (1 << 20)), st), "copy_multi")
     torch.cuda.synchronize()
     assert (a[4:4004] == 0).all() and (a[:4] != 0).any() and (a[4004:] != 0).any() and (b == 0).all() and torch.equal(out, keep)
+
+
+@pytest.mark.parametrize("widths", [[672, 672, 512], [386, 1000], [384]])
+def test_window_gather_and_blend_equal_the_torch_slicing(hip, widths):
+    """countr_window_gather / countr_window_blend (the sliding-window test path, FSC_test_cross(few-shot).py:326-349) against the tensor
+    slicing and the sequential blend of countr_amd.inference (which follow the reference's loop): bit for bit, for widths that allow
+    16-byte row segments (672, 512) and widths that do not (386: second window at column 2; 1000: last window snapped to 616)."""
+    import ctypes as Ct
+    from countr_amd import inference
+    H = 384
+    torch.manual_seed(5)
+    imgs = [torch.randn(1, 3, H, w, device="cuda") for w in widths]
+    plan = [(i, s0) for i, im in enumerate(imgs) for s0 in inference.window_starts(im.shape[-1])]
+    nw = len(plan)
+    wins = torch.full((nw + 1, 3, H, 384), float("nan"), device="cuda")
+    frames = (Ct.c_void_p * nw)(*[imgs[i].data_ptr() for i, _ in plan])
+    ws = (Ct.c_int * nw)(*[imgs[i].shape[-1] for i, _ in plan])
+    sarr = (Ct.c_int * nw)(*[s0 for _, s0 in plan])
+    _lib.check(hip.countr_window_gather(frames, ws, sarr, nw, H, wins.data_ptr(), st()), "gather")
+    torch.cuda.synchronize()
+    assert torch.isnan(wins[nw]).all()
+    for j, (i, s0) in enumerate(plan):
+        assert torch.equal(wins[j], imgs[i][0, :, :, s0:s0 + 384]), j
+    bad = (Ct.c_int * nw)(*[w for w in ws])           # a window that leaves its image is refused
+    assert hip.countr_window_gather(frames, ws, bad, nw, H, wins.data_ptr(), st()) != 0
+    # blend: n images of one width
+    for w in sorted(set(widths)):
+        starts = inference.window_starts(w)
+        n = 3
+        outs = torch.randn(n * len(starts), H, 384, device="cuda")
+        dm = torch.full((n, H, w), float("nan"), device="cuda")
+        sums = torch.full((n,), float("nan"), device="cuda")
+        wsp = torch.empty(n * hip.countr_window_blend_blocks(H, w), device="cuda")
+        arr = (Ct.c_int * len(starts))(*starts)
+        _lib.check(hip.countr_window_blend(outs.data_ptr(), n, len(starts), arr, H, w, dm.data_ptr(), sums.data_ptr(), wsp.data_ptr(), st()), "blend")
+        torch.cuda.synchronize()
+        for k in range(n):
+            ref = inference.blend_windows(outs[k * len(starts):(k + 1) * len(starts)], starts, w, H)
+            assert torch.equal(dm[k], ref), (w, k)
+            assert abs(sums[k].item() - ref.double().sum().item()) <= 1e-5 * ref.abs().double().sum().item()
+
