@@ -81,6 +81,7 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
   const bf16_t* op = outp + (int64_t)b * N * ro + h * DH;
   const float* lsep = lse + (int64_t)bh * N;
   const int r0 = rb * FA_BQ + wave * 32;  // first resident row (query for MODE 0, key for MODE 1) of this wave
+  const bool active = r0 < N;             // wave-uniform
 
   // ---- resident fragments: R1 (Q | K) and R2 (dO | V), MFMA B-operand layout: lane (li, g) holds row r0 + rt*16 + li
   const bf16_t* r1p = (MODE == 0) ? qp : kp;
@@ -190,6 +191,7 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
     const char* T2 = T1 + TILE;
     const float* ST = reinterpret_cast<const float*>(T1 + 2 * TILE);
 
+    if (active) {   // (a wave whose 32 resident rows all lie beyond N -- N = 288: three of twelve -- only helps staging)
     // ---- S-type products: x1 = T1 R1^T (scores), x2 = T2 R2^T (dP)
     f32x4_t x1[4][2], x2[4][2];
 #pragma unroll
@@ -270,9 +272,11 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
         }
       }
 
+    }   // active
     if (more) lstore((t + 1) & 1);
     __syncthreads();
   }
+  if (!active) return;      // (no barrier behind this point)
 
   // ---- epilogue: lane (li, g) owns resident row r0 + rt*16 + li and channels dt*16 + 4g .. +3; as in the forward the wave's
   // [32][DH] block goes through its slice of the (now idle) tile ring and out as whole rows in 16-byte chunks
