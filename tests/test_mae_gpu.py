@@ -251,3 +251,29 @@ def test_pretrain_step_at_the_real_config_matches_oracle():
     moved = sum(float(np.abs(m.state_dict()[k].detach().float().cpu().numpy() - before[k]).max()) > 0 for k in before if "pos_embed" not in k)
     assert moved >= 200
     print("worst gradient rms error", worst)
+
+
+@pytest.mark.parametrize("B", [2, 8])
+def test_pretrain_step_is_bit_reproducible(B):
+    """Two identical runs of PretrainStep (fresh model, same seeds, hipGraph replay) give the SAME flat gradient buffer bit for bit after
+    every step: no atomics anywhere, and no two launches of one grouped weight-gradient launch may share a partial buffer (round 4's first
+    grouped version did: fc1 and fc2 carry one workspace name once the digits are stripped).  B = 8: the encoder groups run with ONE
+    split-K slab written straight into the gradient; B = 2: several slabs and the table-driven sums."""
+    from countr_amd.trainer import PretrainStep
+    runs = []
+    for _ in range(2):
+        m, _sd = build(NAME, "bf16", seed=1)
+        m.train()
+        step = PretrainStep(m, batch=B, mask_ratio=0.5, lr=1e-4, weight_decay=0.05, use_graph=True)
+        gs = []
+        for it in range(3):
+            imgs, ids_shuffle, _r, _k = W.make_mae_inputs(batch=B, seed=70 + it, mask_ratio=0.5)
+            step.load(torch.from_numpy(imgs).cuda(), torch.from_numpy(ids_shuffle).cuda())
+            step.step()
+            torch.cuda.synchronize()
+            gs.append(step.eng.G.clone())
+        runs.append(gs)
+        del step, m
+    for it in range(3):
+        assert torch.isfinite(runs[0][it]).all()
+        assert torch.equal(runs[0][it], runs[1][it]), (it, int((runs[0][it] != runs[1][it]).sum()))
