@@ -619,7 +619,8 @@ class Engine:
                 q.partial = part.data_ptr()
                 later.append((part.data_ptr(), part.data_ptr(), self._gp(wname), sk, N * K, N * K))
             if bias_name is not None:
-                rs = self._shared("rsg%d." % i + self._role(wname), 64 * 4096)
+                # (1 MB per layer, not per role: with the weights' slabs gone -- `direct` -- nothing else would force the pending sums out per block)
+                rs = self._shared("rsg." + wname, 64 * 4096)
                 rslabs = int(self.L.countr_gemm_rowsum_slabs(C.byref(q), self.code, OP_COL, OP_COL))
                 assert rslabs * N <= 64 * 4096, (wname, rslabs, N)
                 self._claim(rs.data_ptr())
