@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel
 // Several nn.Linear weight gradients in ONE launch (countr_gemm_group): the workgroups of problem i are [start[i], start[i + 1]) of the
 // XCD-ordered index.  Why: the four weight gradients of a transformer block are 16-72 tiles each -- alone each needs 3-16 split-K slabs
 // to fill the chip (fp32 partials written and summed again); together they fill it with one or two.
-constexpr int CWG_GROUP_MAX = 8;
+constexpr int CWG_GROUP_MAX = 10;
 struct CwgGroup {
   CwgArgs it[CWG_GROUP_MAX];
   int start[CWG_GROUP_MAX + 1];
@@ -372,7 +372,7 @@ static void cwg_fill(CwgArgs& g, const countr_gemm_args* a, bool lin, int form) 
 }
 
 // Tile width (in 128-column units) a group of n (COL, COL) split-K launches runs at in ONE launch, or 0 when it does not qualify (the
-// caller then launches them one by one): 2 to 8 nn.Linear weight gradients, each qualifying on its own; 256-column tiles when every
+// caller then launches them one by one): 2 to 10 nn.Linear weight gradients, each qualifying on its own; 256-column tiles when every
 // problem has the columns for them.  (The accumulation order of an output element does not depend on the tile width.)
 int countr_lean_wgrad_group_form(const countr_gemm_args* items, int n) {
   if (n < 2 || n > CWG_GROUP_MAX) return 0;

@@ -184,7 +184,7 @@ extern "C" int countr_gemm_group_tiles(const countr_gemm_args* items, int n, int
 // exists (bf16 (COL, COL) split-K launches: the weight gradients of a transformer block's nn.Linear layers, conv_wgrad.hip), otherwise
 // one by one.  Results equal those of the separate launches bit for bit (same splitk per launch: same accumulation order).
 extern "C" int countr_gemm_group(const countr_gemm_args* items, int n, int dtype, int modeA, int modeB, void* stream) {
-  if (!items || n < 1 || n > 8) { countr_set_error("countr_gemm_group: 1 to 8 launches"); return -1; }
+  if (!items || n < 1 || n > 10) { countr_set_error("countr_gemm_group: 1 to 10 launches"); return -1; }
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_COL && modeB == COUNTR_OP_COL && n > 1) {
     bool ok = true;
     for (int i = 0; i < n && ok; ++i) {

@@ -590,7 +590,7 @@ class Engine:
         no accumulation window the kernel writes the gradient itself (no slab sum).  fp32 mode, or a group the library would run as
         separate launches anyway: the per-layer path."""
         n = len(items)
-        arr = (GemmArgs * n)() if 2 <= n <= 8 and self.code == BF16 and self.group_wgrads else None
+        arr = (GemmArgs * n)() if 2 <= n <= 10 and self.code == BF16 and self.group_wgrads else None
         tiles = 0
         if arr is not None:
             for q, (dy, x, wname, M, N, K, _b) in zip(arr, items):
@@ -885,7 +885,12 @@ class Engine:
         Sy = max(S, 1)
         xs = [A("dx0", (rows, Dd), f32)]
         self._linear(ops, latent, "decoder_embed.weight", xs[0], rows, Dd, D, resid=self._pp("decoder_pos_embed"), res_mod=N)
-        ytok = A("ytok", (B * Sy, Dd), T)
+        # (rows padded to a multiple of 64 with zeros, never written: as a weight gradient's operand the token matrix is then whole k-tiles,
+        # so attn.wk / attn.wv join the block's grouped weight-gradient launch instead of four 16-workgroup launches of their own)
+        tok_rows = -(-(B * Sy) // 64) * 64
+        ytok = A("ytok", (tok_rows, Dd), T)
+        if not self._sizing:
+            ytok.zero_()
         if S == 0:
             # y = shot_token broadcast over the batch (models_mae_cross.py:176): ONE row gather with an all-zero index (it was one cast
             # launch per batch element: 32 tiny launches in front of every B = 32 inference forward)
@@ -1096,8 +1101,11 @@ class Engine:
             # the head of bwd_tok, off the decoder's own dependency chain
             dk_b = [A("dk%d" % i, (B * Sy, Dd), f32) for i in range(self.ddepth)]
             dv_b = [A("dv%d" % i, (B * Sy, Dd), f32) for i in range(self.ddepth)]
-            dkT_b = [A("dkT%d" % i, (B * Sy, Dd), T) if code == BF16 else None for i in range(self.ddepth)]
-            dvT_b = [A("dvT%d" % i, (B * Sy, Dd), T) if code == BF16 else None for i in range(self.ddepth)]
+            dkT_b = [A("dkT%d" % i, (tok_rows, Dd), T) if code == BF16 else None for i in range(self.ddepth)]     # (rows padded with zeros, as ytok)
+            dvT_b = [A("dvT%d" % i, (tok_rows, Dd), T) if code == BF16 else None for i in range(self.ddepth)]
+            if not self._sizing and code == BF16:
+                for t_ in dkT_b + dvT_b:
+                    t_.zero_()
             dy_tok = A("dy_tok", (B * Sy, Dd), f32)
             xws = self._shared("xattn", L.countr_xattn_bwd_workspace_floats(B, N, Sy, Dd))
             tok_dgrads = []
@@ -1121,7 +1129,10 @@ class Engine:
                 g_t = self._layernorm_bwd(ops, dn_t, d["x1"], b + ".norm1", d["m1"], d["r1"], gx, rows, Dd, accumulate=True, dx_t=next_gxT())
                 dk_t, dv_t = (dk, dv) if dkT is None else (dkT, dvT)    # bf16 copies come out of the cross-attention backward
                 for nm, g_kv in (("wk", dk_t), ("wv", dv_t)):
-                    self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
+                    if grouped:     # over the zero-padded rows: whole k-tiles, same sums
+                        grp.append((g_kv, ytok, b + ".attn.%s.weight" % nm, tok_rows, Dd, Dd, b + ".attn.%s.bias" % nm))
+                    else:
+                        self._linear_wgrad(ops, g_kv, ytok, b + ".attn.%s.weight" % nm, B * Sy, Dd, Dd, bias_name=b + ".attn.%s.bias" % nm)
                     tok_dgrads.append((g_kv, b + ".attn.%s.weight" % nm))
                 # ---- self attention: x1 = xin + proj(attn(qkv(LN0(xin))))
                 self._linear_bwd(ops, g_t, d["att"], b + ".selfattn.proj.weight", rows, Dd, Dd, dx=dproj_in, group=grp)

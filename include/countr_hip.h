@@ -115,7 +115,7 @@ int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, int modeA, in
  * maps with Cin % 256 == 0 (128 x 256). */
 int countr_gemm_tiles(const countr_gemm_args* a, int dtype, int modeA, int modeB);
 
-/* n (1..8) independent launches of one (dtype, modeA, modeB) kind, with the results of n countr_gemm calls bit for bit, in ONE kernel
+/* n (1..10) independent launches of one (dtype, modeA, modeB) kind, with the results of n countr_gemm calls bit for bit, in ONE kernel
  * launch where a grouped form exists: bf16 (COL, COL) split-K launches, i.e. the weight gradients dW = dy^T x of a transformer block's
  * nn.Linear layers (autograd of Mlp / Attention / CrossAttention, models_crossvit.py:46-128; timm Block, models_mae_cross.py:32-34).
  * Why: those are 16-72 output tiles each -- alone each needs 3-16 split-K slabs to fill 256 CUs (fp32 partials written, then summed

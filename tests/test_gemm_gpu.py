@@ -713,7 +713,7 @@ def test_grouped_linear_wgrads_equal_the_separate_launches(hip, R, shapes, sk):
         assert torch.equal(grouped[i][1], separate[i][1]), i
     # what does not qualify runs one by one: fp32 launches, a single launch
     assert hip.countr_gemm_group_tiles(arr, n, 0, 1, 1) == 0 and hip.countr_gemm_group_tiles(arr, 1, 1, 1, 1) == 0
-    assert hip.countr_gemm_group(arr, 9, 1, 1, 1, _stream()) != 0
+    assert hip.countr_gemm_group(arr, 11, 1, 1, 1, _stream()) != 0
 
 
 @pytest.mark.parametrize("M,N2", [(4608, 1536), (576, 1536), (14976, 1536), (4608, 2304), (4400, 2304)])   # N2 = 2304 at B = 8: the 192x256 form
