@@ -130,7 +130,7 @@ def main(args):
         it_data = iter(loader) if loader is not None else None
         # the loop's own device work (mask draw, error sums) runs on the step's stream: from another stream every step pays two
         # cross-queue hand-overs (inputs ready -> step, step done -> caller), ~50 us of idle GPU per step on MI355X
-        with torch.cuda.stream(step.stream):
+        with step.on_stream():
             for it in range(n_iter):
                 if it % args.accum_iter == 0:                                               # :270-271 (per accumulation window)
                     lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
@@ -171,7 +171,6 @@ def main(args):
                         print(json.dumps({"epoch": epoch, "it": it + 1, "loss": loss, "lr": lr, "shot_num": S,
                                           "batch_MAE": float(np.abs(s[1:1 + B] - s[1 + B:1 + 2 * B]).mean()),
                                           "grad_norm": float(gn.item()) if gn is not None else None}))
-        torch.cuda.current_stream(device).wait_stream(step.stream)
         # ---- evaluation on the validation split (:329-350): no_grad forward, shot_num drawn per batch, MAE / RMSE / NAE of the counts
         val = evaluate(model, val_loader, n_val, B, device, val_rng, seed, epoch)
         train_mae, train_mse = (train_acc / n_iter).tolist()

@@ -105,7 +105,7 @@ def main(args):
         if loader is not None:
             loader.sampler.set_epoch(epoch)                                             # :236-237
         it_data = iter(loader) if loader is not None else None
-        with torch.cuda.stream(step.stream):      # one stream for the loop's device work and the step (no cross-queue hand-over per step)
+        with step.on_stream():      # one stream for the loop's device work and the step (no cross-queue hand-over per step)
             for it in range(n_iter):
                 if it % args.accum_iter == 0:                                               # :258-259 (per accumulation window)
                     lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
@@ -122,7 +122,6 @@ def main(args):
                     losses.append(lv)
                     if misc.is_main_process():
                         print(json.dumps({"epoch": epoch, "it": it + 1, "loss": lv, "lr": lr}))
-        torch.cuda.current_stream(device).wait_stream(step.stream)
         opt_state = step.optimizer_state()
         if args.output_dir and (epoch % 100 == 0 or epoch + 1 == args.epochs):         # :327-329
             misc.save_model(args, epoch, model, opt_state, suffix="pretraining_%d" % epoch)

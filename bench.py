@@ -44,6 +44,65 @@ def cpu_baseline(batch=4, steps=4, threads=None):
             "sample": "%d finetune step(s) of batch %d (fwd + decoder bwd + AdamW), fp32, torch-CPU oracle" % (steps, batch)}
 
 
+def parity_check(model, step, world, rank, B, NB, dev):
+    """The timed object -- the same FinetuneStep, graph replay, batch k = 0 of every rank -- against the oracle, OUTSIDE every timed region
+    (FSC_finetune_cross.py:286-316).  The oracle is the CHECKER here, never the thing measured.  Every rank steps once on its batch 0 with
+    that batch's seeded loss mask; rank 0 evaluates the oracle at the parameters the engine held in front of the step for EVERY rank's
+    batch and compares: its own loss (1e-2) and counts (1 %), and per trainable tensor the gradient left in the step's flat buffer --
+    after the all-reduce that is the SUM over ranks, so at N > 1 this also checks what RCCL carried -- by direction (cos >= 0.999;
+    exemplar CNN 0.97) and norm (1.5 % / 2 %): the bars of tests/test_trainer_gpu.py::test_finetune_step_at_the_real_config_matches_oracle.
+    Raises on a miss; returns the dict reported as `parity` in the JSON line."""
+    from countr_amd.synthetic import make_batch
+    cur = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    imgs, boxes, gt, mask = make_batch(B, shots=3, seed=rank * NB, device=dev)
+    with step.on_stream():
+        step.load(imgs, boxes, gt, mask, 3)
+        sums = step.step(3).clone()
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    from oracle import countr_ref as R
+    t0 = time.time()
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    total, mine = {}, None
+    for r in range(world):
+        b = [t.cpu().numpy() for t in make_batch(B, shots=3, seed=r * NB)]
+        out, rloss, rg = R.loss_and_grads(cur, b[0], b[1], b[2], b[3], 3)
+        if r == 0:
+            mine = (out, rloss)
+        for k, g in rg.items():
+            if g is not None:
+                total[k] = g.double() if k not in total else total[k] + g.double()
+    out, rloss = mine
+    loss = sums[0].item()
+    rel_loss = abs(loss - rloss.item()) / abs(rloss.item())
+    rc = R.counts(out).numpy()
+    rel_cnt = float((abs(sums[1:1 + B].cpu().numpy() - rc) / abs(rc)).max())
+    worst_cos, worst_norm, worst_cnn, checked = 1.0, 0.0, 1.0, 0
+    for k, ref in total.items():
+        if ref.norm() < 1e-3:
+            continue
+        got = step.eng.gview(k).detach().cpu().double()
+        cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
+        ratio = (got.norm() / ref.norm()).item()
+        if k.startswith("decoder_proj"):
+            ok = cos > 0.97 and abs(ratio - 1) < 0.02
+            worst_cnn = min(worst_cnn, cos)
+        else:
+            ok = cos > 0.999 and abs(ratio - 1) < 0.015
+            worst_cos, worst_norm = min(worst_cos, cos), max(worst_norm, abs(ratio - 1))
+        if not ok:
+            raise SystemExit("bench.py: parity check FAILED on %s: cos %.5f, norm ratio %.4f" % (k, cos, ratio))
+        checked += 1
+    if rel_loss > 1e-2 or rel_cnt > 1e-2 or checked < 55:
+        raise SystemExit("bench.py: parity check FAILED: loss off by %.2e, counts by %.2e, %d gradient tensors" % (rel_loss, rel_cnt, checked))
+    return {"checked": True, "against": "oracle/countr_ref.py (fp32 torch-CPU restatement pinned to the reference's goldens) at the engine's own parameters",
+            "object": "the timed FinetuneStep (graph replay), batch 0 of every rank, shot_num 3", "loss_rel_err": rel_loss, "count_rel_err": rel_cnt,
+            "gradient_tensors": checked, "gradients": "flat buffer after the all-reduce vs the sum of the oracle's per-rank gradients" if world > 1
+            else "flat buffer vs the oracle's gradients", "min_cos": worst_cos, "max_norm_err": worst_norm, "min_cos_exemplar_cnn": worst_cnn,
+            "seconds": time.time() - t0}
+
+
 def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=True):
     """Roofline of the dominant fused kernel: the attention core of one encoder layer (B x 12 heads, N=576, dh=64).
     `us_per_launch` is measured IN-STEP with HIP events on the launch stream: the forward launch list of the plan is replayed
@@ -258,18 +317,19 @@ def time_pretrain(args, world, rank, dev, batch, steps, warmup):
     imgs = torch.rand(batch, 3, 384, 384, device=dev)
 
     def one():
-        with torch.cuda.stream(step.stream):     # the loop runs on the step's stream (see the finetune loop below)
-            step.load(imgs)          # draws a fresh masking permutation (torch.rand + argsort) every step, as the reference
-            return step.step()
-    for _ in range(max(warmup, 2)):
-        one()
+        step.load(imgs)          # draws a fresh masking permutation (torch.rand + argsort) every step, as the reference
+        return step.step()
+    with step.on_stream():         # the loop runs on the step's stream (see the finetune loop below)
+        for _ in range(max(warmup, 2)):
+            one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = one()
+    with step.on_stream():
+        for _ in range(steps):
+            loss = one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -405,6 +465,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step (it runs outside the timed regions)")
     ap.add_argument("--no-b32", action="store_true", help="skip roofline_b32 (profiling runs: keeps the attention kernel's launches of the "
                                                            "kernel-stats CSV at the one problem size of the step)")
     ap.add_argument("--plain", action="store_true", help="counter / trace runs: warm-up + the timed blocks only -- no shot-mix loop, no roofline "
@@ -466,12 +527,12 @@ def main():
 
     def one(k, S):
         imgs, boxes, gt, _ = batches[k % NB]
-        # the loop's own device work (the per-iteration mask draw) runs on the step's stream, as everything does on ONE stream in the
-        # reference's loop: from another stream every step pays two cross-queue hand-overs (inputs ready -> step, step done -> caller)
-        with torch.cuda.stream(step.stream):
-            mask = torch.empty(384, 384, device=dev).bernoulli_(0.8, generator=mgen)
-            step.load(imgs, boxes, gt, mask, S)
-            return step.step(S)
+        # the loop's own device work (the per-iteration mask draw) runs on the step's stream (callers enter step.on_stream() around
+        # their loop), as everything does on ONE stream in the reference's loop: from another stream every step pays two cross-queue
+        # hand-overs (inputs ready -> step, step done -> caller)
+        mask = torch.empty(384, 384, device=dev).bernoulli_(0.8, generator=mgen)
+        step.load(imgs, boxes, gt, mask, S)
+        return step.step(S)
 
     def timed(shots):
         torch.cuda.synchronize()
@@ -479,8 +540,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k, S in enumerate(shots):
-            sums = one(k, S)
+        with step.on_stream():
+            for k, S in enumerate(shots):
+                sums = one(k, S)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -492,8 +554,10 @@ def main():
             dt = t.item()
         return dt, sums
 
-    for k in range(max(args.warmup, 2)):   # the first two steps build the plan and capture the graphs
-        one(k, 3)
+    with step.on_stream():
+        for k in range(max(args.warmup, 2)):   # the first two steps build the plan and capture the graphs
+            one(k, 3)
+    parity = None if (args.plain or args.no_parity) else parity_check(model, step, world, rank, B, NB, dev)
     step.sync.profile = world > 1 or step.sync.comm
     # box-to-box and run-to-run spread (5.3-5.55 ms over the boxes of round 2) is larger than most single optimisations: the block of
     # --steps steps is timed --reps times (each bracketed by barrier + synchronize, max over ranks) and the MEDIAN block is the value
@@ -509,8 +573,9 @@ def main():
             # communication is measured on a short extra run in the per-phase-graph mode (host-issued collectives between the phases),
             # whose step time is reported beside it
             step.sync.capturable = False
-            for k in range(3):
-                one(k, 3)
+            with step.on_stream():
+                for k in range(3):
+                    one(k, 3)
             torch.cuda.synchronize()
             step.sync.exposed_us()          # (drops the warm-up steps' event pairs)
             dt_h, _ = timed([3] * min(args.steps, 20))
@@ -530,8 +595,9 @@ def main():
         return
     from countr_amd.parallel import shared_shot_num
     mix = [shared_shot_num(i, seed=0) for i in range(args.steps)]
-    for S in sorted(set(mix) | {0, 1, 2}):
-        one(0, S); one(1, S)               # build / capture the plans of the other shot counts outside the timed region
+    with step.on_stream():
+        for S in sorted(set(mix) | {0, 1, 2}):
+            one(0, S); one(1, S)           # build / capture the plans of the other shot counts outside the timed region
     dt_mix, _ = timed(mix)
     loss = sums[0].item()
     ranks_seen = None
@@ -552,6 +618,7 @@ def main():
                                    "frozen encoder fwd + decoder fwd/bwd + masked-MSE + AdamW" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
             "final_loss": loss,
+            "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "inputs": "pinned host memory, copied over PCIe every step" if args.host_inputs else "resident in HBM",
             "step_tflops": GF_STEP_PER_IMG * ips / 1e12,
             "timed_region": "per step: device-to-device staging of a batch + fresh loss mask + fwd + loss + decoder bwd + grad all-reduce + AdamW",

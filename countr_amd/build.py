@@ -40,7 +40,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     reused = 0
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")

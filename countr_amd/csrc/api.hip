@@ -1,11 +1,28 @@
 // Library management + error plumbing of libcountr_hip.so (see include/countr_hip.h).
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 #include <string.h>
 #include <stdio.h>
+#include <atomic>
+#include <mutex>
 
 namespace {
 thread_local char g_err[512] = "";
+// Per-device read-only data, allocated ONCE by countr_init(device) (the only place this library allocates) and never written again:
+// a vector of zeros that bias-less launches (input gradients) hand to epilogues that always add a bias.  Launch paths only read the
+// pointer (countr_zero_vec): no allocation, no first-touch race between the forward thread and the autograd thread, legal under
+// stream capture, one vector per device.
+constexpr int MAX_DEV = 64;
+std::mutex g_init_mu;
+std::atomic<float*> g_zero[MAX_DEV];
+}
+
+const float* countr_zero_vec(int n) {
+  int d = -1;
+  if (n > COUNTR_ZERO_VEC_FLOATS || hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) return nullptr;
+  const float* z = g_zero[d].load(std::memory_order_acquire);
+  if (!z) countr_set_error("countr_init(device) has not been called for the current device (it allocates the per-device constants)");
+  return z;
 }
 
 extern "C" void countr_set_error(const char* msg) {
@@ -42,6 +59,17 @@ extern "C" int countr_init(int device) {
     snprintf(buf, sizeof(buf), "countr_init: device arch %s is not gfx950 (kernels are built for MI355X only)", p.gcnArchName);
     countr_set_error(buf);
     return -2;
+  }
+  if (device >= MAX_DEV) { countr_set_error("countr_init: more than 64 devices"); return -1; }
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_zero[device].load(std::memory_order_acquire)) {
+    float* z = nullptr;
+    if (hipMalloc(&z, COUNTR_ZERO_VEC_FLOATS * sizeof(float)) != hipSuccess || hipMemset(z, 0, COUNTR_ZERO_VEC_FLOATS * sizeof(float)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+      countr_set_error("countr_init: cannot allocate the per-device constants");
+      return -3;
+    }
+    g_zero[device].store(z, std::memory_order_release);
   }
   return 0;
 }

@@ -2,7 +2,7 @@
 //   softmax rows fwd/bwd  : the unfused self-attention path (scores via countr_gemm), fp32 statistics
 //   cross attention       : q [B*N, D] against S <= 8 exemplar tokens; one wave per query row
 //   (the fused flash-style self-attention forward lives in flash_attn.hip)
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 
 namespace {

@@ -173,6 +173,10 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { if
 // Error plumbing shared by all translation units (defined in api.hip).
 extern "C" void countr_set_error(const char* msg);
 int countr_check_launch(const char* what);
+// >= n zeros in device memory on the CURRENT device, allocated once by countr_init (api.hip) and read-only afterwards; nullptr (+ error
+// text) when countr_init was not called for this device.  The launch paths never allocate.
+#define COUNTR_ZERO_VEC_FLOATS 8192
+const float* countr_zero_vec(int n);
 #define COUNTR_LAUNCH_CHECK(what) return countr_check_launch(what)
 
 // K order of the 3x3 convolutions' implicit GEMMs in linear.hip / gemm256.hip (K = 9 taps x Cin, k-tile = 64 channels of one tap):
@@ -183,7 +187,8 @@ int countr_check_launch(const char* what);
 #ifndef COUNTR_CONV_CHUNK_MAJOR
 #define COUNTR_CONV_CHUNK_MAJOR 1
 #endif
-// (tap, channel offset) of k-tile t for Cin = 64 << cpt_log; t / 9 as (t * 57) >> 9 is exact for t < 80 (Cin <= 512: t <= 73)
+// (tap, channel offset) of k-tile t for Cin = 64 << cpt_log; t / 9 as (t * 57) >> 9 is exact for t < 512 (Cin <= 512: t <= 71;
+// countr_lean_conv_rows / countr_big_conv refuse wider inputs)
 __device__ __forceinline__ void countr_conv_ktile(int t, int Cin, int& tap, int& cb) {
 #if COUNTR_CONV_CHUNK_MAJOR
   const int c = (t * 57) >> 9;

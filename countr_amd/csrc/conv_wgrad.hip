@@ -19,7 +19,7 @@
 // would cost a wave 25 %, so the k-tiles of a (z, 32-row block) are dealt round-robin to the NC = tilesN * WNB waves that hold that
 // block's fragments anyway (+1.4 % each); every one writes its own slab: rowsum_partial[z * NC + i][Cout]
 // (countr_gemm_rowsum_slabs() tells the caller how many slabs a launch writes).
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 #include <type_traits>

@@ -6,7 +6,7 @@
 //   cast / permute  : weight shadows (OIHW -> OHWI, dgrad form)
 //   masked mse loss : FSC_finetune_cross.py:290-303
 //   adamw           : torch.optim.AdamW(betas=(0.9,0.95))           (FSC_finetune_cross.py:235)
-#include "common.cuh"
+#include "common.hpp"
 #include <stdlib.h>
 #include "../../include/countr_hip.h"
 

@@ -7,7 +7,7 @@
 //   * exp2 domain: p = exp2(s * c - m), c = scale * log2(e).
 //   * PV-type accumulations take their second operand from the lane's own registers by choosing the MFMA k-slot order
 //     kappa(g, e) = {4g..4g+3, 16+4g..16+4g+3}; the transposed tile is read with ds_read_b64_tr_b16 in the same key order.
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 

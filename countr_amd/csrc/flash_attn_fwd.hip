@@ -28,7 +28,7 @@
 // 32x32x16 MFMA occupies the matrix pipe for 32 cycles but hides only ~12 cycles of VALU work; v_fma 2.8, v_exp_f32 8.3,
 // v_cvt_pk_bf16_f32 4.7 cycles per wave instruction.  A tile costs a wave 16 MFMAs and ~570 VALU cycles (half of them the 32
 // v_exp_f32), so the loop is VALU-bound by construction at dh = 64.
-#include "common.cuh"
+#include "common.hpp"
 #ifndef COUNTR_FA_NOPIN
 #define COUNTR_FA_NOPIN 0   // experiments: 1 = no end-of-slot sched_barrier in the pipelined step, 2 = one every fourth slot, 3 = none at all
 #endif

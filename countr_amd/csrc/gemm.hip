@@ -8,13 +8,13 @@
 //         compile-time variants staged through LDS into whole-row-segment stores.
 //   fp32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain), register-staged padded tiles -- the parity mode.
 // Reference call sites: models_crossvit.py:62,65,84-92,115-127; models_mae_cross.py:47-100,138,152.
-#include "common.cuh"
+#include "common.hpp"
 #include <type_traits>
 #include <utility>
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 
-// the kernel template lives in gemm_kernel.cuh; its instantiations in gemm_bf16_a.hip ((ROW, ROW), (ROW, COL), (COL, COL)),
+// the kernel template lives in gemm_kernel.hpp; its instantiations in gemm_bf16_a.hip ((ROW, ROW), (ROW, COL), (COL, COL)),
 // gemm_bf16_b.hip ((COL, ROW), (IM2ROW, ROW), (COL, IM2COL)) and gemm_f32.hip (all six, parity mode).  1 = not one of mine.
 int countr_gemm_bf16_a(const countr_gemm_args& a, int ma, int mb, hipStream_t s);
 int countr_gemm_bf16_b(const countr_gemm_args& a, int ma, int mb, hipStream_t s);

@@ -18,7 +18,7 @@
 //     on the read), W rows read in the permuted order that makes a lane's 16 accumulator registers 16 consecutive output columns.
 //   * epilogue: fp32 accumulators -> LDS (two passes of 64 rows per wave) -> whole 128-byte row segments; bias, LayerNorm fold, GELU on the
 //     read-back side.
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -92,7 +92,7 @@ __device__ __forceinline__ void wait12(bf16x8_t (&f)[2][4], bf16x8_t (&g)[4]) {
                "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
 }
 
-// packed form of common.cuh's gelu_fast (same operations on fp32 pairs: bit-identical results; copy of linear.hip's)
+// packed form of common.hpp's gelu_fast (same operations on fp32 pairs: bit-identical results; copy of linear.hip's)
 __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
   const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -8.f, 8.f), __builtin_amdgcn_fmed3f(x[1], -8.f, 8.f)};
   const f32x2_t x2 = xc * xc;
@@ -568,12 +568,6 @@ int launch_big(const BigArgs& a0, hipStream_t s) {
   COUNTR_LAUNCH_CHECK("countr_gemm(256x256 8-phase)");
 }
 
-float* zero_bias_vec() {
-  static float* z = nullptr;
-  if (!z && (hipMalloc(&z, 8192 * sizeof(float)) != hipSuccess || hipMemset(z, 0, 8192 * sizeof(float)) != hipSuccess)) z = nullptr;
-  return z;
-}
-
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 }  // namespace
@@ -613,8 +607,9 @@ int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
     const long rounds = (tiles + 255) / 256;
     if (tiles < 200 || tiles * 100 < rounds * 256 * 80) return 1;
   }
-  const float* bias = a->bias ? a->bias : zero_bias_vec();
-  if (!bias) return 1;
+  if (!a->bias && a->N > COUNTR_ZERO_VEC_FLOATS) return 1;
+  const float* bias = a->bias ? a->bias : countr_zero_vec(a->N);      // the per-device vector of zeros countr_init allocated
+  if (!bias) return -1;
   BigArgs g;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = bias;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = a->N / 256;
@@ -662,8 +657,9 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
     const long rounds = (tiles + 255) / 256;
     if (tiles < 200 || tiles * 100 < rounds * 256 * 80) return 1;
   }
-  const float* bias = a->bias ? a->bias : zero_bias_vec();
-  if (!bias) return 1;
+  if (!a->bias && a->N > COUNTR_ZERO_VEC_FLOATS) return 1;
+  const float* bias = a->bias ? a->bias : countr_zero_vec(a->N);      // the per-device vector of zeros countr_init allocated
+  if (!bias) return -1;
   if (head < tiles) {
     // the tail first checks that it qualifies (same conditions as ours, plus its own) by launching: it runs BEHIND the head on the stream
     // either way, so launch order on the host is free; launching it first lets a refusal fall back to the single launch

@@ -1,5 +1,5 @@
-// bf16 instantiations of gemm_kernel (gemm_kernel.cuh): nn.Linear forward shapes the lean kernels refuse, (ROW, COL) input gradients, (COL, COL) weight gradients / batched attention products
-#include "gemm_kernel.cuh"
+// bf16 instantiations of gemm_kernel (gemm_kernel.hpp): nn.Linear forward shapes the lean kernels refuse, (ROW, COL) input gradients, (COL, COL) weight gradients / batched attention products
+#include "gemm_kernel.hpp"
 
 int countr_gemm_bf16_a(const countr_gemm_args& a, int ma, int mb, hipStream_t s) {
   if (ma == COUNTR_OP_ROW && mb == COUNTR_OP_ROW) return launch<bf16_t, COUNTR_OP_ROW, COUNTR_OP_ROW>(a, s);

@@ -1,5 +1,5 @@
-// bf16 instantiations of gemm_kernel (gemm_kernel.cuh): (COL, ROW), the 3x3 convolutions' forward / dgrad (IM2ROW, ROW) and weight gradient (COL, IM2COL) on the shapes the lean kernels refuse
-#include "gemm_kernel.cuh"
+// bf16 instantiations of gemm_kernel (gemm_kernel.hpp): (COL, ROW), the 3x3 convolutions' forward / dgrad (IM2ROW, ROW) and weight gradient (COL, IM2COL) on the shapes the lean kernels refuse
+#include "gemm_kernel.hpp"
 
 int countr_gemm_bf16_b(const countr_gemm_args& a, int ma, int mb, hipStream_t s) {
   if (ma == COUNTR_OP_COL && mb == COUNTR_OP_ROW) return launch<bf16_t, COUNTR_OP_COL, COUNTR_OP_ROW>(a, s);

@@ -1,5 +1,5 @@
-// fp32 (parity mode) instantiations of gemm_kernel (gemm_kernel.cuh): exact v_mfma_f32_16x16x4_f32 chains, all six operand-mode pairs
-#include "gemm_kernel.cuh"
+// fp32 (parity mode) instantiations of gemm_kernel (gemm_kernel.hpp): exact v_mfma_f32_16x16x4_f32 chains, all six operand-mode pairs
+#include "gemm_kernel.hpp"
 
 int countr_gemm_f32(const countr_gemm_args& a, int ma, int mb, hipStream_t s) {
   if (ma == COUNTR_OP_ROW && mb == COUNTR_OP_ROW) return launch<float, COUNTR_OP_ROW, COUNTR_OP_ROW>(a, s);

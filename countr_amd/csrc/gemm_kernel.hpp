@@ -1,8 +1,8 @@
-// gemm_kernel.cuh -- the generic MFMA GEMM kernel template of gemm.hip and its tile-shape selection, shared by the translation units
+// gemm_kernel.hpp -- the generic MFMA GEMM kernel template of gemm.hip and its tile-shape selection, shared by the translation units
 // that instantiate it (gemm_bf16_a.hip, gemm_bf16_b.hip, gemm_f32.hip: one ~19 000-instruction kernel per (dtype, operand modes,
 // variant) -- 19 of them -- compiled in parallel instead of in one 97-second unit).
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 #include <type_traits>
 #include <utility>
 #include "../../include/countr_hip.h"
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
     // profiles/r2_gemm_conv192_pmc.txt.)
     // ... round 4: with the faster kernels of linear.hip / gemm256.hip it does pay in the step (4.62 -> 4.58 ms), and this kernel follows
     // their order on unsplit convolutions so that a sample's result does not depend on which kernel its batch size selects
-    // (common.cuh: COUNTR_CONV_CHUNK_MAJOR)
+    // (common.hpp: COUNTR_CONV_CHUNK_MAJOR)
     const bool chunk_major = COUNTR_CONV_CHUNK_MAJOR && MA == COUNTR_OP_IM2ROW && kstart == 0 && kend == g.K && g.K == 9 * g.Cin && ntiles <= 79;
     auto ktile = [&](int t) {
       int tt = t + kskew; if (tt >= ntiles) tt -= ntiles;

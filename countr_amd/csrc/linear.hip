@@ -18,7 +18,7 @@
 // Launch forms: <NLD = 4> 4 compute + 4 loader waves, 3-stage LDS ring, one workgroup per CU (grids of <= 256 tiles);
 //               <NLD = 0> 4 waves that stage and multiply, 2 stages, two workgroups per CU (bigger grids).
 // Reference call sites: models_crossvit.py:62,65 (Mlp), :84,92 (Attention qkv / proj), :115-127 (CrossAttention), models_mae_cross.py:152.
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -85,7 +85,7 @@ template <int PENDING> __device__ __forceinline__ void frag_wait5(bf16x8_t (&f)[
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f2) : "n"(PENDING));
 }
 
-// packed form of common.cuh's gelu_fast (same operations on fp32 pairs: bit-identical results)
+// packed form of common.hpp's gelu_fast (same operations on fp32 pairs: bit-identical results)
 __device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
   const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -8.f, 8.f), __builtin_amdgcn_fmed3f(x[1], -8.f, 8.f)};
   const f32x2_t x2 = xc * xc;
@@ -612,10 +612,10 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   if ((a->lda % 8) || (a->ldb % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2) & 15)) return 1;
   if ((int64_t)128 * a->lda * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll || (int64_t)256 * a->ldb * 2 + (int64_t)a->K * 2 >= (int64_t)0x7f000000ll) return 1;   // per-tile descriptor offsets
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
-  static float* zero_bias = nullptr;     // no bias (input gradients): the epilogue adds a vector of zeros
+  const float* zero_bias = nullptr;     // no bias (input gradients): the epilogue adds the per-device vector of zeros (countr_init)
   if (!a->bias) {
-    if (a->N > 8192) return 1;
-    if (!zero_bias && (hipMalloc(&zero_bias, 8192 * sizeof(float)) != hipSuccess || hipMemset(zero_bias, 0, 8192 * sizeof(float)) != hipSuccess)) { zero_bias = nullptr; return 1; }
+    if (a->N > COUNTR_ZERO_VEC_FLOATS) return 1;
+    if (!(zero_bias = countr_zero_vec(a->N))) return -1;
   }
   int epi;
   if (a->out_bf16) {
@@ -703,16 +703,14 @@ int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0) {
   if (a->C2) return 1;
 #endif
   if (a->partial || a->nbatch > 1 || a->alpha != 1.0f || a->rowsum_partial || a->resid || a->act != COUNTR_ACT_NONE || !a->out_bf16) return 1;
-  if (a->M < 1 || (a->N % 128) || (a->Cin % 64) || a->K != 9 * a->Cin || a->H < 2 || a->W < 2) return 1;
+  if (a->M < 1 || (a->N % 128) || (a->Cin % 64) || a->Cin > 512 || a->K != 9 * a->Cin || a->H < 2 || a->W < 2) return 1;
   if ((a->ldb % 8) || (a->ldc % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15)) return 1;
   if ((int64_t)(a->M + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll || a->N > 4096) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
   const long tiles = (long)((a->M + 127) / 128) * (a->N / 128);
   if (tiles <= 256 && row0 == 0) return 1;     // small maps: the generic kernel's split-K / wave-specialised 128x128 forms
-  static float* zero_bias = nullptr;
-  if (!a->bias && !zero_bias) {
-    if (hipMalloc(&zero_bias, 4096 * sizeof(float)) != hipSuccess || hipMemset(zero_bias, 0, 4096 * sizeof(float)) != hipSuccess) { zero_bias = nullptr; return 1; }
-  }
+  const float* zero_bias = nullptr;
+  if (!a->bias && !(zero_bias = countr_zero_vec(a->N))) return -1;
   LinArgs g;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = nullptr; g.bias = a->bias ? a->bias : zero_bias; g.resid = nullptr;
 #ifdef LIN_STAMP

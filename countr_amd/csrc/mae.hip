@@ -1,6 +1,6 @@
 // MAE-pretraining specific kernels (reference models_mae_noct.py): row gather used for random masking / unshuffle and
 // their backward (:110-135, :163-170), and the all-patch pixel MSE with on-the-fly patchify (:84-96, :181-198).
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)

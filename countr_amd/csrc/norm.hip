@@ -2,7 +2,7 @@
 //   LayerNorm fwd/bwd      : nn.LayerNorm(eps=1e-6)          models_mae_cross.py:146,182; models_crossvit.py:153-155
 //   GroupNorm(8)+ReLU      : decode_head*                     models_mae_cross.py:80-100   (NHWC maps)
 //   InstanceNorm+ReLU+pool : decoder_proj1-4                  models_mae_cross.py:47-71    (NHWC maps)
-#include "common.cuh"
+#include "common.hpp"
 #include <stdlib.h>
 #include "../../include/countr_hip.h"
 

@@ -5,7 +5,7 @@
 //   countr_window_gather  cuts the windows of several images straight into the engine's input batch [nw, 3, H, 384]
 //   countr_window_blend   stitches the densities of n images of one width (+ per-image sums, the predicted counts x 60)
 // fp32 in / out like the reference's tensors; results equal the torch slicing / blending bit for bit (x / 2 is exact).
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/countr_hip.h"
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)

@@ -519,12 +519,17 @@ class Engine:
         k-slab, 128-byte pieces two k-tiles ahead, pays the HBM latency on every k-tile -- the encoder's fc2 took 38.7 us in the step
         against 28.7 us with the panel resident (tools/bench_chain.py); with the hints fc2 runs at 29.4, proj 16.5 -> 15, qkv 23 ->
         20.7 us, step 4.83 -> 4.70 ms (A/B inside one gpurun call).  A side-lane warm-up kernel gave the same kernel gains and lost them
-        again to the fork / join gaps and to the GEMM it ran beside (4.80 vs 4.68 ms).  Results never change."""
+        again to the fork / join gaps and to the GEMM it ran beside (4.80 vs 4.68 ms).  Results never change.
+        `ops` must be in EXECUTION order of one lane; a hint never crosses a fork / lane / join marker (the launch in front of one may
+        run beside or after the consumer: wasted bandwidth)."""
         if not self.warm_weights or self.code != BF16 or self._sizing:
             return
         bufs = self._weight_buffers()
         nxt = None
         for fn, args, a in reversed(ops):
+            if fn is None and args and args[0] in ("fork", "lane", "join", "xfork", "xlane", "xjoin"):
+                nxt = None
+                continue
             if fn is not self.L.countr_gemm or a is None:
                 continue
             dtype, ma, mb = args[1], args[2], args[3]
@@ -1019,7 +1024,11 @@ class Engine:
             mark = lambda *a: (None, a, None)
             p.fwd_par = ([mark("xfork"), mark("xlane", 1)] + p.fwd[ex[0]:ex[1]] + [mark("xlane", 0)] + p.fwd[:ex[0]] + [mark("xjoin")]
                          + p.fwd[ex[1]:])
-        self._auto_warm(p.fwd)
+        if ex is None:
+            self._auto_warm(p.fwd)
+        else:     # per lane, in the order fwd_par executes: the encoder's last launch warms the first decoder-block panel (not the exemplar
+            self._auto_warm(p.fwd[:ex[0]] + p.fwd[ex[1]:])      # CNN's, which ran beside it), the exemplar lane keeps its hints to itself
+            self._auto_warm(p.fwd[ex[0]:ex[1]])
         if not train:
             return p
 

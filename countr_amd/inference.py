@@ -62,6 +62,9 @@ def blend_windows_batched(outputs, starts, width, height=384):
     return dm
 
 
+MAX_BLEND_WINDOWS = 16     # csrc/window.hip: MAX_STARTS
+
+
 @torch.no_grad()
 def _native_maps(model, images, boxes, shot_num, max_batch, want_sums):
     """density_maps through the two window kernels of the C ABI (countr_window_gather / countr_window_blend: windows cut straight into
@@ -73,7 +76,9 @@ def _native_maps(model, images, boxes, shot_num, max_batch, want_sums):
         return None
     h = images[0].shape[-2]
     plan = [(i, s) for i, im in enumerate(images) for s in window_starts(im.shape[-1])]
+    # (countr_window_blend takes at most MAX_BLEND_WINDOWS window positions per image: wider panoramas go to the torch path below)
     if (not plan or len(plan) > min(max_batch, 64) or h != getattr(model, "img_size", 384)
+            or any(len(window_starts(im.shape[-1])) > MAX_BLEND_WINDOWS for im in images)
             or any((not im.is_cuda) or im.dtype != torch.float32 or im.dim() != 4 or im.shape[0] != 1 or im.shape[1] != 3 or im.shape[-2] != h
                    or not im.is_contiguous() for im in images)):
         return None

@@ -54,6 +54,22 @@ class _GraphStep:
     def _make_sync(self, process_group):
         return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
 
+    def on_stream(self):
+        """Context manager for a training loop that wants all of its device work on the step's stream (no cross-queue hand-over per
+        step): on entry the step's stream waits for everything the caller's stream holds (model build, weight casts, LayerNorm-fold
+        repack, accumulators allocated outside), inside `torch.cuda.current_stream()` IS the step's stream, on exit the caller's stream
+        waits for the step's.  (A bare `with torch.cuda.stream(step.stream)` lacks the first edge: load()'s wait is then a self-wait.)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            outer = torch.cuda.current_stream(self.eng.device)
+            self.stream.wait_stream(outer)
+            with torch.cuda.stream(self.stream):
+                yield self.stream
+            outer.wait_stream(self.stream)
+        return cm()
+
     def _to_device(self, tensors):
         """Host batches (the DataLoader's pinned tensors) go host -> device on a dedicated copy stream into staging buffers, so the
         PCIe transfer of batch t+1 overlaps the compute of step t; the step stream then only does device-to-device copies into
@@ -544,8 +560,10 @@ class FinetuneStep(_GraphStep):
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
         """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream.  Dense fp32 device tensors of
-        the buffers' shapes are copied by ONE launch that step() issues together with the AdamW scalars (the sources are kept alive
-        until then); anything else is copied here, tensor by tensor."""
+        the buffers' shapes are copied by ONE launch that step() issues together with the AdamW scalars: the sources are kept alive
+        until then and MUST NOT BE MODIFIED between load() and the return of the following step() (a persistent input buffer refilled in
+        place in between would change the batch that trains); a load() that is superseded by another load() drops its references.
+        Anything else is copied here, tensor by tensor."""
         cur = torch.cuda.current_stream(self.eng.device)
         self.stream.wait_stream(cur)           # producers of the inputs ran on the caller's stream
         src = (imgs, boxes, gt, mask)

@@ -95,8 +95,8 @@ typedef struct countr_gemm_args {
                            countr_gemm_rowsum_slabs() of this launch (the lean convolution weight gradient deals the bias-gradient
                            work over more waves and writes [rowsum_slabs][M]; the sum over ALL slabs is the bias gradient)        */
   /* Cache warm-up hint (ABI 3): a read-only range -- normally the B operand of the NEXT launch on the stream -- that spare workgroups
-   * of this launch read once and discard (16-byte aligned pointer and size).  Honoured by the bf16 (ROW, ROW) kernels when the grid
-   * leaves CUs idle (fewer than 256 tiles); ignored otherwise.  Never changes a result.  Why: the frozen encoder's weight panels
+   * of this launch read once and discard (16-byte aligned pointer and size).  Honoured by the bf16 (ROW, ROW) kernels: the CUs a grid of
+   * fewer than 256 tiles leaves idle (up to 64 workgroups, a multiple of 8), or 32 extra workgroups in front of a bigger grid.  Never changes a result.  Why: the frozen encoder's weight panels
    * (blocks.i.attn / mlp, models_mae_cross.py:32-34,141-145) are cold in every step -- ~5 GB stream through the 256-MB memory-side cache
    * between two uses -- and a single-round GEMM that walks a cold [N][K] panel k-slab by k-slab pays the HBM latency on every k-tile
    * (fc2: 38.7 us in the step, 28.7 us with the panel resident: tools/bench_chain.py). */

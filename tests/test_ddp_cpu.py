@@ -150,6 +150,104 @@ def _worker_prs(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_w8(rank, world, port, steps, out):
+    """BASELINE config 3's world (8 ranks, FSC_finetune_cross.py:178-183,230) on the real model's bucket layout: per-rank shot draws,
+    the trainer's own window / skip / AdamW set logic (the unbound methods on a stand-in object: the logic is host-only), zero-fill of
+    the conditional bucket a rank has no gradient for, four-bucket all-reduce with the first two started early -- exact integer-valued
+    gradients, so the reduced buffer must EQUAL the sum over the eight ranks whatever order gloo adds in."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from countr_amd.engine import ParamLayout
+        from countr_amd.parallel import GradSync, rank_shot_nums, shard_batch
+        from countr_amd.trainer import FinetuneStep, _GraphStep
+        torch.set_num_threads(1)
+        meta = json.load(open(os.path.join(G, "meta.json")))
+        lay = ParamLayout([(a, tuple(b)) for a, b in meta["schema"]])
+        n = lay.n_train
+        buckets = [lay.bucket_range(b) for b in range(4)]
+        assert buckets[0][0] == 0 and buckets[3][1] == n and all(buckets[i][1] == buckets[i + 1][0] for i in range(3))
+        assert [e - s for s, e in buckets][3] == 512                        # shot_token alone
+        eng = types.SimpleNamespace(opt_seen=set())
+        me = types.SimpleNamespace(per_rank=True, _touched=set(), _touched_any=set(), eng=eng)
+
+        def grad_of(r, step, shots):
+            g = torch.randint(-8, 9, (n,), generator=torch.Generator().manual_seed(1000 * step + r), dtype=torch.int32).float()
+            unused = 2 if shots[r] == 0 else 3                             # the conditional bucket rank r's backward does not write
+            g[buckets[unused][0]:buckets[unused][1]] = float("nan")         # ... holds stale content
+            return g
+        flat = torch.zeros(n)
+        sync = GradSync(flat, None, None, buckets=buckets)
+        assert sync.world == world and sync.comm and sync.grad_scale == 1.0 / world
+        log = []
+        for step in steps:
+            shots = rank_shot_nums(step, world, seed=3)
+            flat.copy_(grad_of(rank, step, shots))
+            me._touched = {3 if shots[rank] == 0 else 2}                    # FinetuneStep._phases
+            me._touched_any = {3 if s_ == 0 else 2 for s_ in shots}         # FinetuneStep.step(shots_all=...)
+            touched, zfill = _GraphStep._window_sets(me)
+            cskip = FinetuneStep._comm_skip(me, touched)
+            skip, zero = FinetuneStep._adam_sets(me, touched)
+            for b in zfill:                                                 # _zero_buckets
+                flat[buckets[b][0]:buckets[b][1]] = 0
+            sync.start(0); sync.start(1)
+            sync.finish(skip=cskip)
+            want = torch.zeros(n)
+            for r in range(world):
+                g = grad_of(r, step, shots)
+                unused = 2 if shots[r] == 0 else 3
+                if unused in touched:
+                    g[buckets[unused][0]:buckets[unused][1]] = 0
+                want += torch.nan_to_num(g, nan=0.0) if unused in touched else g
+            for b in range(4):
+                lo, hi = buckets[b]
+                if b in cskip:                                              # nobody has a gradient: not reduced, never read
+                    assert torch.isnan(flat[lo:hi]).all(), (step, b)
+                    assert b in skip or b in zero
+                else:
+                    assert torch.equal(flat[lo:hi], want[lo:hi]), (step, b)
+            log.append((step, tuple(shots), tuple(sorted(touched)), tuple(zfill), tuple(cskip), tuple(skip), tuple(zero), sorted(eng.opt_seen)))
+        every = [None] * world
+        dist.all_gather_object(every, [(a[0], a[1], a[2], a[4], a[5], a[6], a[7]) for a in log])     # all but the rank's own zero-fill set
+        assert all(e_ == every[0] for e_ in every)
+        parts = [shard_batch(64, r, world) for r in range(world)]           # config 3: global batch 64 -> 8 per rank, contiguous, complete
+        assert parts == [(8 * r, 8 * r + 8) for r in range(world)]
+        out.put((rank, "ok", log if rank == 0 else None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:]), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_buckets_per_rank_shots_and_zero_fill():
+    from countr_amd.parallel import rank_shot_nums
+    world = 8
+    draws = {t: rank_shot_nums(t, world, seed=3) for t in range(400)}
+    no_zero = [t for t, d in draws.items() if all(s_ > 0 for s_ in d)]      # nobody uses shot_token: bucket 3 skipped by all
+    mixed = [t for t, d in draws.items() if 0 in d and any(s_ > 0 for s_ in d)]
+    assert no_zero and mixed
+    # first a step where no rank draws 0 (shot_token: no gradient anywhere, never seen -> AdamW skips it), then mixed steps (both
+    # conditional buckets reduced, zero-filled on the ranks without), then the no-zero step again (shot_token now stepped with g = 0)
+    steps = [no_zero[0], mixed[0], mixed[1], no_zero[0]]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_w8, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted((r, st) for r, st, _ in res) == [(r, "ok") for r in range(world)], res
+    log = [l for _r, _s, l in res if l is not None][0]
+    assert log[0][4] == (3,) and log[0][5] == (3,) and log[0][6] == ()      # step 1: bucket 3 neither reduced nor stepped
+    assert log[1][2] == (2, 3) and log[1][4] == () and log[1][5] == ()      # mixed: everything reduced and stepped
+    assert log[3][4] == (3,) and log[3][5] == () and log[3][6] == (3,)      # later no-zero step: not reduced, stepped with g = 0 (torch 1.13 zero_grad)
+
+
 def test_per_rank_shot_num_zero_filled_buckets_sum_to_the_oracle_gradients():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

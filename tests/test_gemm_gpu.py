@@ -1009,3 +1009,71 @@ def test_prefetch_hint_changes_nothing(hip, M, N, K, epi):
     if resid is not None:
         ref = ref + resid.double()
     assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item() + 3e-5
+
+
+_FIRST_CALL_CHILD = r'''
+import ctypes as C, sys, threading, torch
+from countr_amd import _lib
+L = _lib.lib()
+M, N, K = 512, 256, 128
+g = torch.Generator().manual_seed(5)
+A = (torch.rand(M, K, generator=g) * 2 - 1).cuda().bfloat16()
+W = (torch.rand(N, K, generator=g) * 2 - 1).cuda().bfloat16()
+ref = A.double() @ W.double().t()
+def args(out):
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+    a.lda, a.ldb, a.ldc = K, K, N
+    a.M, a.N, a.K = M, N, K
+    a.alpha = 1.0; a.out_bf16 = 1; a.nbatch = 1; a.nb1 = 1; a.splitk = 1      # no bias: the epilogue adds the per-device zero vector
+    return a
+mode = sys.argv[1]
+if mode == "noinit":
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    rc = L.countr_gemm(C.byref(args(out)), 1, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"countr_init" in L.countr_last_error(), (rc, L.countr_last_error())
+elif mode == "threads":
+    outs = [torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    bar = threading.Barrier(2)
+    rcs = [None, None]
+    def run(i):
+        bar.wait()
+        r0 = L.countr_init(0)                                              # both threads race through the one-time allocation
+        rcs[i] = (r0, L.countr_gemm(C.byref(args(outs[i])), 1, 0, 0, C.c_void_p(streams[i].cuda_stream)))
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert rcs == [(0, 0), (0, 0)], rcs
+    for o in outs:
+        assert (o.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert torch.equal(outs[0], outs[1])
+elif mode == "capture":
+    _lib.check(L.countr_init(0), "init")
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    a = args(out)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):                                             # the process's FIRST bias-less launch happens under capture
+        _lib.check(L.countr_gemm(C.byref(a), 1, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    torch.cuda.synchronize()
+    assert out.abs().max().item() == 0                                     # captured, not run
+    gr.replay(); torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+print("child ok")
+'''
+
+
+@pytest.mark.parametrize("mode", ["noinit", "threads", "capture"])
+def test_bias_less_launch_first_call(mode):
+    """ABI conventions (SURVEY 8b): no allocation inside a launch, no mutable global state after countr_init, thread-safe.  Bias-less
+    launches of linear.hip / gemm256.hip read a per-device vector of zeros that countr_init allocates (rounds 3-4 allocated it lazily
+    inside the first launch).  Fresh process each: (noinit) a launch without countr_init fails with a message instead of allocating;
+    (threads) two threads race countr_init + their first launch on two streams; (capture) the first launch of the process is recorded
+    into a hipGraph."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FIRST_CALL_CHILD, mode], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and "child ok" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])

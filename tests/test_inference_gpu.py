@@ -172,3 +172,28 @@ def test_config5_batch_of_32_windows(precision, fp32_model):
         p1, d1 = inference.count_image(m, samples, bx, S, pos=pos)
         assert dm.shape == d1.shape and abs(pred - p1) <= 1e-3 * max(abs(p1), 1.0)
     assert float(res[4][1].abs().sum()) == 0.0      # 300 px wide: no window, all-zero map
+
+
+@pytest.mark.gpu
+def test_panorama_with_more_than_16_windows(fp32_model):
+    """A 2432-px-wide image has 17 window positions -- more than countr_window_blend takes (MAX_STARTS 16 in csrc/window.hip); the
+    reference loop has no such limit (FSC_test_cross(few-shot).py:322-351).  The call must take the torch stitch path and give the
+    sequential blend of the 17 single-window forwards (round 4 ran the forward and then raised CountrError)."""
+    from countr_amd import inference
+    m = fp32_model
+    w = 384 + 128 * 16
+    st = inference.window_starts(w)
+    assert len(st) == 17 > inference.MAX_BLEND_WINDOWS
+    img = torch.from_numpy(np.random.RandomState(5).uniform(0, 1, size=(1, 3, 384, w)).astype(np.float32)).cuda()
+    empty = torch.zeros(1, 0, device="cuda")
+    assert inference._native_maps(m, [img], [empty], 0, 32, False) is None
+    (dm,), (s_,) = inference.density_maps(m, [img], [empty], 0, max_batch=32, return_sums=True)
+    with torch.no_grad():
+        wins = torch.stack([m(img[:, :, :, a:a + 384], empty, 0)[0].clone() for a in st])
+    ref = inference.blend_windows(wins, st, w)
+    assert dm.shape == (384, w)
+    assert (dm - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert abs(float(s_) - ref.double().sum().item()) <= 1e-4 * ref.double().abs().sum().item()
+    # 16 windows (width 2304) still go through the window kernels
+    img16 = img[:, :, :, :2304].contiguous()
+    assert len(inference.window_starts(2304)) == 16 and inference._native_maps(m, [img16], [empty], 0, 32, False) is not None

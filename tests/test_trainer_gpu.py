@@ -323,3 +323,75 @@ def test_gradient_accumulation_matches_torch_adamw(use_graph):
         ref.step()
         check_params(m, ref, lr, w, "accum")
     assert step.eng.group_steps == [3, 3, 3]
+
+
+def check_step_against_oracle(step, m, cur, batch, S, sums, model_name="mae_vit_base_patch16"):
+    """One FinetuneStep result (loss / counts in `sums`, gradients in the step's flat buffer) against the oracle evaluated at `cur` --
+    the parameters the engine held BEFORE the step.  bf16 bars = tests/test_model_gpu.py::test_bf16_gradients_close_to_oracle (measured
+    values in profiles/r3_bf16_gradient_quality.txt).  Returns the worst (1 - cos, |ratio - 1|) seen outside the exemplar CNN."""
+    imgs, boxes, gt, mask = batch
+    B = imgs.shape[0]
+    out, rloss, rg = R.loss_and_grads(cur, imgs, boxes, gt, mask, S, model_name)
+    loss = sums[0].item()
+    assert abs(loss - rloss.item()) <= 1e-2 * abs(rloss.item()), (S, loss, rloss.item())
+    rc = R.counts(out).numpy()
+    cnt = sums[1:1 + B].cpu().numpy()
+    assert (np.abs(cnt - rc) / np.abs(rc)).max() < (6e-2 if S == 0 else 1e-2), (S, cnt, rc)
+    gtc = sums[1 + B:1 + 2 * B].cpu().numpy()
+    assert np.abs(gtc - gt.reshape(B, -1).sum(1) / 60).max() < 1e-2
+    checked, worst = 0, (0.0, 0.0)
+    for k, ref in rg.items():
+        if ref is None:
+            continue
+        ref = ref.double()
+        if ref.norm() < 1e-3:
+            continue
+        got = step.eng.gview(k).detach().cpu().double()
+        cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
+        ratio = (got.norm() / ref.norm()).item()
+        if S == 0:
+            assert cos > 0.985 and 0.78 < ratio < 1.02, (S, k, cos, ratio)
+        elif k.startswith("decoder_proj"):
+            assert cos > 0.97 and abs(ratio - 1) < 0.02, (S, k, cos, ratio)
+        else:
+            assert cos > 0.999 and abs(ratio - 1) < 0.015, (S, k, cos, ratio)
+            worst = (max(worst[0], 1 - cos), max(worst[1], abs(ratio - 1)))
+        checked += 1
+    assert checked >= (50 if S == 0 else 55), checked
+    return worst
+
+
+def test_finetune_step_at_the_real_config_matches_oracle():
+    """The BENCHMARKED object at its own size (BASELINE config 2; FSC_finetune_cross.py:286-316): FinetuneStep on mae_vit_base_patch16,
+    bf16, B = 8, use_graph=True (side lanes, fused loss, grouped weight gradients, fused AdamW) over the shot schedule [3, 0, 1, 3, 3, 0].
+    A graph key = (shot_num, AdamW skip / zero sets): steps 1-4 each meet a new key (run eagerly, then captured), steps 5 and 6 REPLAY
+    the graphs steps 4 and 2 captured, on parameters the fused AdamW has moved since.  Every step is compared with
+    the oracle evaluated at the engine's own parameters in front of it: loss to 1e-2, counts to 1 % (6 % at shot_num 0: module
+    docstring of test_model_gpu.py), every trainable tensor's gradient (read from the step's flat buffer) by direction and norm."""
+    import models_mae_cross as mm
+    from countr_amd.trainer import FinetuneStep
+    name = "mae_vit_base_patch16"
+    m = mm.__dict__[name](norm_pix_loss=False, precision="bf16")
+    sd = W.make_state_dict(name, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to("cuda").train()
+    B = 8
+    step = FinetuneStep(m, batch=B, lr=1e-5, weight_decay=0.05, use_graph=True)
+    torch.set_num_threads(min(__import__("os").cpu_count(), 32))
+    before = None
+    for it, S in enumerate([3, 0, 1, 3, 3, 0]):
+        batch = W.make_inputs(batch=B, shots=3, seed=80 + it)
+        ngraphs = len(step.graphs)
+        cur = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+        before = before or cur
+        with step.on_stream():                               # as bench.py and the CLI drive it
+            step.load(*(torch.from_numpy(a).cuda() for a in batch), S)
+            sums = step.step(S).clone()
+        torch.cuda.synchronize()
+        assert len(step.graphs) == (ngraphs + 1 if it < 4 else 4), (it, len(step.graphs))      # steps 5, 6: pure replays
+        worst = check_step_against_oracle(step, m, cur, batch, S, sums, name)
+        print("step", it, "shot_num", S, "worst 1-cos %.2e, |norm ratio - 1| %.2e" % worst)
+    after = m.state_dict()
+    moved = sum(float((after[k].detach().float().cpu() - torch.from_numpy(before[k])).abs().max()) > 0 for k in before
+                if k.startswith(("decoder", "decode_head", "shot_token")) and "pos_embed" not in k)
+    assert moved >= 70
