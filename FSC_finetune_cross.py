@@ -89,7 +89,7 @@ def main(args):
         args.lr = args.blr * eff_batch / 256     # :218-221
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95),
-                        accum_iter=args.accum_iter, per_rank_shot=args.per_rank_shot)
+                        accum_iter=args.accum_iter, per_rank_shot=args.per_rank_shot, mask_seed=seed)   # seed = args.seed + rank (:168)
     if ckpt is not None and args.do_resume and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:415: all three, else skipped
         # (raises when the entry EXISTS and fits neither this model's torch.optim.AdamW layout nor the older flat form: continuing late
         # in the LR schedule with zeroed moments would be a silent restart of the bias correction)
@@ -114,7 +114,6 @@ def main(args):
             print("FSC147 not found under %s: training on synthetic batches" % args.data_path)
         n_iter = args.synthetic_steps if args.synthetic_steps > 0 else 50
         n_val = max(1, n_iter // 4)
-    loss_mask_gen = torch.Generator(device=device).manual_seed(seed)
     # mosaics only come out of the augmented loader: without it no rank ever bans shot_num 0 and there is nothing to agree on
     flag_group = (torch.distributed.new_group(backend="gloo") if misc.get_world_size() > 1 and loader is not None and args.do_aug
                   else None)
@@ -137,7 +136,7 @@ def main(args):
                 if it_data is not None:
                     imgs, gt, _n, boxes, _pos, m_flag, _ids = next(it_data)
                     # loss mask: Bernoulli(0.8) per pixel, one mask per batch (FSC_finetune_cross.py:290-292)
-                    mask = (torch.rand(384, 384, device=device, generator=loss_mask_gen) < 0.8).float()
+                    mask = None      # drawn by the step itself (FinetuneStep(mask_seed=seed): Philox stream keyed by seed + rank)
                     # host tensors go straight to load(): it stages them over PCIe on a copy stream while the previous step computes
                     mosaic = int(torch.as_tensor(m_flag).sum().item()) != 0
                 else:

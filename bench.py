@@ -516,22 +516,21 @@ def main():
     model = models_mae_cross.__dict__["mae_vit_base_patch16"](norm_pix_loss=False, precision=args.precision)
     model.to(dev).train()
     B = args.batch
-    step = FinetuneStep(model, batch=B, lr=1e-5, weight_decay=0.05, use_graph=not args.no_graph, process_group=None)
+    step = FinetuneStep(model, batch=B, lr=1e-5, weight_decay=0.05, use_graph=not args.no_graph, process_group=None, mask_seed=1234 + rank)
     # device-resident synthetic batches (inputs are in HBM when the timed region starts); every timed step stages a batch into the
-    # plan's input buffers (device-to-device) and draws a fresh Bernoulli(0.8) loss mask, as the reference loop does per iteration
+    # plan's input buffers (device-to-device) and draws a fresh Bernoulli(0.8) loss mask, as the reference loop does per iteration --
+    # both inside the step's graph (its prologue kernel: trainer._Prologue)
     NB = 4
     batches = [make_batch(B, shots=3, seed=rank * NB + k, device=dev) for k in range(NB)]
     if args.host_inputs:
         batches = [tuple(t.cpu().pin_memory() if torch.is_tensor(t) else t for t in b) for b in batches]
-    mgen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     def one(k, S):
         imgs, boxes, gt, _ = batches[k % NB]
-        # the loop's own device work (the per-iteration mask draw) runs on the step's stream (callers enter step.on_stream() around
-        # their loop), as everything does on ONE stream in the reference's loop: from another stream every step pays two cross-queue
-        # hand-overs (inputs ready -> step, step done -> caller)
-        mask = torch.empty(384, 384, device=dev).bernoulli_(0.8, generator=mgen)
-        step.load(imgs, boxes, gt, mask, S)
+        # the loop runs on the step's stream (callers enter step.on_stream() around their loop), as everything does on ONE stream in
+        # the reference's loop: from another stream every step pays two cross-queue hand-overs (inputs ready -> step, step done -> caller).
+        # mask=None: a fresh Bernoulli(0.8) mask per step (FSC_finetune_cross.py:290-292), drawn by the step itself
+        step.load(imgs, boxes, gt, None, S)
         return step.step(S)
 
     def timed(shots):
@@ -621,7 +620,7 @@ def main():
             "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "inputs": "pinned host memory, copied over PCIe every step" if args.host_inputs else "resident in HBM",
             "step_tflops": GF_STEP_PER_IMG * ips / 1e12,
-            "timed_region": "per step: device-to-device staging of a batch + fresh loss mask + fwd + loss + decoder bwd + grad all-reduce + AdamW",
+            "timed_region": "per step (ONE hipGraph replay at N = 1): device-to-device staging of a batch + fresh loss mask + fwd + loss + decoder bwd + grad all-reduce + AdamW",
             "shot_mix": {"images_per_sec": world * B * args.steps / dt_mix, "ms_per_step": 1e3 * dt_mix / args.steps,
                          "shot_nums": "uniform 0..3 per step (%s)" % "".join(str(x) for x in mix[:32])},
         }

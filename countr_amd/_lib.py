@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
@@ -107,6 +107,9 @@ _SIGS = {
     "countr_colsum": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "countr_cast_permute": [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "countr_copy_multi": [_i, _vp, _vp, _vp, _vp],
+    "countr_step_prologue_record_bytes": [],
+    "countr_step_prologue_copy_blocks": [],
+    "countr_step_prologue": [_vp, _i, _vp, _vp, _vp, _i, _vp],
     "countr_gather_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "countr_mae_indices": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "countr_patch_mse_workspace_floats": [_i, _i, _i, _i],

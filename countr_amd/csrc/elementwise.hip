@@ -664,6 +664,94 @@ extern "C" int countr_copy_multi(int n, const void* const* src, void* const* dst
   COUNTR_LAUNCH_CHECK("countr_copy_multi");
 }
 
+// ---- step prologue: everything an optimisation step needs from the host, as ONE kernel node at the head of the step's hipGraph ----
+// (FSC_finetune_cross.py:271-295: lr for the iteration, the batch hand-over, the Bernoulli(0.8) loss mask drawn per iteration.)
+// Between two graph replays every separate launch / copy costs a queue hand-over (round 4: mask draw + staging launch = 3.6 + 10.6 us
+// of work inside ~160 us of idle GPU).  The arguments of a captured node are frozen, so what changes per step travels through a RING
+// of 256-byte records in pinned host memory that the kernel reads directly: record index = *counter % slots, where counter is a
+// device int64 the LAST block of every execution increments (device-scope ticket) -- eager launches and replays alike, so the host
+// mirrors it by counting executions and fills record (executions % slots) before each one.
+struct PrologueRec {               // 256 bytes, host-written (countr_amd/trainer.py::_Prologue)
+  unsigned long long src[6], dst[6];
+  long long n16[6];
+  int first[6];                    // first copy block of entry i (blocks [0, COPY_BLOCKS) are dealt by the host in proportion to the bytes)
+  int n, draw_mask;
+  unsigned int key[2], ctr[2];     // Philox4x32-10 key / high counter words (seed, step)
+  float hyper[8];                  // AdamW scalars {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
+  unsigned int mask_thr;           // mask = 1 where the 32-bit draw < mask_thr (= floor(p 2^32))
+  unsigned int pad[7];
+};
+static_assert(sizeof(PrologueRec) == 256, "PrologueRec layout is part of the ABI");
+constexpr int PRO_COPY_BLOCKS = 1152, PRO_MASK_BLOCKS = 96;
+
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0, unsigned int k1,
+                                              unsigned int out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned int)p1; c3 = (unsigned int)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueRec* __restrict__ ring, int slots, long long* counter, float* hyper_dev,
+                                                            float* mask, int mask_n4) {
+  __shared__ PrologueRec rec;
+  const long long seq = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 16) reinterpret_cast<uint4*>(&rec)[threadIdx.x] = reinterpret_cast<const uint4*>(ring + (seq % slots))[threadIdx.x];
+  __syncthreads();
+  const int b = blockIdx.x;
+  if (b < PRO_COPY_BLOCKS) {
+    if (b == 0 && threadIdx.x < 8) hyper_dev[threadIdx.x] = rec.hyper[threadIdx.x];
+    int e = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) e += (i < rec.n && b >= rec.first[i]) ? 1 : 0;
+    if (rec.n > 0) {
+      const int nb = (e + 1 < rec.n ? rec.first[e + 1] : PRO_COPY_BLOCKS) - rec.first[e];
+      const uint4* __restrict__ s = reinterpret_cast<const uint4*>(rec.src[e]);
+      uint4* __restrict__ d = reinterpret_cast<uint4*>(rec.dst[e]);
+      const long long n = rec.n16[e], stride = (long long)nb * 256 * 4;
+      for (long long i = ((long long)b - rec.first[e]) * 256 + threadIdx.x; i < n; i += stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) v[u] = s ? s[i + (long long)u * nb * 256] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + (long long)u * nb * 256 < n) d[i + (long long)u * nb * 256] = v[u];
+      }
+    }
+  } else if (rec.draw_mask) {      // element 4 g + j of the mask = word j of Philox(counter = (g, 0, ctr[0], ctr[1]), key) < mask_thr
+    for (int g = (b - PRO_COPY_BLOCKS) * 256 + threadIdx.x; g < mask_n4; g += PRO_MASK_BLOCKS * 256) {
+      unsigned int r[4];
+      philox4x32_10((unsigned int)g, 0u, rec.ctr[0], rec.ctr[1], rec.key[0], rec.key[1], r);
+      reinterpret_cast<float4*>(mask)[g] = float4{r[0] < rec.mask_thr ? 1.f : 0.f, r[1] < rec.mask_thr ? 1.f : 0.f,
+                                                  r[2] < rec.mask_thr ? 1.f : 0.f, r[3] < rec.mask_thr ? 1.f : 0.f};
+    }
+  }
+  // last block done -> the next execution reads the next record
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const long long t = __hip_atomic_fetch_add(counter + 1, 1ll, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (long long)gridDim.x - 1) {
+      __hip_atomic_store(counter + 1, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(counter, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+extern "C" int countr_step_prologue_record_bytes(void) { return (int)sizeof(PrologueRec); }
+extern "C" int countr_step_prologue_copy_blocks(void) { return PRO_COPY_BLOCKS; }
+extern "C" int countr_step_prologue(const void* ring, int slots, int64_t* counter, float* hyper_dev, float* mask, int mask_n, void* stream) {
+  if (!ring || slots < 1 || !counter || !hyper_dev || ((uintptr_t)ring & 15) || (mask && ((mask_n & 3) || ((uintptr_t)mask & 15)))) {
+    countr_set_error("countr_step_prologue: null / unaligned argument (mask_n % 4 == 0)"); return -1;
+  }
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(PRO_COPY_BLOCKS + (mask ? PRO_MASK_BLOCKS : 0)), dim3(256), 0, STREAM(stream),
+                     reinterpret_cast<const PrologueRec*>(ring), slots, reinterpret_cast<long long*>(counter), hyper_dev, mask, mask ? mask_n / 4 : 0);
+  COUNTR_LAUNCH_CHECK("countr_step_prologue");
+}
+
 extern "C" int countr_gelu_bwd(const void* dh, const void* pre, void* dpre, int64_t n, int dtype, void* stream) {
   if (!dh || !pre || !dpre || (n & 7)) { countr_set_error("countr_gelu_bwd: n must be a multiple of 8"); return -1; }
   const int nb = nblocks(n / 8, 256, 8192);

@@ -15,13 +15,91 @@ from . import _lib
 from .parallel import GradSync
 
 
+class _Prologue:
+    """Host side of countr_step_prologue (include/countr_hip.h): the per-iteration hand-over of an optimisation step -- staging copies
+    of the batch, the Bernoulli loss mask (FSC_finetune_cross.py:290-292) and the AdamW scalars -- as the FIRST NODE of the step's
+    captured graph, so that nothing is launched between two graph replays (round 4: a torch mask draw + a staging launch sat in
+    ~160 us of idle GPU there).  A captured node's arguments are frozen; what changes per step goes through a ring of 256-byte records
+    in pinned host memory.  Execution k (eager run or replay) reads record k % SLOTS -- the kernel counts its own executions on the
+    device, `seq` mirrors that count here -- so fill() writes record seq % SLOTS once the execution that last read it has finished
+    (an event per slot, SLOTS steps old: never a wait in practice)."""
+    SLOTS = 16
+
+    def __init__(self, eng, seed=0):
+        import numpy as np
+        self.eng = eng
+        L = eng.L
+        self.rb = int(L.countr_step_prologue_record_bytes())
+        self.nblk = int(L.countr_step_prologue_copy_blocks())
+        assert self.rb == 256
+        self.ring = torch.zeros(self.SLOTS * self.rb, dtype=torch.uint8).pin_memory()
+        self.view = self.ring.numpy()
+        self.counter = torch.zeros(2, dtype=torch.int64, device=eng.device)
+        self.seq = 0
+        self.events = [None] * self.SLOTS
+        self.hyper = np.zeros(8, np.float32)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.draws = 0                      # masks drawn so far = the Philox counter's high words (checkpointable)
+        self.keep = ()
+
+    def fill(self, pairs, draw_mask, p_keep=0.8, keep=()):
+        """pairs: [(src ptr or None, dst ptr, bytes)], at most 6, 16-byte aligned.  Writes the record the NEXT execution reads."""
+        import numpy as np
+        k = self.seq % self.SLOTS
+        ev = self.events[k]
+        if ev is not None:
+            ev.synchronize()
+        n = len(pairs)
+        assert n <= 6
+        rec = self.view[k * self.rb:(k + 1) * self.rb]
+        u64 = rec[0:144].view(np.uint64)
+        i32 = rec[144:176].view(np.int32)
+        u32 = rec[176:192].view(np.uint32)
+        tot = sum(b for _s, _d, b in pairs) or 1
+        first, used = [], 0
+        for i, (_s, _d, b) in enumerate(pairs):          # copy blocks in proportion to the bytes, at least one each
+            first.append(used)
+            used += max(1, min(self.nblk - used - (n - 1 - i), int(round(self.nblk * b / tot))))
+        for i in range(6):
+            s_, d_, b_ = pairs[i] if i < n else (0, 0, 0)
+            u64[i], u64[6 + i], u64[12 + i] = (s_ or 0), d_, b_ // 16
+            i32[i] = first[i] if i < n else self.nblk
+        i32[6], i32[7] = n, int(bool(draw_mask))
+        u32[0], u32[1] = self.seed & 0xFFFFFFFF, self.seed >> 32
+        u32[2], u32[3] = self.draws & 0xFFFFFFFF, (self.draws >> 32) & 0xFFFFFFFF
+        rec[192:224].view(np.float32)[:] = self.hyper
+        rec[224:228].view(np.uint32)[0] = min(int(p_keep * 4294967296.0), 0xFFFFFFFF)
+        if draw_mask:
+            self.draws += 1
+        self.keep = keep
+
+    def launch(self, mask):
+        """Enqueue (or capture) the prologue on the engine's current stream.  mask: the fp32 mask tensor the record may ask to draw."""
+        eng = self.eng
+        _lib.check(eng.L.countr_step_prologue(self.ring.data_ptr(), self.SLOTS, self.counter.data_ptr(), eng.hyper.data_ptr(),
+                                              mask.data_ptr() if mask is not None else None, mask.numel() if mask is not None else 0,
+                                              eng._stream()), "countr_step_prologue")
+
+    def executed(self, stream):
+        """One execution (eager or replayed) of a phase that holds the prologue has been enqueued on `stream`."""
+        k = self.seq % self.SLOTS
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record(stream)
+        self.seq += 1
+        for t in self.keep:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+        self.keep = ()
+
+
 class _GraphStep:
     """Shared machinery of the optimisation steps: dedicated stream (`self.stream`: load() makes it wait for the caller's current
     stream and step() makes the caller's stream wait for it -- a caller that runs its loop under `torch.cuda.stream(step.stream)`,
     as bench.py and the CLIs do, turns both into same-queue no-ops and saves ~50 us of idle GPU per step), per-phase hipGraph capture/replay, bucketed gradient
     all-reduce behind the backward phases, host-batch staging on a copy stream, device-side AdamW scalars."""
 
-    def __init__(self, model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter=1):
+    def __init__(self, model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter=1, mask_seed=0):
         self.model = model
         self.accum = int(accum_iter)   # micro-steps per optimisation step (reference --accum_iter: loss / accum_iter, update every
         self._micro = 0                # accum_iter-th iteration -- FSC_finetune_cross.py:300-305); gradients accumulate in eng.G
@@ -47,8 +125,8 @@ class _GraphStep:
         self.bucket_rest = (self.bucket0[1], lay.n_train)
         self.sync = self._make_sync(process_group)
         self.world = self.sync.world
-        self._ring = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(16)]
-        self._ring_ev = [None] * 16
+        self.pro = _Prologue(self.eng, mask_seed)
+        self._draw_mask = False
         self.grad_scale = 1.0 / self.accum
 
     def _make_sync(self, process_group):
@@ -219,54 +297,30 @@ class _GraphStep:
                 return
         self.graphs[gk] = g
 
-    def _flush_pending(self, extra=None):
-        """Launch the staging copies load() deferred -- together with `extra` = (src, dst, bytes), the AdamW scalars read by the kernel
-        straight from pinned host memory -- as ONE countr_copy_multi: the separate SDMA copy of the scalars between two graph replays
-        cost a queue hand-over (~25 us of idle GPU per step, tools/seq_step.sh)."""
-        pend, self._pending = self._pending, None
-        pairs = list(zip(*pend[:3])) if pend is not None else []
-        if extra is not None:
-            pairs.append(extra)
-        if not pairs:
-            return
-        n = len(pairs)
-        vp = C.c_void_p * n
-        _lib.check(self.eng.L.countr_copy_multi(n, vp(*[a for a, _b, _c in pairs]), vp(*[b for _a, b, _c in pairs]),
-                                                (C.c_int64 * n)(*[c for _a, _b, c in pairs]), self.eng._stream()), "copy_multi")
-        if pend is not None:
-            self._staging_consumed()
-            for t in pend[3]:
-                if t.is_cuda:
-                    t.record_stream(self.stream)
-
     def _upload_hyper(self, skip=()):
-        """Step-dependent AdamW scalars go through a small device buffer so that graph replay sees new values.  Bias corrections
-        are per counter group (torch.optim.AdamW counts steps per parameter): group 0 steps always, group 1 (exemplar CNN, bucket
-        2) and group 2 (shot_token, bucket 3) only once they have had a gradient."""
+        """Step-dependent AdamW scalars travel in the prologue's record (-> eng.hyper on the device) so that graph replay sees new
+        values.  Bias corrections are per counter group (torch.optim.AdamW counts steps per parameter): group 0 steps always, group 1
+        (exemplar CNN, bucket 2) and group 2 (shot_token, bucket 3) only once they have had a gradient."""
         eng = self.eng
         eng.step_count += 1
         eng.group_steps[0] += 1
         for bucket, grp in ((2, 1), (3, 2)):
             if bucket not in skip:
                 eng.group_steps[grp] += 1
-        slot = eng.step_count % len(self._ring)
-        ev = self._ring_ev[slot]
-        if ev is not None:
-            ev.synchronize()  # the copy that last used this pinned slot has completed
-        h = self._ring[slot]
+        h = self.pro.hyper
         h[0] = self.lr
         h[3] = self.grad_scale / self.world
         for grp, (i1, i2) in enumerate(((1, 2), (4, 5), (6, 7))):
             t = max(eng.group_steps[grp], 1)
             h[i1] = 1.0 - self.betas[0] ** t
             h[i2] = 1.0 - self.betas[1] ** t
-        if self._pending is not None:
-            self._flush_pending(extra=(h.data_ptr(), eng.hyper.data_ptr(), 32))
-        else:
-            eng.hyper.copy_(h, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._ring_ev[slot] = ev
+
+    def _prologue_mask(self):
+        """The mask buffer the prologue may draw into (None: this step has no loss mask)."""
+        return None
+
+    def _prologue_launch(self):
+        self.pro.launch(self._prologue_mask())
 
     # ------------------------------------------------------------------ optimizer state (checkpoint 'optimizer' entry)
     # The checkpoint's 'optimizer' entry is a torch.optim.AdamW state_dict in the REFERENCE's parameter order (util/misc.py:312-318
@@ -397,17 +451,14 @@ class _GraphStep:
 
     def _step(self, key):
         """backward phases in bucket order: after phase i the gradients of bucket i are final and its all-reduce starts on the
-        side stream, overlapping phase i+1; the last phase's bucket(s) are reduced by finish(); then the fused AdamW."""
+        side stream, overlapping phase i+1; the last phase's bucket(s) are reduced by finish(); then the fused AdamW.  The first
+        phase starts with the prologue (staging copies of load(), loss mask, AdamW scalars: _Prologue)."""
         eng = self.eng
         last = self._micro + 1 == self.accum      # only the last micro-step of a window reduces and applies the gradients
         with torch.cuda.stream(self.stream):
             if eng.M is None:
                 eng.M = torch.zeros_like(eng.G)
                 eng.V = torch.zeros_like(eng.G)
-            # the staging copies of load() travel with the AdamW scalars (_upload_hyper) when those are uploaded IN FRONT of the phases:
-            # the last micro-step of a window in the two whole-step-graph forms; otherwise they are launched here
-            if not (last and self.use_graph and (not self.sync.comm or self.sync.capturable)):
-                self._flush_pending()
             phases = self._phases(key)
             # this step's forward overwrites the plan's activation buffers (also when it is a graph replay): a pending autograd
             # backward of an earlier module forward with the same (batch, shot_num) must refuse (models_mae_cross._DecoderFn)
@@ -415,15 +466,20 @@ class _GraphStep:
                 pl = eng.plans.get((self.B, gkey[0], True))
                 if pl is not None:
                     pl.fwd_gen = getattr(pl, "fwd_gen", 0) + 1
+            # what the window's end reduces / steps is known before anything runs (the sets follow from the shot_nums drawn so far), so
+            # the AdamW scalars of an applying step travel with the prologue at the head of its first phase
+            ckey, cskip, zfill = None, (), ()
+            if last:
+                touched, zfill = self._window_sets()
+                cskip = tuple(self._comm_skip(touched))
+                skip, zero = self._adam_sets(touched)
+                self._upload_hyper(skip)
+                ckey = (tuple(skip), tuple(zero))
+            pend, self._pending = self._pending, None
+            self.pro.fill(list(zip(*pend[:3])) if pend is not None else [], self._draw_mask, keep=pend[3] if pend is not None else ())
             if self.use_graph and not self.sync.comm:
                 # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
-                # costs ~20 us of idle GPU (4 launches per step before).  The AdamW scalars are uploaded first; only phase c reads them.
-                ckey = None
-                if last:
-                    skip, zero = self._adam_sets(self._window_sets()[0])
-                    self._upload_hyper(skip)
-                    ckey = (tuple(skip), tuple(zero))
-
+                # costs ~20 us of idle GPU (4 launches per step before) -- and nothing else is launched between two replays
                 def whole(k, phases=phases):
                     self._run_phases_merged(phases)
                     if k[1] is not None:
@@ -432,14 +488,6 @@ class _GraphStep:
             elif self.use_graph and self.sync.capturable:
                 # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
                 # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
-                ckey, cskip, zfill = None, (), ()
-                if last:
-                    touched, zfill = self._window_sets()
-                    cskip = tuple(self._comm_skip(touched))
-                    skip, zero = self._adam_sets(touched)
-                    self._upload_hyper(skip)
-                    ckey = (tuple(skip), tuple(zero))
-
                 def whole(k, phases=phases, cskip=cskip, zfill=zfill):
                     for i, (_name, fn, gkey) in enumerate(phases):
                         fn(gkey)
@@ -449,7 +497,7 @@ class _GraphStep:
                         self._zero_buckets(zfill)
                         self.sync.finish(skip=cskip)
                         self._phase_c(k[1])
-                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip, zfill))
+                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else ()))
                 self._run_captured_comm(gk, whole)
             else:
                 for i, (name, fn, gkey) in enumerate(phases):
@@ -457,13 +505,13 @@ class _GraphStep:
                     if last and i + 1 < len(phases):
                         self.sync.start(i)
                 if last:
-                    touched, zfill = self._window_sets()
                     if zfill:
                         self._run_phase("z", self._zero_buckets, zfill)
-                    self.sync.finish(skip=tuple(self._comm_skip(touched)))
-                    skip, zero = self._adam_sets(touched)
-                    self._upload_hyper(skip)
-                    self._run_phase("c", self._phase_c, (tuple(skip), tuple(zero)))
+                    self.sync.finish(skip=cskip)
+                    self._run_phase("c", self._phase_c, ckey)
+            self.pro.executed(self.stream)
+            if pend is not None:
+                self._staging_consumed()
         torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
         if last:
             self.model.mark_weights_synced()
@@ -477,12 +525,16 @@ class _GraphStep:
 
 class FinetuneStep(_GraphStep):
     def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None, accum_iter=1, per_rank_shot=False):
-        """per_rank_shot: the reference's semantics (FSC_finetune_cross.py:276-284 draws shot_num per RANK; DDP's
+                 process_group=None, accum_iter=1, per_rank_shot=False, mask_seed=0):
+        """mask_seed: load(..., mask=None) lets the step draw the iteration's Bernoulli(0.8) loss mask itself (FSC_finetune_cross.py:
+        290-292 draws np.random.binomial per iteration; the reference seeds numpy with seed + rank, :168-170 -- pass the same here):
+        mask number t of this step object = Philox4x32-10(key = mask_seed, counter = (element / 4, 0, t)) < 0.8 * 2^32, drawn by the
+        step's prologue kernel inside the captured graph.
+        per_rank_shot: the reference's semantics (FSC_finetune_cross.py:276-284 draws shot_num per RANK; DDP's
         find_unused_parameters=True at :230 makes differing parameter subsets legal): step(S, shots_all=...) takes this rank's
         shot_num and every rank's; a conditional bucket (exemplar CNN / shot_token) some rank has a gradient for is all-reduced by
         EVERY rank -- zero-filled on the ranks without one -- and stepped by every rank, so parameters stay identical."""
-        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter)
+        super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter, mask_seed)
         self.per_rank = bool(per_rank_shot)
         self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
@@ -494,6 +546,7 @@ class FinetuneStep(_GraphStep):
         S, acc = key
         eng = self.eng
         p = eng.plan(self.B, S, True)
+        self._prologue_launch()
         eng.run(p.fwd_par)
         if S not in self.sums:
             self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
@@ -502,6 +555,9 @@ class FinetuneStep(_GraphStep):
         _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
                                            sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
         eng.run(self._lists(p, acc).bwd_head)
+
+    def _prologue_mask(self):
+        return self.mask
 
     def _make_sync(self, process_group):
         lay = self.eng.layout   # buckets in backward-completion order: head | decoder blocks + embed | exemplar CNN | shot_token
@@ -559,32 +615,37 @@ class FinetuneStep(_GraphStep):
 
     # ------------------------------------------------------------------ public
     def load(self, imgs, boxes, gt, mask, S):
-        """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream.  Dense fp32 device tensors of
-        the buffers' shapes are copied by ONE launch that step() issues together with the AdamW scalars: the sources are kept alive
+        """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream.  mask: the iteration's loss
+        mask [384, 384], or None -- the step then draws Bernoulli(0.8) itself (mask_seed of the constructor).  Dense fp32 device
+        tensors of the buffers' shapes are copied by the prologue kernel at the head of step()'s graph: the sources are kept alive
         until then and MUST NOT BE MODIFIED between load() and the return of the following step() (a persistent input buffer refilled in
         place in between would change the batch that trains); a load() that is superseded by another load() drops its references.
         Anything else is copied here, tensor by tensor."""
         cur = torch.cuda.current_stream(self.eng.device)
         self.stream.wait_stream(cur)           # producers of the inputs ran on the caller's stream
-        src = (imgs, boxes, gt, mask)
-        imgs, boxes, gt, mask = self._to_device(src)
+        src = tuple(t for t in (imgs, boxes, gt, mask) if t is not None)
+        self._draw_mask = mask is None
+        if mask is None:
+            imgs, boxes, gt = self._to_device((imgs, boxes, gt))
+        else:
+            imgs, boxes, gt, mask = self._to_device((imgs, boxes, gt, mask))
         with torch.cuda.stream(self.stream):
             p = self.eng.plan(self.B, S, True)
             self._pending = None
             if not self._load_fused(p, imgs, boxes, gt, mask, S, keep=src):
                 self.eng._load_inputs(p, imgs, boxes, S)
                 self.gt.copy_(gt, non_blocking=True)
-                self.mask.copy_(mask, non_blocking=True)
+                if mask is not None:
+                    self.mask.copy_(mask, non_blocking=True)
                 self._staging_consumed()
                 for t in src:                          # their memory must not be recycled before our copies have run
                     if t.is_cuda:
                         t.record_stream(self.stream)
 
     def _load_fused(self, p, imgs, boxes, gt, mask, S, keep=()):
-        """All staging copies of a batch in ONE launch (countr_copy_multi) when every source is a dense fp32 device tensor of the
-        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices).  The
-        launch is deferred to step() (_flush_pending)."""
-        pairs = [(imgs, p.buf["img"]), (gt, self.gt), (mask, self.mask)]
+        """All staging copies of a batch by the step's prologue kernel when every source is a dense fp32 device tensor of the
+        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices)."""
+        pairs = [(imgs, p.buf["img"]), (gt, self.gt)] + ([(mask, self.mask)] if mask is not None else [])
         if S > 0:
             if boxes.dim() != 5 or boxes.shape[1] != S:
                 return False
@@ -644,6 +705,7 @@ class PretrainStep(_GraphStep):
         K, acc = key
         eng = self.eng
         p = eng.plan(self.B, K, True)
+        self._prologue_launch()
         eng.run(p.fwd)
         eng.loss_launch(p, self.B, self.model.norm_pix_loss)
         eng.run(self._lists(p, acc).bwd_dec)
@@ -666,8 +728,14 @@ class PretrainStep(_GraphStep):
         (imgs,) = self._to_device((imgs,))
         with torch.cuda.stream(self.stream):
             p = self.eng.plan(self.B, self.K, True)
-            p.buf["img"].copy_(imgs, non_blocking=True)
-            self._staging_consumed()
+            dst = p.buf["img"]
+            self._pending = None
+            if (imgs.is_cuda and imgs.dtype == dst.dtype and imgs.is_contiguous() and imgs.numel() == dst.numel()
+                    and not (imgs.numel() * imgs.element_size()) % 16 and not imgs.data_ptr() % 16):
+                self._pending = ([imgs.data_ptr()], [dst.data_ptr()], [imgs.numel() * imgs.element_size()], [imgs, src])   # copied by the prologue
+            else:
+                dst.copy_(imgs, non_blocking=True)
+                self._staging_consumed()
             if ids_shuffle is None:
                 ids_shuffle = self.model.draw_masking(self.B, self.eng.device)
             self.eng.set_masking(p, ids_shuffle)

@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 4 (countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
+int countr_version(void);               /* ABI version, currently 5 (5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -250,6 +250,21 @@ int countr_colsum(const void* x, float* out, float* workspace, int M, int N, int
  * FSC_finetune_cross.py:270-296 -- into the static input buffers of a plan.  src[i] == NULL zero-fills dst[i] (the gradients DDP's
  * find_unused_parameters=True, FSC_finetune_cross.py:230, contributes for parameters a rank did not use in an iteration). */
 int countr_copy_multi(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
+/* Step prologue (ABI 5): what an optimisation step takes from the host per iteration -- the batch hand-over (samples / gt_density /
+ * boxes .to(device): FSC_finetune_cross.py:273-275), the Bernoulli loss mask drawn per iteration (:290-292: np.random.binomial(1, 0.8,
+ * [384, 384])) and the iteration's AdamW scalars (lr of lr_sched.adjust_learning_rate :271, bias corrections) -- as ONE launch with
+ * FROZEN arguments, so that it can be the first node of the step's captured hipGraph and nothing is launched between two replays.
+ * ring: `slots` records of countr_step_prologue_record_bytes() (= 256) bytes in memory the device can read and the host can write
+ * (pinned host memory); counter: device int64[2], zero-initialised by the caller, owned by the kernel afterwards: execution k (eager or
+ * replayed) reads record k % slots and its last block increments counter[0] -- the host counts executions and fills record k before
+ * execution k, not before execution k - slots has finished.  Record layout (little endian): u64 src[6], u64 dst[6], i64 n16[6]
+ * (16-byte units; src 0 = zero fill), i32 first[6] (first of the countr_step_prologue_copy_blocks() copy blocks dealt to entry i,
+ * ascending, first[0] = 0), i32 n (0..6 copies), i32 draw_mask, u32 key[2], u32 ctr[2], f32 hyper[8], u32 mask_thr, 28 bytes pad.
+ * hyper_dev: device fp32[8] <- hyper.  mask (NULL: none), mask_n % 4 == 0: with draw_mask, element 4g + j = (word j of
+ * Philox4x32-10(counter = (g, 0, ctr[0], ctr[1]), key) < mask_thr) ? 1 : 0 -- Bernoulli(mask_thr / 2^32), reproducible from (key, ctr). */
+int countr_step_prologue_record_bytes(void);
+int countr_step_prologue_copy_blocks(void);
+int countr_step_prologue(const void* ring, int slots, int64_t* counter, float* hyper_dev, float* mask, int mask_n, void* stream);
 int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co, int Ci, int taps, int dtype,
                         void* stream);
 

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), "include/countr_hip.h declares %s but libcountr_hip.so does not export it" % s
-    assert L.countr_version() == _lib.ABI_VERSION == 4
+    assert L.countr_version() == _lib.ABI_VERSION == 5
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU error path")
@@ -143,3 +143,21 @@ def test_shared_shot_num_and_sharding():
     parts = [shard_batch(35, r, 8) for r in range(8)]
     assert parts[0][0] == 0 and parts[-1][1] == 35 and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
     assert max(e - s for s, e in parts) - min(e - s for s, e in parts) <= 1
+
+
+def test_philox_oracle_matches_random123_known_answers():
+    """oracle/philox.py (the checker of the step prologue's loss-mask draw) against the three philox4x32-10 known-answer vectors the
+    Random123 distribution ships (kat_vectors: zero, all-ones, pi-digit counters / keys), + the Bernoulli(0.8) mask built on it."""
+    import numpy as np
+    from oracle.philox import philox4x32_10, loss_mask
+    kat = [([0, 0, 0, 0], (0, 0), "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+           ([0xffffffff] * 4, (0xffffffff, 0xffffffff), "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0), "d16cfe09 94fdcceb 5001e420 24126ea1")]
+    for ctr, key, want in kat:
+        got = " ".join("%08x" % v for v in philox4x32_10(np.array(ctr, dtype=np.uint32), key))
+        assert got == want, (ctr, got)
+    m0, m1 = loss_mask(7, 0), loss_mask(7, 1)
+    assert m0.shape == (384 * 384,) and set(np.unique(m0)) == {0.0, 1.0}
+    assert abs(m0.mean() - 0.8) < 5e-3 and abs(m1.mean() - 0.8) < 5e-3          # sigma of the mean = 1.04e-3
+    assert 0.15 < (m0 != m1).mean() < 0.5                                        # independent draws differ on 2 p (1 - p) = 32 %
+    assert (loss_mask(8, 0) != m0).any()

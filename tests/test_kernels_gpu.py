@@ -609,3 +609,75 @@ def test_window_gather_and_blend_equal_the_torch_slicing(hip, widths):
             assert torch.equal(dm[k], ref), (w, k)
             assert abs(sums[k].item() - ref.double().sum().item()) <= 1e-5 * ref.abs().double().sum().item()
 
+
+
+def test_step_prologue_ring_copies_mask_and_counter(hip):
+    """countr_step_prologue (the first node of a captured step): execution k reads record k % slots of the host ring -- copies (incl.
+    a zero fill and an odd size), AdamW scalars, the Philox loss mask bit for bit against oracle/philox.py -- counts its own executions
+    on the device, and does so under hipGraph replay too (arguments frozen, records rewritten between replays)."""
+    import numpy as np
+    from oracle.philox import loss_mask
+    L = hip
+    RB, NBLK, SLOTS = L.countr_step_prologue_record_bytes(), L.countr_step_prologue_copy_blocks(), 3
+    assert RB == 256
+    ring = torch.zeros(SLOTS * RB, dtype=torch.uint8).pin_memory()
+    view = ring.numpy()
+    counter = torch.zeros(2, dtype=torch.int64, device="cuda")
+    hyper = torch.zeros(8, device="cuda")
+    mask = torch.full((384 * 384,), -1.0, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.rand(n, generator=g).cuda() for n in (8 * 3 * 384 * 384, 8 * 384 * 384, 1236)]
+    dsts = [torch.zeros_like(t) for t in srcs] + [torch.ones(4096, device="cuda")]
+    seed = 0x1234_5678_9abc
+
+    def fill(k, t, draw, scale):
+        rec = view[k * RB:(k + 1) * RB]
+        u64, i32, u32 = rec[0:144].view(np.uint64), rec[144:176].view(np.int32), rec[176:192].view(np.uint32)
+        pairs = [(s_.data_ptr(), d_.data_ptr(), s_.numel() * 4) for s_, d_ in zip(srcs, dsts)] + [(0, dsts[3].data_ptr(), 4096 * 4)]
+        first = [0, 700, 1000, 1100]
+        for i in range(6):
+            s_, d_, b_ = pairs[i] if i < 4 else (0, 0, 0)
+            u64[i], u64[6 + i], u64[12 + i] = s_, d_, b_ // 16
+            i32[i] = first[i] if i < 4 else NBLK
+        i32[6], i32[7] = 4, int(draw)
+        u32[0], u32[1], u32[2], u32[3] = seed & 0xFFFFFFFF, seed >> 32, t, 0
+        rec[192:224].view(np.float32)[:] = np.arange(8, dtype=np.float32) * scale
+        rec[224:228].view(np.uint32)[0] = int(0.8 * 4294967296.0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (ring.data_ptr(), SLOTS, counter.data_ptr(), hyper.data_ptr(), mask.data_ptr(), mask.numel())
+    for k in range(4):                     # eager executions 0..3 (slot 0 is reused by execution 3)
+        for s_ in srcs:
+            s_.mul_(0.5).add_(k)
+        for d_ in dsts[:3]:
+            d_.zero_()
+        dsts[3].fill_(1.0)
+        fill(k % SLOTS, k, draw=(k != 1), scale=k + 1.0)
+        torch.cuda.synchronize()
+        _lib.check(L.countr_step_prologue(*args, st), "prologue")
+        torch.cuda.synchronize()
+        assert counter.tolist() == [k + 1, 0]
+        for s_, d_ in zip(srcs, dsts):
+            assert torch.equal(s_, d_)
+        assert float(dsts[3].abs().max()) == 0.0
+        assert torch.equal(hyper.cpu(), torch.arange(8.0) * (k + 1.0))
+        want = loss_mask(seed, 0 if k <= 1 else k)          # k = 1 draws nothing: the mask of execution 0 stays
+        assert np.array_equal(mask.cpu().numpy(), want), k
+    # the same launch captured once and replayed: executions 4, 5, 6
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gr, stream=side):
+            _lib.check(L.countr_step_prologue(*args, C.c_void_p(side.cuda_stream)), "prologue(capture)")
+    torch.cuda.synchronize()
+    assert counter.tolist() == [4, 0]                        # capture executes nothing
+    for k in range(4, 7):
+        srcs[2].add_(1.0)
+        fill(k % SLOTS, k, draw=True, scale=0.25 * k)
+        torch.cuda.synchronize()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert counter.tolist() == [k + 1, 0]
+        assert torch.equal(srcs[2], dsts[2]) and torch.equal(hyper.cpu(), torch.arange(8.0) * 0.25 * k)
+        assert np.array_equal(mask.cpu().numpy(), loss_mask(seed, k)), k
+    assert L.countr_step_prologue(None, SLOTS, counter.data_ptr(), hyper.data_ptr(), None, 0, st) != 0

@@ -401,3 +401,31 @@ def test_finetune_step_at_the_real_config_matches_oracle():
     moved = sum(float((after[k].detach().float().cpu() - torch.from_numpy(before[k])).abs().max()) > 0 for k in before
                 if k.startswith(("decoder", "decode_head", "shot_token")) and "pos_embed" not in k)
     assert moved >= 70
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_step_draws_its_own_loss_mask(use_graph):
+    """load(mask=None): the step draws the iteration's Bernoulli(0.8) loss mask in its prologue (FSC_finetune_cross.py:290-292 draws one
+    per iteration) -- mask t of the step object is oracle/philox.loss_mask(mask_seed, t); the loss of every step equals the oracle's
+    loss under exactly that mask (a mask that was not redrawn, or drawn for another t, moves the loss by ~1e-2), eager and replayed."""
+    from oracle.philox import loss_mask
+    from countr_amd.trainer import FinetuneStep
+    m, sd = make("fp32")
+    step = FinetuneStep(m, batch=2, lr=1e-4, use_graph=use_graph, mask_seed=99)
+    masks = []
+    for it, S in enumerate([3, 3, 0, 3]):
+        imgs, boxes, gt, _mask = W.make_inputs(batch=2, shots=3, seed=60 + it)
+        cur = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt)), None, S)
+        loss = step.step(S)[0].item()
+        mk = loss_mask(99, it).reshape(384, 384)
+        assert np.array_equal(step.mask.cpu().numpy(), mk), it
+        masks.append(mk)
+        _, rloss, _ = R.loss_and_grads(cur, imgs, boxes, gt, mk, S, NAME)
+        assert abs(loss - rloss.item()) <= 2e-3 * abs(rloss.item()), (it, S, loss, rloss.item())
+    assert all((masks[0] != mk).mean() > 0.2 for mk in masks[1:])
+    # a caller-supplied mask still wins
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=3, seed=70)
+    step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), 3)
+    step.step(3)
+    assert np.array_equal(step.mask.cpu().numpy(), mask)
