@@ -341,7 +341,11 @@ def check_step_against_oracle(step, m, cur, batch, S, sums, model_name="mae_vit_
     rc = R.counts(out).numpy()
     cnt = sums[1:1 + B].cpu().numpy()
     den = np.maximum(np.abs(rc), count_scale if count_scale is not None else 0.0)
-    assert (np.abs(cnt - rc) / den).max() < (6e-2 if S == 0 else 1e-2), (S, cnt, rc)
+    # (first step = the pinned initial weights: the bars of tests/test_model_gpu.py; later steps: AdamW has moved every fp32 master weight
+    # by a few 1e-5, 1e-3 of a bf16 ulp, so the bf16 shadows realise the coherent shift only through the few weights that crossed a
+    # rounding boundary -- measured 1.2 % of the initial count after three steps; bar 2.5 %)
+    bar = (6e-2 if S == 0 else 1e-2) if count_scale is None else (6e-2 if S == 0 else 2.5e-2)
+    assert (np.abs(cnt - rc) / den).max() < bar, (S, cnt, rc)
     gtc = sums[1 + B:1 + 2 * B].cpu().numpy()
     assert np.abs(gtc - gt.reshape(B, -1).sum(1) / 60).max() < 1e-2
     checked, worst = 0, (0.0, 0.0)
