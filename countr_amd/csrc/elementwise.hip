@@ -668,9 +668,9 @@ extern "C" int countr_copy_multi(int n, const void* const* src, void* const* dst
 // (FSC_finetune_cross.py:271-295: lr for the iteration, the batch hand-over, the Bernoulli(0.8) loss mask drawn per iteration.)
 // Between two graph replays every separate launch / copy costs a queue hand-over (round 4: mask draw + staging launch = 3.6 + 10.6 us
 // of work inside ~160 us of idle GPU).  The arguments of a captured node are frozen, so what changes per step travels through a RING
-// of 256-byte records in pinned host memory that the kernel reads directly: record index = *counter % slots, where counter is a
-// device int64 the LAST block of every execution increments (device-scope ticket) -- eager launches and replays alike, so the host
-// mirrors it by counting executions and fills record (executions % slots) before each one.
+// of 256-byte records in pinned host memory that the device reads directly: record index = *counter % slots, where counter is a
+// device int64 every execution increments -- eager launches and replays alike, so the host mirrors it by counting executions and
+// fills record (executions % slots) before each one.
 struct PrologueRec {               // 256 bytes, host-written (countr_amd/trainer.py::_Prologue)
   unsigned long long src[6], dst[6];
   long long n16[6];
@@ -696,15 +696,27 @@ __device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueRec* __restrict__ ring, int slots, long long* counter, float* hyper_dev,
-                                                            float* mask, int mask_n4) {
+// Two kernel nodes: a one-block fetch (the ONLY reader of host memory: 1248 blocks reading their record over PCIe took 98 us) copies
+// record (counter % slots) into device memory, writes the AdamW scalars and counts the execution; the wide kernel behind it reads the
+// device copy.
+__global__ __launch_bounds__(64) void step_prologue_fetch_kernel(const PrologueRec* __restrict__ ring, int slots, long long* counter, PrologueRec* rec_dev,
+                                                                float* hyper_dev) {
+  const long long seq = counter[0];
+  const uint4* r = reinterpret_cast<const uint4*>(ring + (seq % slots));
+  if (threadIdx.x < 16) {
+    const uint4 v = r[threadIdx.x];
+    reinterpret_cast<uint4*>(rec_dev)[threadIdx.x] = v;
+    if (threadIdx.x == 12 || threadIdx.x == 13) reinterpret_cast<uint4*>(hyper_dev)[threadIdx.x - 12] = v;      // bytes 192..223: hyper[8]
+  }
+  if (threadIdx.x == 0) counter[0] = seq + 1;       // the next execution (stream order) reads the next record
+}
+
+__global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueRec* __restrict__ rec_dev, float* mask, int mask_n4) {
   __shared__ PrologueRec rec;
-  const long long seq = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x < 16) reinterpret_cast<uint4*>(&rec)[threadIdx.x] = reinterpret_cast<const uint4*>(ring + (seq % slots))[threadIdx.x];
+  if (threadIdx.x < 16) reinterpret_cast<uint4*>(&rec)[threadIdx.x] = reinterpret_cast<const uint4*>(rec_dev)[threadIdx.x];
   __syncthreads();
   const int b = blockIdx.x;
   if (b < PRO_COPY_BLOCKS) {
-    if (b == 0 && threadIdx.x < 8) hyper_dev[threadIdx.x] = rec.hyper[threadIdx.x];
     int e = 0;
 #pragma unroll
     for (int i = 1; i < 6; ++i) e += (i < rec.n && b >= rec.first[i]) ? 1 : 0;
@@ -729,26 +741,20 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueRec* _
                                                   r[2] < rec.mask_thr ? 1.f : 0.f, r[3] < rec.mask_thr ? 1.f : 0.f};
     }
   }
-  // last block done -> the next execution reads the next record
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const long long t = __hip_atomic_fetch_add(counter + 1, 1ll, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == (long long)gridDim.x - 1) {
-      __hip_atomic_store(counter + 1, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(counter, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 }
 
 extern "C" int countr_step_prologue_record_bytes(void) { return (int)sizeof(PrologueRec); }
 extern "C" int countr_step_prologue_copy_blocks(void) { return PRO_COPY_BLOCKS; }
 extern "C" int countr_step_prologue(const void* ring, int slots, int64_t* counter, float* hyper_dev, float* mask, int mask_n, void* stream) {
-  if (!ring || slots < 1 || !counter || !hyper_dev || ((uintptr_t)ring & 15) || (mask && ((mask_n & 3) || ((uintptr_t)mask & 15)))) {
-    countr_set_error("countr_step_prologue: null / unaligned argument (mask_n % 4 == 0)"); return -1;
+  if (!ring || slots < 1 || !counter || !hyper_dev || (((uintptr_t)ring | (uintptr_t)counter | (uintptr_t)hyper_dev) & 15) ||
+      (mask && ((mask_n & 3) || ((uintptr_t)mask & 15)))) {
+    countr_set_error("countr_step_prologue: null / unaligned argument (16-byte pointers, mask_n % 4 == 0)"); return -1;
   }
+  PrologueRec* rec_dev = reinterpret_cast<PrologueRec*>(counter + 2);       // counter: int64[2 + 32]: {executions, reserved, record copy}
+  hipLaunchKernelGGL(step_prologue_fetch_kernel, dim3(1), dim3(64), 0, STREAM(stream), reinterpret_cast<const PrologueRec*>(ring), slots,
+                     reinterpret_cast<long long*>(counter), rec_dev, hyper_dev);
   hipLaunchKernelGGL(step_prologue_kernel, dim3(PRO_COPY_BLOCKS + (mask ? PRO_MASK_BLOCKS : 0)), dim3(256), 0, STREAM(stream),
-                     reinterpret_cast<const PrologueRec*>(ring), slots, reinterpret_cast<long long*>(counter), hyper_dev, mask, mask ? mask_n / 4 : 0);
+                     rec_dev, mask, mask ? mask_n / 4 : 0);
   COUNTR_LAUNCH_CHECK("countr_step_prologue");
 }
 

@@ -34,7 +34,7 @@ class _Prologue:
         assert self.rb == 256
         self.ring = torch.zeros(self.SLOTS * self.rb, dtype=torch.uint8).pin_memory()
         self.view = self.ring.numpy()
-        self.counter = torch.zeros(2, dtype=torch.int64, device=eng.device)
+        self.counter = torch.zeros(2 + 32, dtype=torch.int64, device=eng.device)      # {executions, reserved, record copy}
         self.seq = 0
         self.events = [None] * self.SLOTS
         self.hyper = np.zeros(8, np.float32)

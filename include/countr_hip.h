@@ -255,9 +255,10 @@ int countr_copy_multi(int n, const void* const* src, void* const* dst, const int
  * [384, 384])) and the iteration's AdamW scalars (lr of lr_sched.adjust_learning_rate :271, bias corrections) -- as ONE launch with
  * FROZEN arguments, so that it can be the first node of the step's captured hipGraph and nothing is launched between two replays.
  * ring: `slots` records of countr_step_prologue_record_bytes() (= 256) bytes in memory the device can read and the host can write
- * (pinned host memory); counter: device int64[2], zero-initialised by the caller, owned by the kernel afterwards: execution k (eager or
- * replayed) reads record k % slots and its last block increments counter[0] -- the host counts executions and fills record k before
- * execution k, not before execution k - slots has finished.  Record layout (little endian): u64 src[6], u64 dst[6], i64 n16[6]
+ * (pinned host memory); counter: device int64[34] (16-byte aligned), zero-initialised by the caller, owned by the library afterwards:
+ * counter[0] = executions so far, [2..33] = device copy of the current record.  Execution k (eager or replayed) reads record k % slots
+ * -- a one-block kernel fetches it from the host and increments counter[0], a wide kernel does the work -- so the host counts
+ * executions and fills record k before execution k, not before execution k - slots has finished.  Record layout (little endian): u64 src[6], u64 dst[6], i64 n16[6]
  * (16-byte units; src 0 = zero fill), i32 first[6] (first of the countr_step_prologue_copy_blocks() copy blocks dealt to entry i,
  * ascending, first[0] = 0), i32 n (0..6 copies), i32 draw_mask, u32 key[2], u32 ctr[2], f32 hyper[8], u32 mask_thr, 28 bytes pad.
  * hyper_dev: device fp32[8] <- hyper.  mask (NULL: none), mask_n % 4 == 0: with draw_mask, element 4g + j = (word j of
