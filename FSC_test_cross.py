@@ -78,9 +78,6 @@ def main(args):
         ext = None
         if args.external:     # FSC_test_cross(few-shot).py:96-129: the split's own exemplar crops, cut to --box_bound, for every image
             ext = fsc147.external_exemplars(annotations, split, im_dir, args.box_bound)
-            if ext.shape[0] > 8:
-                raise SystemExit("--external with %d exemplars: the cross-attention kernel holds at most 8 exemplar tokens (use --box_bound <= 8)"
-                                 % ext.shape[0])
         for im_id in split:
             img, dots, boxes, pos, _gt_map = fsc147.test_item(annotations, im_dir, im_id, args.box_bound, ext)
             items.append((im_id, img, boxes, [tuple(r) for r in pos], dots.shape[0]))

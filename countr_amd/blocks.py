@@ -117,8 +117,6 @@ class Runner:
 
     def cross_attention(self, q, k, v, B, N, S, heads):
         D = q.shape[1]
-        if S > 8:
-            raise _lib.CountrError("CrossAttention against %d key tokens is not supported by the gfx950 kernels (exemplar tokens: at most 8)" % S)
         out = torch.empty((B * N, D), device=q.device, dtype=self.tdt)
         _lib.check(self.L.countr_xattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, N, S, D, heads, D,
                                            (D // heads) ** -0.5, self.code, _stream()), "countr_xattn_fwd")

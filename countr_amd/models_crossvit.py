@@ -77,7 +77,7 @@ class Attention(_HipModule):
 
 
 class CrossAttention(_HipModule):
-    """models_crossvit.py:96-128: queries from x, keys / values from y (at most 8 tokens: the exemplar tokens)."""
+    """models_crossvit.py:96-128: queries from x, keys / values from y (any number of tokens; up to 8 -- the exemplar tokens -- sit in registers)."""
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., precision="bf16"):
         super().__init__()

@@ -244,3 +244,50 @@ def test_backward_after_overwriting_forward_is_refused():
     out3 = m(imgs, boxes, 3)                   # a forward of another shot_num in between does not disturb it
     m(imgs, boxes, 0)
     out3.sum().backward()
+
+
+@pytest.mark.parametrize("precision,tol,ctol", [("fp32", 1e-3, None), ("bf16", 6e-2, 1e-2)])
+def test_forward_with_more_than_eight_exemplars_matches_oracle(precision, tol, ctol, fp32_model, bf16_model):
+    """FSC_test_cross(few-shot).py:56,138-139 defaults to --box_bound -1: EVERY annotated box of an image is an exemplar, and
+    CrossAttention (models_crossvit.py:111-128) takes any number of key tokens.  Rounds 1-4 refused more than 8; the cross-attention
+    kernels now walk longer key lists with an online softmax.  12 exemplars on one image against the oracle."""
+    m, sd = fp32_model if precision == "fp32" else bf16_model
+    imgs, boxes, _gt, _mask = W.make_inputs(batch=1, shots=12, seed=31)
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    ref = R.forward(sd, imgs, boxes, 12).numpy()
+    with torch.no_grad():
+        out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 12).cpu().numpy()
+    assert out.shape == ref.shape == (1, 384, 384)
+    assert rel(out, ref) < tol, rel(out, ref)
+    c, rc = out.sum() / 60, ref.sum() / 60
+    assert abs(c - rc) < (0.5 if ctol is None else ctol * abs(rc)), (c, rc)
+
+
+def test_gradients_with_ten_exemplars_match_oracle():
+    """The decoder-side backward with a key list longer than the register form holds (shot_num 10, reduced-depth model, fp32 parity
+    mode): every trainable tensor's gradient against the oracle's autograd."""
+    from functools import partial
+    import torch.nn as nn
+    from countr_amd.models_mae_cross import SupervisedMAE
+    name = "tiny_test"
+    p, D, depth, H, Dd, ddepth, Hd = W.CONFIGS[name]
+    sd = W.make_state_dict(name, seed=3)
+    m = SupervisedMAE(patch_size=p, embed_dim=D, depth=depth, num_heads=H, decoder_embed_dim=Dd, decoder_depth=ddepth,
+                      decoder_num_heads=Hd, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), precision="fp32")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to("cuda").train()
+    imgs, boxes, gt, mask = W.make_inputs(batch=2, shots=10, seed=33)
+    out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 10)
+    loss = R.masked_mse_loss(out, torch.from_numpy(gt).cuda(), torch.from_numpy(mask).cuda())
+    loss.backward()
+    _, rloss, rg = R.loss_and_grads(sd, imgs, boxes, gt, mask, 10, name)
+    assert abs(loss.item() - rloss.item()) <= 1e-3 * abs(rloss.item())
+    checked = 0
+    for k, prm in m.named_parameters():
+        if prm.grad is None or rg.get(k) is None:
+            continue
+        ref = rg[k].double()
+        got = prm.grad.detach().cpu().double()
+        assert (got - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-9, (k, (got - ref).norm().item(), ref.norm().item())
+        checked += 1
+    assert checked >= 50
