@@ -3,9 +3,9 @@
 Inside SupervisedMAE / MaskedAutoencoderViTNoCT they are parameter containers: they own nn.Parameters under the reference's attribute
 names (state_dict keys match) and the model's engine (countr_amd/engine.py) runs static launch lists over them.  CALLED ON THEIR OWN
 -- Mlp(x), Attention(x), CrossAttention(x, y), Block(x), CrossAttentionBlock(x, y): the reference's signatures, [B, N, C] tensors -- they
-run their forward through the same C-ABI exports (countr_amd/blocks.py: countr_gemm, countr_layernorm_fwd, countr_attn_fwd,
-countr_xattn_fwd ...), so that a maintainer can swap a single module of the reference model for its HIP counterpart.  Forward only
-(no autograd through a standalone module; the encoder Blocks of the reference run under no_grad anyway, models_mae_cross.py:204-205);
+run through the same C-ABI exports (countr_amd/blocks.py: countr_gemm, countr_layernorm_fwd, countr_attn_fwd,
+countr_xattn_fwd ...), so that a maintainer can swap a single module of the reference model for its HIP counterpart -- also under
+autograd (every primitive's backward is a C-ABI launch too: blocks.LinearFn / LayerNormFn / SelfAttentionFn / CrossAttentionFn);
 `precision` ('bf16' default, 'fp32' = parity mode) is an extra keyword / attribute.  PatchEmbed stays a container (the model's engine
 fuses it with the pos-embed add)."""
 import torch
@@ -50,7 +50,9 @@ class Mlp(_HipModule):
 
     def forward(self, x):
         r = self._runner()
-        r.check_input(x, module=self)
+        if r.check_input(x, module=self):                                   # autograd is recording: differentiable primitives
+            x2, B, N = blocks._rows_grad(x)
+            return blocks.mlp_autograd(r, self, x2.to(r.tdt)).view(B, N, -1).to(x.dtype)
         x2, B, N = blocks._rows(x)
         return blocks.mlp_forward(r, self, r.to_operand(x2)).view(B, N, -1).to(x.dtype)
 
@@ -71,7 +73,9 @@ class Attention(_HipModule):
 
     def forward(self, x):
         r = self._runner()
-        r.check_input(x, module=self)
+        if r.check_input(x, module=self):
+            x2, B, N = blocks._rows_grad(x)
+            return blocks.attention_autograd(r, self, x2.to(r.tdt), B, N).view(B, N, -1).to(x.dtype)
         x2, B, N = blocks._rows(x)
         return blocks.attention_forward(r, self, r.to_operand(x2), B, N).view(B, N, -1).to(x.dtype)
 
@@ -94,7 +98,12 @@ class CrossAttention(_HipModule):
 
     def forward(self, x, y):
         r = self._runner()
-        r.check_input(x, y, module=self)
+        if r.check_input(x, y, module=self):
+            x2, B, N = blocks._rows_grad(x)
+            y2, By, S = blocks._rows_grad(y)
+            if By != B:
+                raise ValueError("CrossAttention: x and y must share the batch dimension")
+            return blocks.cross_attention_autograd(r, self, x2.to(r.tdt), y2.to(r.tdt), B, N, S).view(B, N, -1).to(x.dtype)
         x2, B, N = blocks._rows(x)
         y2, By, S = blocks._rows(y)
         if By != B:
@@ -117,7 +126,11 @@ class Block(_HipModule):
 
     def forward(self, x):
         r = self._runner()
-        r.check_input(x, module=self)
+        if r.check_input(x, module=self):
+            x2, B, N = blocks._rows_grad(x)
+            x2 = x2 + blocks.attention_autograd(r, self.attn, blocks.layernorm_autograd(r, x2, self.norm1), B, N)
+            x2 = x2 + blocks.mlp_autograd(r, self.mlp, blocks.layernorm_autograd(r, x2, self.norm2))
+            return x2.view(B, N, -1).to(x.dtype)
         x2, B, N = blocks._rows(x)
         x2 = blocks.attention_forward(r, self.attn, r.layernorm(x2, self.norm1), B, N, resid=x2)
         x2 = blocks.mlp_forward(r, self.mlp, r.layernorm(x2, self.norm2), resid=x2)
@@ -141,7 +154,15 @@ class CrossAttentionBlock(_HipModule):
 
     def forward(self, x, y):
         r = self._runner()
-        r.check_input(x, y, module=self)
+        if r.check_input(x, y, module=self):
+            x2, B, N = blocks._rows_grad(x)
+            y2, By, S = blocks._rows_grad(y)
+            if By != B:
+                raise ValueError("CrossAttentionBlock: x and y must share the batch dimension")
+            x2 = x2 + blocks.attention_autograd(r, self.selfattn, blocks.layernorm_autograd(r, x2, self.norm0), B, N)
+            x2 = x2 + blocks.cross_attention_autograd(r, self.attn, blocks.layernorm_autograd(r, x2, self.norm1), y2.to(r.tdt), B, N, S)
+            x2 = x2 + blocks.mlp_autograd(r, self.mlp, blocks.layernorm_autograd(r, x2, self.norm2))
+            return x2.view(B, N, -1).to(x.dtype)
         x2, B, N = blocks._rows(x)
         y2, By, S = blocks._rows(y)
         if By != B:

@@ -1,7 +1,8 @@
 """GPU: the reference's block modules CALLED ON THEIR OWN (countr_amd.models_crossvit: Mlp, Attention, CrossAttention, Block,
 CrossAttentionBlock -- models_crossvit.py:46-156, timm Block) against the oracle's restatement of the same modules on the same
 weights: fp32 parity mode to 1e-3 of the output's maximum (measured ~1e-6), bf16 mode to bf16 tolerance; the module surface
-(constructor keywords, [B, N, C] in / out, dtype preserved, forward-only and GPU-only errors)."""
+(constructor keywords, [B, N, C] in / out, dtype preserved, GPU-only errors); and the same modules UNDER AUTOGRAD -- trainable, as
+the reference's are -- against fp64 autograd of the oracle's restatement."""
 import numpy as np
 import pytest
 import torch
@@ -80,8 +81,7 @@ def test_module_surface_and_errors():
     from countr_amd.models_crossvit import Attention, Block, CrossAttention
     a = Attention(128, num_heads=2, qkv_bias=True).cuda()
     x = torch.randn(1, 64, 128, device="cuda")
-    with pytest.raises(RuntimeError, match="forward-only"):
-        a(x)                                             # autograd is recording and the parameters require grad
+    assert a(x).requires_grad                            # autograd is recording and the parameters require grad: trainable
     with torch.no_grad():
         out = a(x.half())
         assert out.dtype == torch.float16 and out.shape == x.shape
@@ -113,3 +113,75 @@ def test_a_block_of_the_full_model_is_callable():
     with torch.no_grad():
         got = m.blocks[3](x.cuda())
     assert _rel(got, ref) < 1e-3
+
+
+def _grad_check(mod, ref_fn, inputs, tol, cos_min):
+    """mod(*inputs).backward(w) through the C-ABI autograd primitives against fp64 autograd of the oracle's restatement on the same
+    weights: input gradients and every parameter gradient by relative error of the tensor (fp32) / direction + norm (bf16)."""
+    xs = [t.clone().cuda().requires_grad_(True) for t in inputs]
+    out = mod(*xs)
+    assert out.requires_grad and out.dtype == torch.float32
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(99)).cuda()
+    (out * w).sum().backward()
+    p = {"b." + k: v.detach().cpu().double().requires_grad_(True) for k, v in mod.named_parameters()}
+    xr = [t.double().requires_grad_(True) for t in inputs]
+    ref = ref_fn(p, *xr)
+    assert _rel(out.detach(), ref.detach()) < (tol if tol > 1e-3 else 1e-3)
+    (ref * w.cpu().double()).sum().backward()
+    pairs = [("input%d" % i, a.grad, b.grad) for i, (a, b) in enumerate(zip(xs, xr))] + \
+            [(k, v.grad, p["b." + k].grad) for k, v in mod.named_parameters()]
+    for name, got, want in pairs:
+        assert got is not None, name
+        got = got.detach().cpu().double()
+        err = (got - want).norm().item() / want.norm().item()
+        cos = ((got * want).sum() / (got.norm() * want.norm())).item()
+        assert err < tol and cos > cos_min, (name, err, cos)
+    return len(pairs)
+
+
+GRAD_CASES = [("fp32", 2e-3, 0.999999), ("bf16", 6e-2, 0.998)]
+
+
+@pytest.mark.parametrize("precision,tol,cos_min", GRAD_CASES)
+@pytest.mark.parametrize("dim,heads,B,N", [(512, 16, 2, 576), (768, 12, 1, 576), (256, 4, 1, 200)])
+def test_block_is_trainable_and_matches_oracle_autograd(precision, tol, cos_min, dim, heads, B, N):
+    """timm Block under autograd (dh 32 / 64: the fused attention forward + backward kernels in bf16; the unfused softmax path in fp32)."""
+    from countr_amd.models_crossvit import Block
+    blk = _init(Block(dim, heads, 4.0, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), precision=precision), 11).cuda()
+    x = torch.randn(B, N, dim, generator=torch.Generator().manual_seed(12)) * 0.8
+
+    def ref(p, xd):
+        h = xd + R.self_attention(R.layer_norm(xd, p["b.norm1.weight"], p["b.norm1.bias"]), p, "b.attn", heads)
+        return h + R.mlp(R.layer_norm(h, p["b.norm2.weight"], p["b.norm2.bias"]), p, "b.mlp")
+    assert _grad_check(blk, ref, [x], tol, cos_min) == 13
+
+
+@pytest.mark.parametrize("precision,tol,cos_min", GRAD_CASES)
+@pytest.mark.parametrize("S", [3, 11])
+def test_cross_attention_block_is_trainable_and_matches_oracle_autograd(precision, tol, cos_min, S):
+    """models_crossvit.py:130-156 under autograd, gradients to x, y (the exemplar tokens) and all 26 parameter tensors; S = 11 takes the
+    many-key cross-attention kernels."""
+    from countr_amd.models_crossvit import CrossAttentionBlock
+    dim, heads, B, N = 512, 16, 2, 576
+    blk = _init(CrossAttentionBlock(dim, heads, 4.0, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), precision=precision), 13).cuda()
+    g = torch.Generator().manual_seed(14)
+    x, y = torch.randn(B, N, dim, generator=g) * 0.8, torch.randn(B, S, dim, generator=g)
+
+    def ref(p, xd, yd):
+        h = xd + R.self_attention(R.layer_norm(xd, p["b.norm0.weight"], p["b.norm0.bias"]), p, "b.selfattn", heads)
+        h = h + R.cross_attention(R.layer_norm(h, p["b.norm1.weight"], p["b.norm1.bias"]), yd, p, "b.attn", heads)
+        return h + R.mlp(R.layer_norm(h, p["b.norm2.weight"], p["b.norm2.bias"]), p, "b.mlp")
+    assert _grad_check(blk, ref, [x, y], tol, cos_min) == 2 + 26
+
+
+@pytest.mark.parametrize("precision,tol,cos_min", GRAD_CASES)
+def test_leaf_modules_are_trainable(precision, tol, cos_min):
+    from countr_amd.models_crossvit import Attention, CrossAttention, Mlp
+    g = torch.Generator().manual_seed(15)
+    x, y = torch.randn(2, 576, 512, generator=g), torch.randn(2, 2, 512, generator=g)
+    mlp = _init(Mlp(512, 2048, precision=precision), 16).cuda()
+    _grad_check(mlp, lambda p, xd: R.mlp(xd, p, "b"), [x], tol, cos_min)
+    att = _init(Attention(512, 16, qkv_bias=True, precision=precision), 17).cuda()
+    _grad_check(att, lambda p, xd: R.self_attention(xd, p, "b", 16), [x], tol, cos_min)
+    xat = _init(CrossAttention(512, 16, qkv_bias=True, precision=precision), 18).cuda()
+    _grad_check(xat, lambda p, xd, yd: R.cross_attention(xd, yd, p, "b", 16), [x, y], tol, cos_min)

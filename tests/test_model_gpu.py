@@ -283,11 +283,15 @@ def test_gradients_with_ten_exemplars_match_oracle():
     _, rloss, rg = R.loss_and_grads(sd, imgs, boxes, gt, mask, 10, name)
     assert abs(loss.item() - rloss.item()) <= 1e-3 * abs(rloss.item())
     checked = 0
+    big = max(g.double().norm().item() for g in rg.values() if g is not None)
     for k, prm in m.named_parameters():
         if prm.grad is None or rg.get(k) is None:
             continue
         ref = rg[k].double()
         got = prm.grad.detach().cpu().double()
-        assert (got - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-9, (k, (got - ref).norm().item(), ref.norm().item())
+        if ref.norm().item() < 1e-6 * big:      # (conv biases in front of an InstanceNorm: zero gradient up to rounding, in both)
+            assert got.norm().item() < 1e-5 * big, k
+            continue
+        assert (got - ref).norm().item() <= 2e-3 * ref.norm().item(), (k, (got - ref).norm().item(), ref.norm().item())
         checked += 1
     assert checked >= 50
