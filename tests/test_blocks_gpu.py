@@ -130,9 +130,13 @@ def _grad_check(mod, ref_fn, inputs, tol, cos_min):
     (ref * w.cpu().double()).sum().backward()
     pairs = [("input%d" % i, a.grad, b.grad) for i, (a, b) in enumerate(zip(xs, xr))] + \
             [(k, v.grad, p["b." + k].grad) for k, v in mod.named_parameters()]
+    big = max(want.norm().item() for _n, _g, want in pairs)
     for name, got, want in pairs:
         assert got is not None, name
         got = got.detach().cpu().double()
+        if want.norm().item() < 1e-9 * big:          # (attn.wk.bias: a bias on the keys shifts every score of a row alike -- zero gradient)
+            assert got.norm().item() < 1e-4 * big, (name, got.norm().item())
+            continue
         err = (got - want).norm().item() / want.norm().item()
         cos = ((got * want).sum() / (got.norm() * want.norm())).item()
         assert err < tol and cos > cos_min, (name, err, cos)
@@ -159,7 +163,7 @@ def test_block_is_trainable_and_matches_oracle_autograd(precision, tol, cos_min,
 @pytest.mark.parametrize("precision,tol,cos_min", GRAD_CASES)
 @pytest.mark.parametrize("S", [3, 11])
 def test_cross_attention_block_is_trainable_and_matches_oracle_autograd(precision, tol, cos_min, S):
-    """models_crossvit.py:130-156 under autograd, gradients to x, y (the exemplar tokens) and all 26 parameter tensors; S = 11 takes the
+    """models_crossvit.py:130-156 under autograd, gradients to x, y (the exemplar tokens) and all 22 parameter tensors; S = 11 takes the
     many-key cross-attention kernels."""
     from countr_amd.models_crossvit import CrossAttentionBlock
     dim, heads, B, N = 512, 16, 2, 576
@@ -171,7 +175,7 @@ def test_cross_attention_block_is_trainable_and_matches_oracle_autograd(precisio
         h = xd + R.self_attention(R.layer_norm(xd, p["b.norm0.weight"], p["b.norm0.bias"]), p, "b.selfattn", heads)
         h = h + R.cross_attention(R.layer_norm(h, p["b.norm1.weight"], p["b.norm1.bias"]), yd, p, "b.attn", heads)
         return h + R.mlp(R.layer_norm(h, p["b.norm2.weight"], p["b.norm2.bias"]), p, "b.mlp")
-    assert _grad_check(blk, ref, [x, y], tol, cos_min) == 2 + 26
+    assert _grad_check(blk, ref, [x, y], tol, cos_min) == 2 + 22
 
 
 @pytest.mark.parametrize("precision,tol,cos_min", GRAD_CASES)

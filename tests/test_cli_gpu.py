@@ -76,16 +76,17 @@ def test_finetune_then_test_cli_on_files(fake_fsc, tmp_path):
     log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "val", "--box_bound", "0"])
     assert json.loads([l for l in log.splitlines() if l.startswith("{")][-1])["images"] == 2
     # --external (FSC_test_cross(few-shot).py:96-129): the split's own exemplar crops, cut to --box_bound, serve every image; the
-    # counts differ from the per-image exemplars', 5 external exemplars run (shot_num = 5), and an unbounded list is refused loudly
+    # counts differ from the per-image exemplars', 5 external exemplars run (shot_num = 5), and the UNBOUNDED list of the train split
+    # (--box_bound -1, the reference's default: every box of every image, more than the 8 keys rounds 1-4 stopped at) runs too
     few = [l for l in run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "test"]).splitlines() if "pred_cnt" in l]
     for bound in ("3", "5"):
         log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "test", "--external", "--box_bound", bound])
         ext = [l for l in log.splitlines() if "pred_cnt" in l]
         assert len(ext) == len(few) == 2 and ext != few
         assert all(np.isfinite(float(l.split("pred_cnt:")[1].split(",")[0])) for l in ext)
-    r = subprocess.run([sys.executable, "FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "train", "--external"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "at most 8" in r.stderr
+    log = run(["FSC_test_cross.py", "--data_path", fake_fsc, "--resume", ckpt, "--split", "train", "--external"])
+    many = [l for l in log.splitlines() if "pred_cnt" in l]
+    assert many and all(np.isfinite(float(l.split("pred_cnt:")[1].split(",")[0])) for l in many)
 
 
 def test_finetune_cli_default_batch_size(tmp_path):

@@ -294,4 +294,4 @@ def test_gradients_with_ten_exemplars_match_oracle():
             continue
         assert (got - ref).norm().item() <= 2e-3 * ref.norm().item(), (k, (got - ref).norm().item(), ref.norm().item())
         checked += 1
-    assert checked >= 50
+    assert checked >= 40
