@@ -58,7 +58,7 @@ def get_args_parser():
     p.add_argument("--team", default=None, type=str)
     p.add_argument("--wandb_id", default=None, type=str)
     # additions
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--synthetic_steps", default=0, type=int,
                    help="K > 0: K iterations per epoch on synthetic images; 0: FSC147 from --data_path (synthetic, 50 it/epoch, if absent)")
     p.add_argument("--log_every", default=20, type=int, help="iterations between loss reports (each report is a host sync)")

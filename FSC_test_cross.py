@@ -46,7 +46,7 @@ def get_args_parser():
     p.add_argument("--dist_on_itp", action="store_true")
     p.add_argument("--dist_url", default="env://")
     # additions
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="the reference tests in fp32")
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"], help="the reference tests in fp32")
     p.add_argument("--synthetic", default=0, type=int, help="evaluate N synthetic images instead of FSC147")
     p.add_argument("--group_images", default=8, type=int, help="images whose sliding windows share forward batches (up to 32 windows each)")
     return p

@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
+# the same sources built with IEEE fp16 as the 16-bit storage / matrix-operand type (precision="fp16"; csrc/common.hpp, build.py)
+LIB_PATH_F16 = os.environ.get("COUNTR_LIB_F16", os.path.join(_HERE, "libcountr_hip_f16.so"))
 
 F32, BF16 = 0, 1
 ABI_VERSION = 5
@@ -38,24 +40,30 @@ class GemmArgs(C.Structure):
     ]
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Load (once) and return the ctypes handle; raises CountrError if the library is not built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(variant=""):
+    """Load (once) and return the ctypes handle of a library variant ("" = bf16 build, "f16" = fp16 build); raises CountrError if it
+    is not built."""
+    L = _libs.get(variant)
+    if L is None:
+        path = LIB_PATH_F16 if variant == "f16" else LIB_PATH
+        if not os.path.exists(path):
             raise CountrError(
-                "libcountr_hip.so is not built (run `python -m countr_amd.build` or __graft_entry__.build()); "
-                "the HIP path has no CPU fallback")
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
-        if _lib.countr_version() != ABI_VERSION:      # a stale build: its countr_gemm_args is shorter than GemmArgs above
-            v = _lib.countr_version()
-            _lib = None
-            raise CountrError("libcountr_hip.so has ABI version %d, this package needs %d: rebuild (python -m countr_amd.build)" % (v, ABI_VERSION))
-    return _lib
+                "%s is not built (run `python -m countr_amd.build` or __graft_entry__.build()); "
+                "the HIP path has no CPU fallback" % os.path.basename(path))
+        L = C.CDLL(path)
+        _declare(L)
+        if L.countr_version() != ABI_VERSION:      # a stale build: its countr_gemm_args is shorter than GemmArgs above
+            raise CountrError("%s has ABI version %d, this package needs %d: rebuild (python -m countr_amd.build)"
+                              % (os.path.basename(path), L.countr_version(), ABI_VERSION))
+        _libs[variant] = L
+    return L
+
+
+def variant_of(precision):
+    return "f16" if precision == "fp16" else ""
 
 
 def _declare(L):
@@ -129,8 +137,8 @@ _RESTYPES = {"countr_xattn_bwd_workspace_floats": C.c_int64, "countr_groupnorm_b
 
 def check(rc, what=""):
     if rc != 0:
-        msg = lib().countr_last_error()
-        raise CountrError("%s failed (rc=%d): %s" % (what or "countr call", rc, msg.decode() if msg else ""))
+        msgs = [m.decode() for m in (L.countr_last_error() for L in _libs.values()) if m]      # (the error text is per library and thread)
+        raise CountrError("%s failed (rc=%d): %s" % (what or "countr call", rc, " | ".join(msgs)))
 
 
 def exported_symbols():

@@ -23,14 +23,15 @@ def _stream():
 
 
 class Runner:
-    """precision 'bf16': bf16 GEMM operands, fp32 accumulation, fp32 residual stream; 'fp32': exact-fp32 MFMA everywhere (parity)."""
+    """precision 'bf16' / 'fp16': 16-bit GEMM operands (the two builds of the library, _lib.variant_of), fp32 accumulation, fp32
+    residual stream; 'fp32': exact-fp32 MFMA everywhere (parity)."""
 
     def __init__(self, precision="bf16"):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
-        self.L = _lib.lib()
-        self.code = BF16 if precision == "bf16" else F32
-        self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
+        if precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+        self.L = _lib.lib(_lib.variant_of(precision))
+        self.code = BF16 if precision in ("bf16", "fp16") else F32
+        self.tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
 
     # ---- plumbing
     def check_input(self, *tensors, module=None):
@@ -49,14 +50,14 @@ class Runner:
         if self.code == F32:
             return p.detach().float().contiguous()
         src = p.detach().float().contiguous()
-        w = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+        w = torch.empty(src.shape, device=src.device, dtype=self.tdt)
         _lib.check(self.L.countr_cast_permute(src.data_ptr(), w.data_ptr(), src.numel(), 0, 0, 0, 0, BF16, _stream()), "cast")
         return w
 
     def to_operand(self, x_f32):
         if self.code == F32:
             return x_f32
-        y = torch.empty(x_f32.shape, device=x_f32.device, dtype=torch.bfloat16)
+        y = torch.empty(x_f32.shape, device=x_f32.device, dtype=self.tdt)
         _lib.check(self.L.countr_cast_permute(x_f32.data_ptr(), y.data_ptr(), x_f32.numel(), 0, 0, 0, 0, BF16, _stream()), "cast")
         return y
 
@@ -67,7 +68,7 @@ class Runner:
         N = lin.weight.shape[0]
         W = self.weight(lin.weight)
         f32 = out_f32 or resid is not None or self.code == F32
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if f32 else torch.bfloat16)
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if f32 else self.tdt)
         bias = lin.bias.detach().float().contiguous() if lin.bias is not None else None
         a = GemmArgs()
         a.alpha, a.nbatch, a.nb1, a.splitk = 1.0, 1, 1, 1
@@ -179,7 +180,7 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         W = r.weight(weight)
         f32 = out_f32 or r.code == F32
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if f32 else torch.bfloat16)
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if f32 else r.tdt)
         pre = torch.empty((M, N), device=x.device, dtype=out.dtype) if act == ACT_GELU else None
         b = bias.detach().float().contiguous() if bias is not None else None
         _gemm(r, OP_ROW, OP_ROW, A=x.data_ptr(), B=W.data_ptr(), C=out.data_ptr(), C2=pre.data_ptr() if pre is not None else None,
@@ -204,7 +205,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dx = torch.empty((M, K), device=x.device, dtype=x.dtype)
             _gemm(r, OP_ROW, OP_COL, A=dyt.data_ptr(), B=W.data_ptr(), C=dx.data_ptr(), lda=N, ldb=K, ldc=K, M=M, N=K, K=N,
-                  out_bf16=int(x.dtype == torch.bfloat16))
+                  out_bf16=int(x.dtype in (torch.bfloat16, torch.float16)))
         if ctx.needs_input_grad[2]:
             dW = torch.empty((N, K), device=x.device, dtype=torch.float32)
             _gemm(r, OP_COL, OP_COL, A=dyt.data_ptr(), B=x.data_ptr(), C=dW.data_ptr(), lda=N, ldb=K, ldc=K, M=N, N=K, K=M, out_bf16=0)
@@ -242,7 +243,7 @@ class LayerNormFn(torch.autograd.Function):
         dg, db = torch.empty(D, device=x.device, dtype=torch.float32), torch.empty(D, device=x.device, dtype=torch.float32)
         ws = torch.empty(r.L.countr_layernorm_bwd_nblocks() * 2 * D, device=x.device, dtype=torch.float32)
         _lib.check(r.L.countr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                            dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, D, int(dy.dtype == torch.bfloat16), 0, 0, None,
+                                            dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, D, int(dy.dtype in (torch.bfloat16, torch.float16)), 0, 0, None,
                                             _stream()), "countr_layernorm_bwd")
         return None, dx, dg, db, None
 
@@ -258,7 +259,7 @@ class SelfAttentionFn(torch.autograd.Function):
         dh = D // heads
         ctx.r, ctx.dims = r, (B, N, heads, D, dh)
         if r.code == BF16 and dh in (32, 64):
-            out = torch.empty((B * N, D), device=qkv.device, dtype=torch.bfloat16)
+            out = torch.empty((B * N, D), device=qkv.device, dtype=r.tdt)
             lse = torch.empty((B, heads, N), device=qkv.device, dtype=torch.float32)
             _lib.check(r.L.countr_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, heads, dh, dh ** -0.5, _stream()), "countr_attn_fwd")
             ctx.fused = True

@@ -3,17 +3,45 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// The 16-bit storage / matrix-operand type of the "half" paths.  One source, two libraries (countr_amd/build.py): libcountr_hip.so is
+// built with bfloat16 (precision="bf16", the throughput mode: 8 exponent bits, no loss scaling) and libcountr_hip_f16.so with
+// -DCOUNTR_HALF_FP16=1 = IEEE fp16 (precision="fp16": the reference's own autocast dtype -- torch.cuda.amp.autocast() defaults to fp16,
+// FSC_finetune_cross.py:273-275,286 -- 10 mantissa bits instead of 7; v_mfma_f32_*_f16 runs at the bf16 rate on gfx950).  `bf16_t` is the
+// raw 16-bit pattern in both; every conversion goes through the helpers below, every matrix instruction through COUNTR_MFMA_*.
+#ifndef COUNTR_HALF_FP16
+#define COUNTR_HALF_FP16 0
+#endif
+typedef uint16_t bf16_t;  // raw 16 bits (bfloat16, or fp16 in the COUNTR_HALF_FP16 build)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 #define WAVE 64
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+#if COUNTR_HALF_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;      // (the operand vector type of the fp16 MFMAs)
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;
+#define COUNTR_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define COUNTR_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define COUNTR_H16_ONE_PAIR 0x3c003c00u                              // {1.0, 1.0}
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// both halves of a packed pair (lo = bits 0..15)
+__device__ __forceinline__ void unpack2h(uint32_t w, float& lo, float& hi) {
+  const bf16x2_t h = __builtin_bit_cast(bf16x2_t, w);
+  lo = (float)h[0]; hi = (float)h[1];
+}
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-// fp32 -> bf16 round-to-nearest-even through the native conversion (one v_cvt_pk_bf16_f32 per pair on gfx950)
+#define COUNTR_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define COUNTR_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define COUNTR_H16_ONE_PAIR 0x3f803f80u
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ void unpack2h(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+#endif
+// fp32 -> 16-bit round-to-nearest-even through the native conversion (one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 per pair on gfx950)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
@@ -36,8 +64,8 @@ template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v
 }
 template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
   uint2 t = *reinterpret_cast<const uint2*>(p);
-  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  unpack2h(t.x, v[0], v[1]);
+  unpack2h(t.y, v[2], v[3]);
 }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) {
@@ -55,10 +83,10 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v
 }
 template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
   uint4 t = *reinterpret_cast<const uint4*>(p);
-  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-  v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-  v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  unpack2h(t.x, v[0], v[1]);
+  unpack2h(t.y, v[2], v[3]);
+  unpack2h(t.z, v[4], v[5]);
+  unpack2h(t.w, v[6], v[7]);
 }
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {

@@ -171,7 +171,7 @@ __device__ __forceinline__ void cwg_body(const CwgArgs& g, const int v) {
   f32x16_t accb;
 #pragma unroll
   for (int e = 0; e < 16; ++e) accb[e] = 0.f;
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR));
 
   Frag fr[4][4];   // [set = k-step][a0, a1, b0, b1]
 #if CWG_ABL == 2
@@ -190,14 +190,14 @@ __device__ __forceinline__ void cwg_body(const CwgArgs& g, const int v) {
 #if CWG_ABL == 1
 #define CWG_MM(SET, TM, TN) acc[TM][TN][(SET) * 4 + (TM) * 2 + (TN)] += (float)fr[SET][TM].lo[0] * (float)fr[SET][2 + TN].hi[1]
 #else
-#define CWG_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(fr[SET][TM]), frag_bits(fr[SET][2 + TN]), acc[TM][TN], 0, 0, 0)
+#define CWG_MM(SET, TM, TN) acc[TM][TN] = COUNTR_MFMA_32X32X16(frag_bits(fr[SET][TM]), frag_bits(fr[SET][2 + TN]), acc[TM][TN], 0, 0, 0)
 #endif
 #ifdef CWG_NOSB
 #define CWG_SB
 #else
 #define CWG_SB __builtin_amdgcn_sched_barrier(0)
 #endif
-#define CWG_BIAS(SET) if (mine) { accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bits(tmr ? fr[SET][1] : fr[SET][0]), ones, accb, 0, 0, 0); CWG_SB; }
+#define CWG_BIAS(SET) if (mine) { accb = COUNTR_MFMA_32X32X16(frag_bits(tmr ? fr[SET][1] : fr[SET][0]), ones, accb, 0, 0, 0); CWG_SB; }
   // MFMAs of set U with the reads of set R = k-step KK of the stage at a0 / a1 / b0 / b1 between them
 #define CWG_STEP_RD(U, R, KK) CWG_MM(U, 0, 0); CWG_SB; CWG_RD(R, 0, KK, a0); CWG_SB; CWG_MM(U, 0, 1); CWG_SB; CWG_RD(R, 2, KK, b0); CWG_SB; \
                               CWG_MM(U, 1, 0); CWG_SB; CWG_RD(R, 1, KK, a1); CWG_SB; CWG_MM(U, 1, 1); CWG_SB; CWG_RD(R, 3, KK, b1); CWG_SB; CWG_BIAS(U)

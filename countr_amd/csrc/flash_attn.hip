@@ -166,8 +166,11 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
         float dot = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          dot = __builtin_fmaf(__uint_as_float(dw[e] << 16), __uint_as_float(ow[e] << 16), dot);
-          dot = __builtin_fmaf(__uint_as_float(dw[e] & 0xffff0000u), __uint_as_float(ow[e] & 0xffff0000u), dot);
+          float dlo, dhi, olo, ohi;
+          unpack2h(dw[e], dlo, dhi);
+          unpack2h(ow[e], olo, ohi);
+          dot = __builtin_fmaf(dlo, olo, dot);
+          dot = __builtin_fmaf(dhi, ohi, dot);
         }
         dot += dpp_mov<0xB1>(dot);                          // lanes l ^ 1
         dot += dpp_mov<0x4E>(dot);                          // lanes l ^ 2
@@ -202,10 +205,10 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
       for (int st = 0; st < 4; ++st) {
         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(T1 + (st * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
         const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(T2 + (st * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
-        x1[st][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, r1[0][ks], x1[st][0], 0, 0, 0);
-        x1[st][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, r1[1][ks], x1[st][1], 0, 0, 0);
-        x2[st][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, r2[0][ks], x2[st][0], 0, 0, 0);
-        x2[st][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, r2[1][ks], x2[st][1], 0, 0, 0);
+        x1[st][0] = COUNTR_MFMA_16X16X32(a1, r1[0][ks], x1[st][0], 0, 0, 0);
+        x1[st][1] = COUNTR_MFMA_16X16X32(a1, r1[1][ks], x1[st][1], 0, 0, 0);
+        x2[st][0] = COUNTR_MFMA_16X16X32(a2, r2[0][ks], x2[st][0], 0, 0, 0);
+        x2[st][1] = COUNTR_MFMA_16X16X32(a2, r2[1][ks], x2[st][1], 0, 0, 0);
       }
 
     // ---- P and dS (x1 <- P, x2 <- dS); streamed index of element (st, reg) is t*64 + st*16 + g*4 + reg
@@ -258,8 +261,8 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
           s16x8_t vv;
           vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3]; vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
           const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, vv);
-          acc[0][dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf[0][ps], acc[0][dt][0], 0, 0, 0);
-          acc[0][dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf[1][ps], acc[0][dt][1], 0, 0, 0);
+          acc[0][dt][0] = COUNTR_MFMA_16X16X32(tf, dsf[0][ps], acc[0][dt][0], 0, 0, 0);
+          acc[0][dt][1] = COUNTR_MFMA_16X16X32(tf, dsf[1][ps], acc[0][dt][1], 0, 0, 0);
         }
         if (MODE == 1) {
           const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(T2 + off));
@@ -267,8 +270,8 @@ __device__ __forceinline__ void fa_bwd_body(char* smem, const int bid, const int
           s16x8_t vv;
           vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3]; vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
           const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, vv);
-          acc[NACC - 1][dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, pf[0][ps], acc[NACC - 1][dt][0], 0, 0, 0);
-          acc[NACC - 1][dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, pf[1][ps], acc[NACC - 1][dt][1], 0, 0, 0);
+          acc[NACC - 1][dt][0] = COUNTR_MFMA_16X16X32(tf, pf[0][ps], acc[NACC - 1][dt][0], 0, 0, 0);
+          acc[NACC - 1][dt][1] = COUNTR_MFMA_16X16X32(tf, pf[1][ps], acc[NACC - 1][dt][1], 0, 0, 0);
         }
       }
 

@@ -367,13 +367,13 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
         constexpr int j = J;
         fa_lds_wait<2 * KS - 1 - j>(f[j]);
         __builtin_amdgcn_sched_barrier(0);
-        SA[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], qf[j >> 1], SA[j & 1], 0, 0, 0);
+        SA[j & 1] = COUNTR_MFMA_32X32X16(f[j], qf[j >> 1], SA[j & 1], 0, 0, 0);
       });
     } else {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) SA[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(K0, blk, ks), qf[ks], SA[blk], 0, 0, 0);
+        for (int blk = 0; blk < 2; ++blk) SA[blk] = COUNTR_MFMA_32X32X16(kfrag(K0, blk, ks), qf[ks], SA[blk], 0, 0, 0);
     }
     if (RAGGED && T == 1) mask_tail(SA, 0);
     float mx = fmaxf(SA[0][0], SA[1][0]);
@@ -465,14 +465,14 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
             f32x16_t z;
 #pragma unroll
             for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], PRE ? negm : z, 0, 0, 0);
+            Sn[blk] = COUNTR_MFMA_32X32X16(fr[j], qf[ks], PRE ? negm : z, 0, 0, 0);
           } else {
-            Sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[ks], Sn[blk], 0, 0, 0);
+            Sn[blk] = COUNTR_MFMA_32X32X16(fr[j], qf[ks], Sn[blk], 0, 0, 0);
           }
         } else {
           constexpr int e = j - NQK, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
           if constexpr (ABL == 3) o[d][e] += __builtin_bit_cast(float, (int)fr[j][0] | ((int)pfrag(blk, s)[0] << 16));
-          else o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], pfrag(blk, s), o[d], 0, 0, 0);
+          else o[d] = COUNTR_MFMA_32X32X16(fr[j], pfrag(blk, s), o[d], 0, 0, 0);
         }
         constexpr int u0 = (j == 0) ? SC::PRE : SC::unit_end[j == 0 ? 0 : j - 1], u1 = SC::unit_end[j];
         if constexpr (ABL != 9) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
           constexpr int e = E, blk = e / (2 * DB), s = (e / DB) & 1, d = e % DB;
           fa_lds_wait<2 * (4 * DB - 1 - e)>(f[e]);
           __builtin_amdgcn_sched_barrier(0);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], pfrag(blk, s), o[d], 0, 0, 0);
+          o[d] = COUNTR_MFMA_32X32X16(f[e], pfrag(blk, s), o[d], 0, 0, 0);
           if constexpr (e < 2 * DB) {
             constexpr int per = 8 / (2 * DB);
 #pragma unroll
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
 #pragma unroll
           for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int d = 0; d < DB; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(V, blk, s, d), pfrag(blk, s), o[d], 0, 0, 0);
+            for (int d = 0; d < DB; ++d) o[d] = COUNTR_MFMA_32X32X16(vfrag(V, blk, s, d), pfrag(blk, s), o[d], 0, 0, 0);
       }
     }
   };

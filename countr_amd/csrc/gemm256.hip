@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
         acc[TM][TN][0] += __uint_as_float(a_[0] ^ b_[0]); acc[TM][TN][5] += __uint_as_float(a_[1] ^ b_[1]); \
         acc[TM][TN][10] += __uint_as_float(a_[2] ^ b_[2]); acc[TM][TN][15] += __uint_as_float(a_[3] ^ b_[3]); }
 #else
-#define G_MM(TM, TN, WF, XF) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF, XF, acc[TM][TN], 0, 0, 0)
+#define G_MM(TM, TN, WF, XF) acc[TM][TN] = COUNTR_MFMA_32X32X16(WF, XF, acc[TM][TN], 0, 0, 0)
 #endif
   // one output quadrant: rows half AH (wave-tile rows 64 AH + [0, 64)), column tile TN, fragments WF[kk] x xa[tm2][kk]
 #ifndef G256_ORDER

@@ -696,13 +696,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLD)) void gemm_kernel(const countr
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn)
-            acc[h * 4 + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][tn], xf[s & 1][tm], acc[h * 4 + tm][tn], 0, 0, 0);
+            acc[h * 4 + tm][tn] = COUNTR_MFMA_16X16X32(wf[kk][tn], xf[s & 1][tm], acc[h * 4 + tm][tn], 0, 0, 0);
 #endif
         if (do_rowsum) {  // wave-uniform: row sums of the M-side operand = bias gradient of a wgrad GEMM
-          const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+          const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR));
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm)
-            accb[h * 4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[s & 1][tm], accb[h * 4 + tm], 0, 0, 0);
+            accb[h * 4 + tm] = COUNTR_MFMA_16X16X32(ones, xf[s & 1][tm], accb[h * 4 + tm], 0, 0, 0);
         }
       };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;

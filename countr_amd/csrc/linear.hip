@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
         acc[TM][TN][0] += __uint_as_float(a_[0] ^ b_[0]); acc[TM][TN][5] += __uint_as_float(a_[1] ^ b_[1]); \
         acc[TM][TN][10] += __uint_as_float(a_[2] ^ b_[2]); acc[TM][TN][15] += __uint_as_float(a_[3] ^ b_[3]); }
 #else
-#define LIN_MM(SET, TM, TN) acc[TM][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[SET][2 + TN], fr[SET][TM], acc[TM][TN], 0, 0, 0)
+#define LIN_MM(SET, TM, TN) acc[TM][TN] = COUNTR_MFMA_32X32X16(fr[SET][2 + TN], fr[SET][TM], acc[TM][TN], 0, 0, 0)
 #endif
 #define LIN_SB __builtin_amdgcn_sched_barrier(0)
   // MFMAs of set U with the four reads of set R (addresses xa / wa) between them
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
 #define LIN_MM2(SET, TN) { const u32x4_t a_ = __builtin_bit_cast(u32x4_t, fr[SET][2 + TN]), b_ = __builtin_bit_cast(u32x4_t, fr2[SET]); \
         acc[TM - 1][TN][0] += __uint_as_float(a_[0] ^ b_[0]); acc[TM - 1][TN][7] += __uint_as_float(a_[2] ^ b_[3]); }
 #else
-#define LIN_MM2(SET, TN) acc[TM - 1][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[SET][2 + TN], fr2[SET], acc[TM - 1][TN], 0, 0, 0)
+#define LIN_MM2(SET, TN) acc[TM - 1][TN] = COUNTR_MFMA_32X32X16(fr[SET][2 + TN], fr2[SET], acc[TM - 1][TN], 0, 0, 0)
 #endif
 #define LIN_STEP6(U) LIN_MM(U, 0, 0); LIN_MM(U, 0, 1); LIN_MM(U, 1, 0); LIN_MM(U, 1, 1); LIN_MM2(U, 0); LIN_MM2(U, 1); LIN_SB
 #ifdef LIN_STAMP   // s_memtime anatomy (tools/stamp_lin.py): loaders [1] load wait [2] barrier [3] DMA issue; compute waves [2] barrier
@@ -531,8 +531,10 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
           const u32x4_t h = *reinterpret_cast<const u32x4_t*>(g.C2 + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            p[e][0] *= gelu_fast_grad(__uint_as_float(h[e] << 16));
-            p[e][1] *= gelu_fast_grad(__uint_as_float(h[e] & 0xffff0000u));
+            float hlo, hhi;
+            unpack2h(h[e], hlo, hhi);
+            p[e][0] *= gelu_fast_grad(hlo);
+            p[e][1] *= gelu_fast_grad(hhi);
           }
         }
         if constexpr (EPI == EPI_GELU) {

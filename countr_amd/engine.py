@@ -21,6 +21,8 @@ import torch
 from . import _lib
 from ._lib import F32, BF16, OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL, ACT_NONE, ACT_GELU, ACT_GELU_BWD, GemmArgs
 
+HALF_DTYPES = (torch.bfloat16, torch.float16)      # the 16-bit storage types (dtype code BF16 on the C side: one per library build)
+
 ALIGN = 64  # elements; every tensor starts on a 256-byte boundary of the flat buffers
 
 
@@ -156,7 +158,7 @@ class Engine:
         """cfg = (patch, embed_dim, depth, heads, dec_dim, dec_depth, dec_heads); ln_eps: eps of the model's norm_layer (the
         reference factories pass partial(nn.LayerNorm, eps=1e-6), models_mae_cross.py:210-239)."""
         self.ln_eps = float(ln_eps)
-        self.L = _lib.lib()
+        self.L = _lib.lib(_lib.variant_of(precision))
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.CountrError("the CounTR HIP engine needs a GPU device (no CPU fallback)")
@@ -169,11 +171,15 @@ class Engine:
         self.img = img_size
         self.grid = img_size // self.patch
         self.N = self.grid * self.grid
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.precision = precision
-        self.code = BF16 if precision == "bf16" else F32
-        self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
+        # 'bf16' (throughput mode) and 'fp16' (the reference's autocast dtype, FSC_finetune_cross.py:273-275,286: three more mantissa
+        # bits, same MFMA rate) run the SAME 16-bit code paths -- the dtype code BF16 means "16-bit storage" -- from two builds of the
+        # library that differ in the conversions and the matrix instruction's operand type (_lib.variant_of, csrc/common.hpp)
+        self.half = precision in ("bf16", "fp16")
+        self.code = BF16 if self.half else F32
+        self.tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
         self.attention = attention
         self.layout = self._make_layout(named_shapes)
         lay = self.layout
@@ -181,7 +187,7 @@ class Engine:
         self.G = torch.zeros(lay.n_train, device=self.device, dtype=torch.float32)
         self.M = None  # AdamW state, allocated on first optimizer use
         self.V = None
-        self.Wt = self.P if precision == "fp32" else torch.zeros(lay.total, device=self.device, dtype=torch.bfloat16)
+        self.Wt = self.P if precision == "fp32" else torch.zeros(lay.total, device=self.device, dtype=self.tdt)
         # permuted conv-weight shadows: OHWI for the forward/wgrad implicit GEMM, "dgrad form" for dgrad
         self.conv_names = self._conv_names()
         self.Wf, self.Wd = {}, {}
@@ -193,20 +199,20 @@ class Engine:
         # kernel (linear.hip) like the forward -- ~4 us per launch against the (ROW, COL) form on gemm_kernel; written by the shadow
         # launch that follows AdamW
         self.WtT = {}
-        if precision == "bf16" and self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
+        if self.half and self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
             for n in lay.train_names:
                 shp = lay.shapes[n]
                 if n.startswith("decoder_blocks.") and n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
-                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
+                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=self.tdt)
         # MAE pretraining (every Linear trains and has an input gradient): all 82 transposes = 222 MB, refreshed in three shadow launches
         # behind AdamW.  Round 3 measured this as a loss at 8 images (8.40 against 8.12 ms: the transposes cost 376 us, more than the
         # (ROW, ROW) launches saved at M = 2304); with round 4's 64x64-tile transposes and the warm-up hints -- which only the (ROW, ROW)
         # kernels honour -- it is neutral at 8 images (7.82 vs 7.80 ms) and a gain at config 4's 16: 10.79 -> 10.55 ms (two A/B pairs)
-        elif precision == "bf16" and not self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
+        elif self.half and not self.FROZEN_ENCODER and os.environ.get("COUNTR_LEAN", "1") != "0":
             for n in lay.train_names:
                 shp = lay.shapes[n]
                 if n.endswith(".weight") and len(shp) == 2 and shp[0] % 128 == 0 and shp[1] % 128 == 0:
-                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=torch.bfloat16)
+                    self.WtT[n] = torch.zeros(math.prod(shp), device=self.device, dtype=self.tdt)
         self.plans = {}
         self.hyper = torch.zeros(8, device=self.device, dtype=torch.float32)   # {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1], bc1[2], bc2[2]}
         self.step_count = 0
@@ -214,13 +220,13 @@ class Engine:
         self.opt_seen = set()           # conditional gradient buckets (2, 3) that have had a gradient at least once
         self.gnorm = None               # device fp32 [countr_adamw_gnorm_floats()]: [0] = gradient L2 norm of the last step
         # frozen-encoder q projection packed pre-scaled for the attention kernel (see _pack_prescaled_q)
-        self.prescale_q = (self.FROZEN_ENCODER and precision == "bf16" and attention != "unfused" and self.D // self.H == 64
+        self.prescale_q = (self.FROZEN_ENCODER and self.half and attention != "unfused" and self.D // self.H == 64
                            and self.N % 64 == 0)
         self.qkv_bias_pre = None
         # frozen encoder, bf16: norm1 / norm2 are folded into the qkv / fc1 layers (gamma into the packed weights, beta into the bias;
         # the proj / fc2 / patch-embed epilogues emit the bf16 operand + 64-column row partials, the qkv / fc1 epilogues apply mean and
         # rstd -- _pack_prescaled_q, _build): 24 LayerNorm launches and their 0.5 GB of traffic per step gone.  COUNTR_LN_FOLD=0 disables.
-        self.ln_fold = (self.FROZEN_ENCODER and precision == "bf16" and self.D % 128 == 0 and os.environ.get("COUNTR_LN_FOLD", "1") != "0"
+        self.ln_fold = (self.FROZEN_ENCODER and self.half and self.D % 128 == 0 and os.environ.get("COUNTR_LN_FOLD", "1") != "0"
                         and os.environ.get("COUNTR_LEAN", "1") != "0")
         self.fc1_bias_pre = self.ln_c_qkv = self.ln_c_fc1 = None
         self._ws = {}
@@ -274,7 +280,7 @@ class Engine:
         """Refresh the low-precision / permuted shadows from the fp32 master buffer."""
         st = self._stream() if stream is None else stream
         L, lay = self.L, self.layout
-        if self.precision == "bf16":
+        if self.half:
             lo = lay.train_start if trainable_only else 0
             _lib.check(L.countr_cast_permute(self.P.data_ptr() + 4 * lo, self.Wt.data_ptr() + 2 * lo, lay.total - lo, 0, 0, 0, 0,
                                              BF16, st), "cast")
@@ -310,14 +316,14 @@ class Engine:
                 Wf, bf = W.clone(), bias.clone()
             Wf[:D] *= c
             bf[:D] *= c
-            self.Wt[ow:ow + 3 * D * D].copy_(Wf.reshape(-1).to(torch.bfloat16))
+            self.Wt[ow:ow + 3 * D * D].copy_(Wf.reshape(-1).to(self.tdt))
             self.qkv_bias_pre[i].copy_(bf)
             if self.ln_fold:
                 self.ln_c_qkv[i].copy_(self.Wt[ow:ow + 3 * D * D].view(3 * D, D).float().sum(1))
                 W1, b1 = view(b + "mlp.fc1.weight", 4 * D, D), view(b + "mlp.fc1.bias", 4 * D)
                 g2, be2 = view(b + "norm2.weight", D), view(b + "norm2.bias", D)
                 o1 = lay.off[b + "mlp.fc1.weight"]
-                self.Wt[o1:o1 + 4 * D * D].copy_((W1 * g2[None, :]).reshape(-1).to(torch.bfloat16))
+                self.Wt[o1:o1 + 4 * D * D].copy_((W1 * g2[None, :]).reshape(-1).to(self.tdt))
                 self.fc1_bias_pre[i].copy_(b1 + W1 @ be2)
                 self.ln_c_fc1[i].copy_(self.Wt[o1:o1 + 4 * D * D].view(4 * D, D).float().sum(1))
 
@@ -499,7 +505,7 @@ class Engine:
     def _linear(self, ops, x, wname, out, M, N, K, act=ACT_NONE, resid=None, res_mod=0, out_bf16=None, pre=None, bias=True, bias_ptr=None, **ln):
         """**ln: the LayerNorm-folding fields of countr_gemm_args (ln_xcopy / ln_stats_out for a producer, ln_stats / ln_colsum /
         ln_nblk / ln_eps for a consumer)."""
-        out_bf16 = (out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        out_bf16 = (out.dtype in HALF_DTYPES) if out_bf16 is None else out_bf16
         self._gemm(ops, self.code, OP_ROW, OP_ROW, A=x.data_ptr(), B=self._wp(wname), C=out.data_ptr(), **ln,
                    C2=(pre.data_ptr() if pre is not None else None),
                    bias=(bias_ptr if bias_ptr is not None else (self._pp(wname[:-6] + "bias") if bias else None)),
@@ -644,7 +650,7 @@ class Engine:
         in the GEMM's epilogue where the lean kernel serves the launch (bf16, transposed shadow), otherwise as a separate pass.
         (Measured, profiles/r4_gelu_bwd_fuse_ab.txt: the derivative costs the GEMM's epilogue 6.6-10.9 us -- 2 transcendentals + 15 VALU per
         element with the matrix pipes idle -- against 8-12 us for the separate bandwidth-bound pass: 20 launches fewer, ~1 us each saved.)"""
-        out_bf16 = (dx.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        out_bf16 = (dx.dtype in HALF_DTYPES) if out_bf16 is None else out_bf16
         if wname in self.WtT:      # W^T [K][N]: (ROW, ROW), the lean kernel
             fuse = gelu_pre is not None and self.code == BF16 and out_bf16 and resid is None
             self._gemm(ops, self.code, OP_ROW, OP_ROW, A=dy.data_ptr(), B=self.WtT[wname].data_ptr(), C=dx.data_ptr(),
@@ -682,7 +688,7 @@ class Engine:
     def _layernorm(self, ops, x, name, y, rows, D, mean=None, rstd=None):
         self._op(ops, self.L.countr_layernorm_fwd, x.data_ptr(), self._pp(name + ".weight"), self._pp(name + ".bias"), y.data_ptr(),
                  mean.data_ptr() if mean is not None else None, rstd.data_ptr() if rstd is not None else None, rows, D, self.ln_eps,
-                 int(y.dtype == torch.bfloat16))
+                 int(y.dtype in HALF_DTYPES))
 
     def _layernorm_bwd(self, ops, dy, x, name, mean, rstd, dx, rows, D, accumulate, dx_t=None):
         """dx_t (bf16 mode): also emit the updated residual gradient as the bf16 operand of the next backward GEMM."""
@@ -694,7 +700,7 @@ class Engine:
         self._claim(ws.data_ptr())
         self._op(ops, self.L.countr_layernorm_bwd, dy.data_ptr(), x.data_ptr(), self._pp(name + ".weight"), mean.data_ptr(),
                  rstd.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), rows, D,
-                 int(dy.dtype == torch.bfloat16), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
+                 int(dy.dtype in HALF_DTYPES), int(accumulate), 0, dx_t.data_ptr() if dx_t is not None else None)
         self._reduce_later(ops, ws.data_ptr(), ws.data_ptr(), self._gp(name + ".weight"), nb, 2 * D, D)
         self._reduce_later(ops, ws.data_ptr(), ws.data_ptr() + 4 * D, self._gp(name + ".bias"), nb, 2 * D, D)
         return dx if self.code == F32 else dx_t
@@ -777,10 +783,10 @@ class Engine:
             part = self._shared("actsk", sk * M * Cout)
             self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), partial=part.data_ptr(), ldb=K, ldc=Cout,
                        M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, splitk=sk)
-            self._op(ops, self.L.countr_splitk_finish, part.data_ptr(), out.data_ptr(), bias_ptr, sk, M, Cout, int(out.dtype == torch.bfloat16))
+            self._op(ops, self.L.countr_splitk_finish, part.data_ptr(), out.data_ptr(), bias_ptr, sk, M, Cout, int(out.dtype in HALF_DTYPES))
             return
         self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), C=out.data_ptr(), bias=bias_ptr,
-                   ldb=K, ldc=Cout, M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, out_bf16=int(out.dtype == torch.bfloat16))
+                   ldb=K, ldc=Cout, M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, out_bf16=int(out.dtype in HALF_DTYPES))
 
     def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout, bias_name=None):
         bk = 64 if self.code == BF16 else 32
@@ -1247,7 +1253,7 @@ class Engine:
         if gnorm and self.gnorm is None:
             self.gnorm = torch.zeros(self.L.countr_adamw_gnorm_floats(), device=self.device, dtype=torch.float32)
         lay = self.layout
-        shadow = (self.Wt.data_ptr() + 2 * lay.train_start) if self.precision == "bf16" else None
+        shadow = (self.Wt.data_ptr() + 2 * lay.train_start) if self.half else None
         _lib.check(self.L.countr_adamw_step(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                             shadow, n, starts, ends, wds, groups, zeros, lr, betas[0], betas[1], eps, step, grad_scale,
                                             hyper_dev.data_ptr() if hyper_dev is not None else None,

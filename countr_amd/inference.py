@@ -83,8 +83,8 @@ def _native_maps(model, images, boxes, shot_num, max_batch, want_sums):
                    or not im.is_contiguous() for im in images)):
         return None
     dev = images[0].device
-    L = _lib.lib()
     eng = model._engine()
+    L = eng.L
     nb = _bucket(len(plan), max_batch)
     p = eng.plan(nb, shot_num, False)
     img = p.buf["img"]

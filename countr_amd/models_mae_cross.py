@@ -5,8 +5,9 @@ The nn.Modules below are parameter containers; forward() packs the parameters in
 buffers (views, no copies afterwards) and runs hand-written HIP kernels through libcountr_hip.so.  There
 is no CPU fallback: calling forward without the built library or without a GPU raises.
 
-Extra (non-reference) constructor keyword: precision = "bf16" (default; bf16 operands, fp32 accumulation,
-statistics and residual stream) or "fp32" (exact-f32 MFMA parity mode).
+Extra (non-reference) constructor keyword: precision = "bf16" (default, the throughput mode: bf16 operands, fp32 accumulation,
+statistics and residual stream), "fp16" (the reference-numerics mode: the reference's own autocast dtype, FSC_finetune_cross.py:273-275,286
+-- same kernels built with fp16 operands, 8x smaller operand rounding, same MFMA rate) or "fp32" (exact-f32 MFMA parity mode).
 """
 from functools import partial
 

@@ -2,7 +2,7 @@
 
 Same constructor, factories, state_dict keys and forward(imgs, mask_ratio) -> (loss, pred, mask) as the reference; the
 nn.Modules are parameter containers and all math runs in libcountr_hip.so (countr_amd/mae_engine.py).  GPU only, no CPU
-fallback.  Extra keyword: precision = "bf16" (default) | "fp32".
+fallback.  Extra keyword: precision = "bf16" (default) | "fp16" | "fp32".
 """
 from functools import partial
 

@@ -128,6 +128,12 @@ class _GraphStep:
         self.pro = _Prologue(self.eng, mask_seed)
         self._draw_mask = False
         self.grad_scale = 1.0 / self.accum
+        # fp16 mode: the loss gradient is multiplied by a constant before the 16-bit backward and divided out again inside the fused
+        # AdamW (its grad_scale scalar) -- the reference's GradScaler (util/misc.py:260-286) with its INITIAL scale 65536 held fixed:
+        # dL/dout of this loss is ~1e-9 per pixel (2 (out - gt) / (384^2 B)), far below fp16's normal range, and at most ~2e-5, so
+        # 2^16 cannot overflow.  Not reproduced: GradScaler's skip-and-halve on a non-finite gradient (the CLI stops on a non-finite
+        # loss instead).  bf16 / fp32: 1.
+        self.loss_scale = 65536.0 if self.eng.precision == "fp16" else 1.0
 
     def _make_sync(self, process_group):
         return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
@@ -309,7 +315,7 @@ class _GraphStep:
                 eng.group_steps[grp] += 1
         h = self.pro.hyper
         h[0] = self.lr
-        h[3] = self.grad_scale / self.world
+        h[3] = self.grad_scale / self.world / self.loss_scale
         for grp, (i1, i2) in enumerate(((1, 2), (4, 5), (6, 7))):
             t = max(eng.group_steps[grp], 1)
             h[i1] = 1.0 - self.betas[0] ** t
@@ -553,7 +559,7 @@ class FinetuneStep(_GraphStep):
         sums = self.sums[S]
         HW = eng.img * eng.img
         _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
-                                           sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0, eng._stream()), "masked_mse")
+                                           sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, float(self.loss_scale), eng._stream()), "masked_mse")
         eng.run(self._lists(p, acc).bwd_head)
 
     def _prologue_mask(self):
@@ -707,7 +713,7 @@ class PretrainStep(_GraphStep):
         p = eng.plan(self.B, K, True)
         self._prologue_launch()
         eng.run(p.fwd)
-        eng.loss_launch(p, self.B, self.model.norm_pix_loss)
+        eng.loss_launch(p, self.B, self.model.norm_pix_loss, grad_scale=float(self.loss_scale))
         eng.run(self._lists(p, acc).bwd_dec)
 
     def _make_sync(self, process_group):

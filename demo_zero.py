@@ -54,7 +54,7 @@ def main():
     p.add_argument("--output_path", type=Path, default="results")
     p.add_argument("--model_path", type=str, default="weights/FSC147.pth")
     p.add_argument("--group_images", type=int, default=8, help="images whose windows share one forward (8 x 1920x1080 = 32 windows)")
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--no_viz", action="store_true", help="counts only, no viz_*.jpg")
     args = p.parse_args()
     args.output_path.mkdir(exist_ok=True, parents=True)

@@ -48,6 +48,11 @@ def bf16_model():
     return build("bf16")
 
 
+@pytest.fixture(scope="module")
+def fp16_model():
+    return build("fp16")
+
+
 CASES = ["b2_s3", "b1_s0", "b1_s1", "b1_s2", "b1_zero_empty"]
 
 
@@ -295,3 +300,61 @@ def test_gradients_with_ten_exemplars_match_oracle():
         assert (got - ref).norm().item() <= 2e-3 * ref.norm().item(), (k, (got - ref).norm().item(), ref.norm().item())
         checked += 1
     assert checked >= 40
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_fp16_within_the_reference_amp_noise(fp16_model, name):
+    """precision="fp16": the reference's OWN mixed-precision dtype (torch.cuda.amp.autocast() defaults to fp16: FSC_finetune_cross.py:
+    273-275,286; util/misc.py:260-286) -- 16-bit operands with 10 mantissa bits instead of bf16's 7, the same MFMA rate (the second
+    build of the library, csrc/common.hpp).  Bars = what the reference's own low-precision autocast measures against its fp32
+    forward (1.8e-2 max-rel, 0.8 % count) -- INCLUDING shot_num 0, where the bf16 mode needs 6 %."""
+    m, _ = fp16_model
+    g = np.load(os.path.join(G, "forward.npz"))
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    im, bx, s = case_inputs(name)
+    with torch.no_grad():
+        out = m(torch.from_numpy(im).cuda(), torch.from_numpy(bx).cuda(), s).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert rel(out, g[name]) < 1.8e-2, rel(out, g[name])
+    cnt = out.reshape(out.shape[0], -1).sum(1) / 60
+    ref = np.array(meta["count_" + name])
+    print(name, "max-rel %.2e" % rel(out, g[name]), "count err %.2e" % (np.abs(cnt - ref) / ref).max())
+    assert (np.abs(cnt - ref) / ref).max() < 1e-2, (cnt, ref)
+
+
+@pytest.mark.parametrize("S,seed", [(3, 3), (0, 2)])
+def test_fp16_step_gradients_close_to_oracle(S, seed):
+    """FinetuneStep in fp16 mode (B = 8, static loss scale 2^16 folded back inside the fused AdamW): loss and every trainable tensor's
+    gradient (flat buffer / loss scale) against the fp32 oracle -- tighter than the bf16 bars of test_bf16_gradients_close_to_oracle:
+    every decoder-side tensor cos >= 0.9999, the exemplar CNN >= 0.995 (bf16: 0.979-0.990)."""
+    from countr_amd.trainer import FinetuneStep
+    m, sd = build("fp16")
+    m.train()
+    B = 8
+    step = FinetuneStep(m, batch=B, lr=1e-5, use_graph=True)
+    assert step.loss_scale == 65536.0
+    imgs, boxes, gt, mask = W.make_inputs(batch=B, shots=3, seed=seed)
+    step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), S)
+    sums = step.step(S).clone()
+    gn = step.grad_norm().item()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    _, rloss, rg = R.loss_and_grads(sd, imgs, boxes, gt, mask, S, MODEL)
+    assert abs(sums[0].item() - rloss.item()) / rloss.item() < 2e-3
+    checked, tot = 0, 0.0
+    for k, ref in rg.items():
+        if ref is None or ref.norm() < 1e-3:
+            continue
+        ref = ref.double()
+        tot += float((ref ** 2).sum())
+        got = step.eng.gview(k).detach().cpu().double() / step.loss_scale
+        assert torch.isfinite(got).all(), k
+        cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
+        ratio = (got.norm() / ref.norm()).item()
+        if k.startswith("decoder_proj"):
+            assert cos > 0.995 and abs(ratio - 1) < 0.01, (k, cos, ratio)
+        else:
+            assert cos > (0.9999 if S else 0.999) and abs(ratio - 1) < (0.005 if S else 0.02), (k, cos, ratio)
+        checked += 1
+    assert checked >= (50 if S == 0 else 55)
+    assert abs(gn - tot ** 0.5) <= 1e-2 * tot ** 0.5, (gn, tot ** 0.5)       # the logged gradient norm is unscaled (util/misc.py:289-301)
