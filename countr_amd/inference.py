@@ -85,6 +85,7 @@ def _native_maps(model, images, boxes, shot_num, max_batch, want_sums):
     dev = images[0].device
     eng = model._engine()
     L = eng.L
+    eng.check_ln_fold(images[plan[0][0]][:, :, :, plan[0][1]:plan[0][1] + 384])     # (first use of a weight set only: may rebuild the plans)
     nb = _bucket(len(plan), max_batch)
     p = eng.plan(nb, shot_num, False)
     img = p.buf["img"]

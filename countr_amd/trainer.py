@@ -636,6 +636,7 @@ class FinetuneStep(_GraphStep):
         else:
             imgs, boxes, gt, mask = self._to_device((imgs, boxes, gt, mask))
         with torch.cuda.stream(self.stream):
+            self.eng.check_ln_fold(imgs)             # (first batch behind a weight load only: the LayerNorm-fold guard, engine.py)
             p = self.eng.plan(self.B, S, True)
             self._pending = None
             if not self._load_fused(p, imgs, boxes, gt, mask, S, keep=src):
