@@ -24,6 +24,11 @@ ATT_FLOP_PER_IMG_LAYER = 4 * 576 * 576 * 64 * 12  # 4 N^2 dh H = 1.0192 GF
 MFMA_BF16_PEAK = 2.5e15
 
 
+def _sha(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
 def cpu_baseline(batch=4, steps=4, threads=None):
     """The oracle (CPU restatement of the reference, validated against it) timed on this host's cores.
     Threads are capped at 32: torch-CPU on all 256 hardware threads of the GPU box is ~100x slower (oversubscription)."""
@@ -163,13 +168,14 @@ def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=Tr
     b2b = e0.elapsed_time(e1) * 1e3 / iters
     achieved = ATT_FLOP_PER_IMG_LAYER * batch / (us * 1e-6)
     traffic, traffic_source = None, None
-    for rnd in ("r4", "r3", "r2"):   # HBM/fabric bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md), NOT this run
+    for rnd in ("r5", "r4", "r3", "r2"):   # HBM/fabric bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md), NOT this run
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "%s_attention_traffic.json" % rnd)))
+            path = os.path.join(ROOT, "profiles", "%s_attention_traffic.json" % rnd)
+            t = json.load(open(path))
             if batch == 8:
                 traffic = t["bytes_per_launch"]
-                traffic_source = "static: profiles/%s_attention_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over " \
-                                 "the eager step), not measured in this run" % rnd
+                traffic_source = "static: profiles/%s_attention_traffic.json (sha256 %s; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate " \
+                                 "passes over the eager step), not measured in this run" % (rnd, _sha(path))
             break
         except Exception:  # noqa: BLE001
             continue
@@ -286,19 +292,24 @@ def family_breakdown(model, step, batch, passes=5):
         extra = (a.M * a.N * 4 if a.resid else 0) + (a.M * a.N * 2 if (a.C2 and a.act == 1) else 0)
         alg[f] += bytes_a + bytes_b + bytes_c + extra
         nl[f] += 1
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r4_family_traffic.json")))
-    except Exception:  # noqa: BLE001
-        pass
+    traffic, tpath = None, None
+    for rnd in ("r5", "r4"):
+        try:
+            tpath = os.path.join(ROOT, "profiles", "%s_family_traffic.json" % rnd)
+            traffic = json.load(open(tpath))
+            break
+        except Exception:  # noqa: BLE001
+            continue
     for k in ("linear", "conv"):
         out[k]["algorithmic_bytes"] = alg[k]
         out[k]["gemm_launches"] = nl[k]
         t = (traffic or {}).get(k) if batch == 8 else None
         out[k]["traffic"] = t["traffic_bytes_per_step"] if t else None
         out[k]["traffic_over_algorithmic"] = (t["traffic_bytes_per_step"] / alg[k]) if t else None
-        out[k]["traffic_source"] = ("static: profiles/r4_family_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over the eager "
-                                    "step, tools/pmc_step.sh: per step, all launches of the family), not measured in this run") if t else None
+        out[k]["traffic_source"] = ("static: profiles/%s (sha256 %s, collected on HEAD %s%s; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                    "passes over the eager step, tools/pmc_step.sh: per step, all launches of the family), not measured in this run"
+                                    % (os.path.basename(tpath), _sha(tpath), traffic.get("collected_on_head") or "unrecorded (round 4 file)",
+                                       " + uncommitted changes" if traffic.get("tree_dirty") else "")) if t else None
     return out
 
 

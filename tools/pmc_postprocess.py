@@ -1,6 +1,6 @@
 """Turns the counter groups of tools/pmc_step.sh (gpurun_out/<tag>_pmc_groups.json) into the round's evidence files:
 profiles/<tag>_family_traffic.json (read by bench.py into roofline_families.{linear,conv}.traffic), <tag>_linear_pmc.txt, <tag>_conv_pmc.txt,
-<tag>_attention_pmc.txt, <tag>_attention_traffic.json.  usage: python tools/r4_postprocess.py [tag] [algorithmic bytes json from the bench line]
+<tag>_attention_pmc.txt, <tag>_attention_traffic.json.  usage: python tools/pmc_postprocess.py [tag] [algorithmic bytes json from the bench line]
 
 traffic = FETCH_SIZE x 2 + WRITE_SIZE (KB): gfx950's rocprofv3 tallies the 128-byte requests of wide coalesced reads at 64 B
 (MI355X_MICROARCH.md, section HBM); the two counters come from separate passes.  They count requests on the L2's memory side, i.e.
@@ -44,7 +44,7 @@ def table(fam, path, title):
         f.write(title + "\n")
         f.write("source: bash tools/pmc_step.sh %s  (rocprofv3 --kernel-trace --pmc <group>, four separate passes over `python bench.py --steps 3 "
                 "--warmup 2 --reps 1 --no-graph --plain`: every launch belongs to a headline step; %d steps profiled), summarised by "
-                "tools/pmc_report.py + tools/r4_postprocess.py\n" % (tag, nsteps))
+                "tools/pmc_report.py + tools/pmc_postprocess.py\n" % (tag, nsteps))
         f.write("traffic = FETCH_SIZE x 2 + WRITE_SIZE (fabric side of the L2: Infinity-Cache hits included); mfma% = SQ_VALU_MFMA_BUSY_CYCLES / "
                 "SQ_BUSY_CYCLES / 32; wait% / stall% = SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES; ldscf% = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n")
         f.write("family total: %.1f MB of traffic per step in %.1f launches\n\n" % (tot / MB, sum(g["n"] for g in sel) / nsteps))
@@ -74,10 +74,14 @@ if len(sys.argv) > 2:
     line = json.load(open(sys.argv[2]))
     for k in ("linear", "conv"):
         alg[k] = line["roofline_families"][k].get("algorithmic_bytes")
-fam = {"source": "tools/pmc_step.sh %s + tools/r4_postprocess.py: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the eager "
+fam = {"source": "tools/pmc_step.sh %s + tools/pmc_postprocess.py: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the eager "
                  "finetune step (bench.py --plain --no-graph), all launches of the family per step; traffic = FETCH_SIZE x 2 + WRITE_SIZE" % tag,
-       "steps_profiled": nsteps}
+       "steps_profiled": nsteps,
+       "collected_on_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None,
+       "tree_dirty": bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "countr_amd", "bench.py"], capture_output=True, text=True).stdout.strip())}
 for k, (tot, nl) in (("linear", lin), ("conv", conv), ("attention", att)):
+    if not isinstance(fam.get(k, {}), dict):
+        continue
     fam[k] = {"traffic_bytes_per_step": tot, "launches_per_step": nl}
     if alg.get(k):
         fam[k]["algorithmic_bytes_per_step"] = alg[k]
