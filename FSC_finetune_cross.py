@@ -89,7 +89,8 @@ def main(args):
         args.lr = args.blr * eff_batch / 256     # :218-221
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95),
-                        accum_iter=args.accum_iter, per_rank_shot=args.per_rank_shot, mask_seed=seed)   # seed = args.seed + rank (:168)
+                        accum_iter=args.accum_iter, per_rank_shot=args.per_rank_shot, mask_seed=seed,   # seed = args.seed + rank (:168)
+                        defer_optimizer=True)
     if ckpt is not None and args.do_resume and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:415: all three, else skipped
         # (raises when the entry EXISTS and fits neither this model's torch.optim.AdamW layout nor the older flat form: continuing late
         # in the LR schedule with zeroed moments would be a silent restart of the bias correction)
@@ -171,6 +172,7 @@ def main(args):
                                           "batch_MAE": float(np.abs(s[1:1 + B] - s[1 + B:1 + 2 * B]).mean()),
                                           "grad_norm": float(gn.item()) if gn is not None else None}))
         # ---- evaluation on the validation split (:329-350): no_grad forward, shot_num drawn per batch, MAE / RMSE / NAE of the counts
+        step.flush()       # defer_optimizer: the epoch's last update is applied before anything reads the parameters (validation, checkpoint)
         val = evaluate(model, val_loader, n_val, B, device, val_rng, seed, epoch)
         train_mae, train_mse = (train_acc / n_iter).tolist()
         opt_state = step.optimizer_state()

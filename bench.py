@@ -58,6 +58,7 @@ def parity_check(model, step, world, rank, B, NB, dev):
     exemplar CNN 0.97) and norm (1.5 % / 2 %): the bars of tests/test_trainer_gpu.py::test_finetune_step_at_the_real_config_matches_oracle.
     Raises on a miss; returns the dict reported as `parity` in the JSON line."""
     from countr_amd.synthetic import make_batch
+    step.flush()                                    # (defer_optimizer: the parameters the checked step starts from)
     cur = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
     imgs, boxes, gt, mask = make_batch(B, shots=3, seed=rank * NB, device=dev)
     with step.on_stream():
@@ -87,7 +88,7 @@ def parity_check(model, step, world, rank, B, NB, dev):
     for k, ref in total.items():
         if ref.norm() < 1e-3:
             continue
-        got = step.eng.gview(k).detach().cpu().double()
+        got = step.eng.gview(k).detach().cpu().double() / step.loss_scale       # (fp16 mode: the flat buffer holds loss_scale x gradient)
         cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
         ratio = (got.norm() / ref.norm()).item()
         if k.startswith("decoder_proj"):
@@ -477,6 +478,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-defer", action="store_true", help="optimizer update at the tail of its own step instead of beside the next step's "
+                                                            "frozen-encoder forward (FinetuneStep(defer_optimizer=False))")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step (it runs outside the timed regions)")
     ap.add_argument("--no-b32", action="store_true", help="skip roofline_b32 (profiling runs: keeps the attention kernel's launches of the "
                                                            "kernel-stats CSV at the one problem size of the step)")
@@ -528,7 +531,8 @@ def main():
     model = models_mae_cross.__dict__["mae_vit_base_patch16"](norm_pix_loss=False, precision=args.precision)
     model.to(dev).train()
     B = args.batch
-    step = FinetuneStep(model, batch=B, lr=1e-5, weight_decay=0.05, use_graph=not args.no_graph, process_group=None, mask_seed=1234 + rank)
+    step = FinetuneStep(model, batch=B, lr=1e-5, weight_decay=0.05, use_graph=not args.no_graph, process_group=None, mask_seed=1234 + rank,
+                        defer_optimizer=not args.no_defer)
     # device-resident synthetic batches (inputs are in HBM when the timed region starts); every timed step stages a batch into the
     # plan's input buffers (device-to-device) and draws a fresh Bernoulli(0.8) loss mask, as the reference loop does per iteration --
     # both inside the step's graph (its prologue kernel: trainer._Prologue)
@@ -556,6 +560,7 @@ def main():
         with step.on_stream():
             for k, S in enumerate(shots):
                 sums = one(k, S)
+            step.flush()        # defer_optimizer: the last step's update is applied INSIDE the timed region (K steps = K optimizer updates)
         host_dt[0] = time.perf_counter() - t0      # the host's own time to enqueue the block (it runs ahead of the GPU when smaller than dt)
         torch.cuda.synchronize()
         if world > 1:
@@ -632,7 +637,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "FSC147 finetune ViT-B/16 (mae_vit_base_patch16), batch=%d per GPU, 384x384, shot_num=3, "
                                    "frozen encoder fwd + decoder fwd/bwd + masked-MSE + AdamW" % B,
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
+                       "optimizer_update": ("deferred: AdamW of step k runs beside the frozen-encoder forward of step k + 1 (bit-identical "
+                                            "parameters; the last update of a timed block is flushed inside it)") if step.defer else "at the tail of its step"},
             "final_loss": loss, "host_enqueue_ms_per_step": host_ms,
             "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "inputs": "pinned host memory, copied over PCIe every step" if args.host_inputs else "resident in HBM",

@@ -578,8 +578,8 @@ class Engine:
         bufs = self._weight_buffers()
         nxt = None
         for fn, args, a in reversed(ops):
-            if fn is None and args and args[0] in ("fork", "lane", "join", "xfork", "xlane", "xjoin"):
-                nxt = None
+            if fn is None and args and (args[0] in ("xfork", "xlane", "xjoin") or (self.parallel_lanes and args[0] in ("fork", "lane", "join"))):
+                nxt = None       # (the plain fork / lane / join markers are inert unless parallel_lanes: run() executes them in list order)
                 continue
             if fn is not self.L.countr_gemm or a is None:
                 continue
@@ -1280,7 +1280,7 @@ class Engine:
         return self.layout.adam_plan(weight_decay, skip, zero)
 
     def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None, skip=None,
-                     zero=(), gnorm=False):
+                     zero=(), gnorm=False, stream=None):
         """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[8] {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1],
         bc1[2], bc2[2]} read by the kernel at run time, so a captured launch can be replayed with new values.  skip=None: the
         shot_num rule of adam_ranges (parameters without a gradient for S are skipped)."""
@@ -1304,15 +1304,15 @@ class Engine:
         _lib.check(self.L.countr_adamw_step(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                             shadow, n, starts, ends, wds, groups, zeros, lr, betas[0], betas[1], eps, step, grad_scale,
                                             hyper_dev.data_ptr() if hyper_dev is not None else None,
-                                            self.gnorm.data_ptr() if gnorm else None, self._stream()), "adamw")
-        self._refresh_conv_shadows()
+                                            self.gnorm.data_ptr() if gnorm else None, stream if stream is not None else self._stream()), "adamw")
+        self._refresh_conv_shadows(stream)
 
     def adamw_step(self, S, lr, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
         """torch.optim.AdamW(betas=(0.9,0.95)) semantics (FSC_finetune_cross.py:235) fused over the flat buffers."""
         self.step_count += 1
         self.adamw_launch(S, weight_decay, betas, eps, lr=lr, step=self.step_count, grad_scale=grad_scale)
 
-    def _refresh_conv_shadows(self):
+    def _refresh_conv_shadows(self, stream=None):
         """OHWI + dgrad-form shadows of every conv weight, one launch (the table of pointers is built once)."""
         if not self.conv_names and not self.WtT:
             return
@@ -1332,4 +1332,4 @@ class Engine:
             m = min(32, n - i0)
             off = lambda arr, ty: C.cast(C.byref(arr, i0 * C.sizeof(ty)), C.POINTER(ty))
             _lib.check(self.L.countr_conv_shadows(m, off(src, vp), off(wf, vp), off(wd, vp), off(co, ip), off(ci, ip), off(taps, ip),
-                                                  self.code, self._stream()), "conv_shadows")
+                                                  self.code, stream if stream is not None else self._stream()), "conv_shadows")

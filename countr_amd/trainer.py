@@ -127,6 +127,10 @@ class _GraphStep:
         self.world = self.sync.world
         self.pro = _Prologue(self.eng, mask_seed)
         self._draw_mask = False
+        self.defer = False             # FinetuneStep(defer_optimizer=True): AdamW of step k runs at the head of step k + 1's graph
+        self._pc = None                # ... the (skip, zero) key of the update that is still pending
+        self._pc_hyper = None          # ... and its scalars {lr, bias corrections, grad_scale}
+        self._cur_pc = None
         self.grad_scale = 1.0 / self.accum
         # fp16 mode: the loss gradient is multiplied by a constant before the 16-bit backward and divided out again inside the fused
         # AdamW (its grad_scale scalar) -- the reference's GradScaler (util/misc.py:260-286) with its INITIAL scale 65536 held fixed:
@@ -237,9 +241,25 @@ class _GraphStep:
         """The plan's backward launch lists that overwrite (first micro-step) or accumulate into (later ones) eng.G."""
         return plan.acc if acc else plan
 
-    def _phase_c(self, key):
+    def _phase_c(self, key, stream=None):
         skip, zero = key
-        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip, zero=zero, gnorm=True)
+        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip, zero=zero, gnorm=True, stream=stream)
+
+    def flush(self):
+        """defer_optimizer mode: apply the optimizer update that is still pending (the last step's), so that the parameters, the AdamW
+        state and grad_norm() are those of a step that has completed.  A no-op otherwise."""
+        if self._pc is None:
+            return
+        with torch.cuda.stream(self.stream):
+            keep = self.pro.hyper.copy()
+            self.pro.hyper[:] = self._pc_hyper
+            self.pro.fill([], False)
+            self.pro.hyper[:] = keep
+            self._prologue_launch()                # (eager: the scalars reach eng.hyper)
+            self._phase_c(self._pc)
+            self.pro.executed(self.stream)
+        torch.cuda.current_stream(self.eng.device).wait_stream(self.stream)
+        self._pc = self._pc_hyper = None
 
     def _run_phase(self, name, fn, S):
         """S: hashable argument of the phase; (name, S) identifies its captured graph."""
@@ -362,6 +382,7 @@ class _GraphStep:
     def optimizer_state(self):
         """torch.optim.AdamW.state_dict() of the equivalent reference optimizer: per-parameter {'step', 'exp_avg', 'exp_avg_sq'} for
         every parameter that has had a gradient, two param_groups in timm's add_weight_decay order."""
+        self.flush()
         eng = self.eng
         nd, dc = self._torch_param_order()
         index = {n: i for i, n in enumerate(nd + dc)}
@@ -399,6 +420,7 @@ class _GraphStep:
         """Restores a checkpoint's 'optimizer' entry: a torch.optim.AdamW state_dict (ours or the reference's -- same layout) or the
         flat v1 / v2 form older countr_amd checkpoints hold.  The moments are copied INTO the existing buffers (captured graphs keep
         pointing at them).  Raises on a state that does not fit this model; returns True."""
+        self.flush()
         eng = self.eng
         M, V = self._moments()
         if isinstance(opt, dict) and opt.get("exp_avg") is not None:            # flat v1 / v2
@@ -481,20 +503,33 @@ class _GraphStep:
                 skip, zero = self._adam_sets(touched)
                 self._upload_hyper(skip)
                 ckey = (tuple(skip), tuple(zero))
+            # defer_optimizer: this execution applies the PREVIOUS step's update (beside its frozen-encoder forward) and leaves its own
+            # pending; the record it reads therefore carries the previous update's scalars
+            defer = self.defer and self.use_graph and (not self.sync.comm or self.sync.capturable)
+            pc = self._pc if defer else None
+            if defer:
+                hyper_now = self.pro.hyper.copy() if last else None
+                if pc is not None:
+                    self.pro.hyper[:] = self._pc_hyper
+            elif self._pc is not None:
+                self.flush()
+            self._cur_pc = pc
             pend, self._pending = self._pending, None
             self.pro.fill(list(zip(*pend[:3])) if pend is not None else [], self._draw_mask, keep=pend[3] if pend is not None else ())
             if self.use_graph and not self.sync.comm:
                 # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
                 # costs ~20 us of idle GPU (4 launches per step before) -- and nothing else is launched between two replays
                 def whole(k, phases=phases):
+                    self._cur_pc = k[2]
                     self._run_phases_merged(phases)
                     if k[1] is not None:
                         self._phase_c(k[1])
-                self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), ckey))
+                self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), None if defer else ckey, pc))
             elif self.use_graph and self.sync.capturable:
                 # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
                 # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
-                def whole(k, phases=phases, cskip=cskip, zfill=zfill):
+                def whole(k, phases=phases, cskip=cskip, zfill=zfill, apply_now=not defer):
+                    self._cur_pc = k[4]
                     for i, (_name, fn, gkey) in enumerate(phases):
                         fn(gkey)
                         if k[1] is not None and i + 1 < len(phases):
@@ -502,8 +537,9 @@ class _GraphStep:
                     if k[1] is not None:
                         self._zero_buckets(zfill)
                         self.sync.finish(skip=cskip)
-                        self._phase_c(k[1])
-                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else ()))
+                        if apply_now:
+                            self._phase_c(k[1])
+                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else (), pc))
                 self._run_captured_comm(gk, whole)
             else:
                 for i, (name, fn, gkey) in enumerate(phases):
@@ -516,6 +552,9 @@ class _GraphStep:
                     self.sync.finish(skip=cskip)
                     self._run_phase("c", self._phase_c, ckey)
             self.pro.executed(self.stream)
+            self._cur_pc = None
+            if defer:
+                self._pc, self._pc_hyper = (ckey, hyper_now) if last else (None, None)
             if pend is not None:
                 self._staging_consumed()
         torch.cuda.current_stream(eng.device).wait_stream(self.stream)   # results are visible to the caller's stream
@@ -531,8 +570,15 @@ class _GraphStep:
 
 class FinetuneStep(_GraphStep):
     def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None, accum_iter=1, per_rank_shot=False, mask_seed=0):
-        """mask_seed: load(..., mask=None) lets the step draw the iteration's Bernoulli(0.8) loss mask itself (FSC_finetune_cross.py:
+                 process_group=None, accum_iter=1, per_rank_shot=False, mask_seed=0, defer_optimizer=False):
+        """defer_optimizer: software pipelining across iterations.  The encoder is frozen (models_mae_cross.py:204-205), so the first
+        ~1.3 ms of a step do not depend on the previous step's optimizer update: AdamW + the shadow refresh of step k (~0.1 ms, bandwidth-
+        bound) run at the HEAD of step k + 1's graph on the side lane in front of the exemplar CNN, beside the encoder's GEMMs, instead
+        of alone at the tail of step k.  Same launches on the same data in the same order per buffer: parameters are bit-identical to the
+        eager order (tests/test_trainer_gpu.py).  The price: after step() the last update is still PENDING -- flush() applies it;
+        optimizer_state(), load_optimizer_state() and grad_norm() flush themselves; call flush() before reading parameters (validation,
+        checkpoints) or letting anything else use the model.  Whole-step graph modes only (one rank, or RCCL with captured collectives).
+        mask_seed: load(..., mask=None) lets the step draw the iteration's Bernoulli(0.8) loss mask itself (FSC_finetune_cross.py:
         290-292 draws np.random.binomial per iteration; the reference seeds numpy with seed + rank, :168-170 -- pass the same here):
         mask number t of this step object = Philox4x32-10(key = mask_seed, counter = (element / 4, 0, t)) < 0.8 * 2^32, drawn by the
         step's prologue kernel inside the captured graph.
@@ -542,6 +588,7 @@ class FinetuneStep(_GraphStep):
         EVERY rank -- zero-filled on the ranks without one -- and stepped by every rank, so parameters stay identical."""
         super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter, mask_seed)
         self.per_rank = bool(per_rank_shot)
+        self.defer = bool(defer_optimizer)
         self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
         self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
@@ -553,7 +600,7 @@ class FinetuneStep(_GraphStep):
         eng = self.eng
         p = eng.plan(self.B, S, True)
         self._prologue_launch()
-        eng.run(p.fwd_par)
+        eng.run(self._fwd_list(p, self._cur_pc))
         if S not in self.sums:
             self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
         sums = self.sums[S]
@@ -564,6 +611,25 @@ class FinetuneStep(_GraphStep):
 
     def _prologue_mask(self):
         return self.mask
+
+    def _fwd_list(self, p, pc):
+        """The forward launch list of plan p; with a pending optimizer update pc (defer_optimizer) the list that applies it first:
+        [fork | lane 1: AdamW + shadow refresh, exemplar CNN | lane 0: the frozen encoder | join | decoder_embed ... head].  Everything
+        that reads a trainable parameter sits behind the AdamW on lane 1 or behind the join."""
+        if pc is None:
+            return p.fwd_par
+        cache = p.__dict__.setdefault("_defer_lists", {})
+        if pc not in cache:
+            mark = lambda *a: (None, a, None)
+            adam = (lambda st, pc=pc: (self._phase_c(pc, stream=st), 0)[1], (), None)
+            ex = getattr(p, "ex_range", None)
+            enc = p.fwd[:p.enc_ops]
+            if ex is None:
+                lane1, rest = [adam], p.fwd[p.enc_ops:]
+            else:
+                lane1, rest = [adam] + p.fwd[ex[0]:ex[1]], p.fwd[p.enc_ops:ex[0]] + p.fwd[ex[1]:]
+            cache[pc] = [mark("xfork"), mark("xlane", 1)] + lane1 + [mark("xlane", 0)] + enc + [mark("xjoin")] + rest
+        return cache[pc]
 
     def _make_sync(self, process_group):
         lay = self.eng.layout   # buckets in backward-completion order: head | decoder blocks + embed | exemplar CNN | shot_token
@@ -693,7 +759,9 @@ class FinetuneStep(_GraphStep):
 
     def grad_norm(self):
         """Device scalar: L2 norm of the (averaged) gradients the last optimizer step consumed -- get_grad_norm_ of
-        util/misc.py:289-301 as returned by NativeScalerWithGradNormCount.__call__ (:266-280).  No host sync."""
+        util/misc.py:289-301 as returned by NativeScalerWithGradNormCount.__call__ (:266-280).  No host sync.  (defer_optimizer: applies
+        the pending update first -- the norm is computed by the AdamW launch.)"""
+        self.flush()
         return self.eng.gnorm[0] if self.eng.gnorm is not None else None
 
 

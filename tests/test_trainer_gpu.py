@@ -435,3 +435,42 @@ def test_step_draws_its_own_loss_mask(use_graph):
     step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt, mask)), 3)
     step.step(3)
     assert np.array_equal(step.mask.cpu().numpy(), mask)
+
+
+@pytest.mark.parametrize("precision,accum", [("bf16", 1), ("fp32", 1), ("bf16", 2)])
+def test_deferred_optimizer_is_bit_identical(precision, accum):
+    """FinetuneStep(defer_optimizer=True): AdamW + shadow refresh of step k run at the head of step k + 1's graph, on the side lane
+    beside the frozen encoder's forward (models_mae_cross.py:204-205: nothing in it depends on the update).  Same launches, same data:
+    every step's loss / counts and, after flush(), every parameter, AdamW moment and the gradient norm are BIT-identical to the eager
+    order -- over a shot schedule that changes the AdamW key (first shot_token step, zero-gradient steps), with accumulation windows,
+    and with a parameter read (flush) in the middle."""
+    from countr_amd.trainer import FinetuneStep
+    sched = [3, 0, 3, 1, 0, 3, 3, 2]
+    res = {}
+    for defer in (False, True):
+        m, sd = make(precision)
+        step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=True, accum_iter=accum, defer_optimizer=defer, mask_seed=5)
+        sums, mids = [], None
+        for it, S in enumerate(sched):
+            imgs, boxes, gt, _mask = W.make_inputs(batch=2, shots=3, seed=200 + it)
+            step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt)), None, S)
+            sums.append(step.step(S, lr=1e-3 * (1 + 0.1 * it)).clone())
+            if defer:
+                assert (step._pc is not None) == step.applied
+            if it == 4:
+                step.flush()                        # a reader in the middle of training (validation, checkpoint)
+                mids = {k: p.detach().clone() for k, p in m.named_parameters()}
+        gn = step.grad_norm().clone()               # (flushes)
+        assert step._pc is None
+        torch.cuda.synchronize()
+        res[defer] = (torch.stack(sums), {k: p.detach().clone() for k, p in m.named_parameters()}, mids, step.eng.M.clone(), step.eng.V.clone(), gn,
+                      step.optimizer_state())
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+        assert torch.equal(a[2][k], b[2][k]), k
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+    assert a[6]["countr_amd"] == b[6]["countr_amd"]
+    moved = sum(float((a[1][k].cpu() - torch.from_numpy(sd[k])).abs().max()) > 0 for k in a[1] if k.startswith(("decoder", "decode_head", "shot_token")) and "pos_embed" not in k)
+    assert moved >= 40
