@@ -10,12 +10,14 @@ namespace {
 constexpr int SMAX_PER_LANE = 16;  // row length <= 1024
 
 // P = softmax(S) row-wise; S fp32 (already scaled), P stored as TO.  One wave per row.
+// ld >= n: row pitch of both matrices; columns n .. ld - 1 of P are written as zeros (a token count that is not a multiple of the GEMM's
+// 16-byte chunk -- 27 x 27 = 729 tokens of mae_vit_huge_patch14 -- is padded in the score / probability matrices only).
 template <typename TO>
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, TO* __restrict__ p, int64_t rows, int n) {
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, TO* __restrict__ p, int64_t rows, int n, int ld) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* sr = s + row * n;
+  const float* sr = s + row * ld;
   float v[SMAX_PER_LANE];
   float mx = -INFINITY;
 #pragma unroll
@@ -32,11 +34,12 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
     sum += v[i];
   }
   const float inv = 1.f / wave_sum(sum);
-  TO* pr = p + row * n;
+  TO* pr = p + row * ld;
 #pragma unroll
   for (int i = 0; i < SMAX_PER_LANE; ++i) {
     const int c = i * 64 + lane;
     if (c < n) stf<TO>(pr + c, v[i] * inv);
+    else if (c < ld) stf<TO>(pr + c, 0.f);
   }
 }
 
@@ -368,12 +371,15 @@ __global__ void xattn_bwd_finish_kernel(const float* __restrict__ partial, float
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream) {
-  if (!s || !p || n > 64 * SMAX_PER_LANE || n <= 0) { countr_set_error("countr_softmax_fwd: row length must be <= 1024"); return -1; }
+extern "C" int countr_softmax_fwd_ld(const float* s, void* p, int64_t rows, int n, int ld, int out_bf16, void* stream) {
+  if (!s || !p || n <= 0 || ld < n || ld > 64 * SMAX_PER_LANE) { countr_set_error("countr_softmax_fwd: need 0 < n <= ld <= 1024"); return -1; }
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (out_bf16) hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), s, (bf16_t*)p, rows, n);
-  else hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, STREAM(stream), s, (float*)p, rows, n);
+  if (out_bf16) hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, STREAM(stream), s, (bf16_t*)p, rows, n, ld);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, STREAM(stream), s, (float*)p, rows, n, ld);
   COUNTR_LAUNCH_CHECK("countr_softmax_fwd");
+}
+extern "C" int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream) {
+  return countr_softmax_fwd_ld(s, p, rows, n, n, out_bf16, stream);
 }
 
 extern "C" int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,

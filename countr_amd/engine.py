@@ -106,19 +106,33 @@ class ParamLayout:
                 for (bucket, nodecay), s, e in self.segments if bucket not in skip]
 
 
-def check_supported(cfg, img_size):
-    """The gfx950 kernels cover the CounTR shapes: fused attention for head_dim 32 / 64 and a patch grid that tiles the image.
-    mae_vit_huge_patch14 (models_mae_cross.py:235-239: patch 14 does not divide 384, head_dim 1280 / 16 = 80) can be constructed
-    and (de)serialised -- its state_dict schema is the reference's -- but cannot be executed."""
+def check_supported(cfg, img_size, precision="bf16"):
+    """What the gfx950 kernels cover.  The CounTR shapes proper -- a patch grid that tiles the image, head_dim 32 / 64 (the fused
+    attention kernels), a token count that is a multiple of 8 -- run in every precision, forward and backward.  mae_vit_huge_patch14
+    (models_mae_cross.py:235-239: patch 14 does not divide 384 -> timm's PatchEmbed conv drops the last 6 pixels and leaves 27 x 27 = 729
+    tokens; head_dim 1280 / 16 = 80; the density head turns 27 into a 432 x 432 map) runs FORWARD-ONLY in the fp32 parity mode, as the
+    reference's own forward does (its training loss compares the map with a 384 x 384 ground truth and cannot run: FSC_finetune_cross.py:
+    294): the generic fp32 GEMM path takes head_dim 80 and K = 588, the score / probability matrices are padded to 736 columns
+    (countr_softmax_fwd_ld).  Returns True for such a forward-only configuration."""
     patch, D, _depth, H, Dd, _dd, Hd = cfg
-    bad = []
+    bad, special = [], False
+    if img_size < patch:
+        bad.append("patch size %d exceeds the %d-pixel input" % (patch, img_size))
     if img_size % patch:
-        bad.append("patch size %d does not divide the %d-pixel input" % (patch, img_size))
+        special = True
+    if ((img_size // max(patch, 1)) ** 2) % 8:
+        special = True
     for what, dim, heads in (("encoder", D, H), ("decoder", Dd, Hd)):
-        if dim % heads or dim // heads not in (32, 64):
-            bad.append("%s head_dim %s (embed_dim %d / %d heads) is not 32 or 64" % (what, dim / heads, dim, heads))
+        if dim % heads or (dim // heads) % 4:
+            bad.append("%s head_dim %s (embed_dim %d / %d heads) is not a multiple of 4" % (what, dim / heads, dim, heads))
+        elif dim // heads not in (32, 64):
+            special = True
+    if special and precision != "fp32" and not bad:
+        bad.append("patch size %d on a %d-pixel input / head_dim %d: this configuration (mae_vit_huge_patch14) runs in the fp32 mode only "
+                   "(precision='fp32'; the 16-bit kernels need head_dim 32 or 64 and a patch grid that tiles the image)" % (patch, img_size, D // max(H, 1)))
     if bad:
         raise _lib.CountrError("this model configuration is not supported by the gfx950 kernels: " + "; ".join(bad))
+    return special
 
 
 # bias-correction counter group of an AdamW range by gradient bucket: the conditional parameter sets start stepping later
@@ -167,10 +181,11 @@ class Engine:
         _lib.check(self.L.countr_init(self.device.index), "countr_init")
         self.cfg = cfg
         self.patch, self.D, self.depth, self.H, self.Dd, self.ddepth, self.Hd = cfg
-        check_supported(cfg, img_size)
+        self.forward_only = check_supported(cfg, img_size, precision)      # (mae_vit_huge_patch14: fp32 forward, like the reference's)
         self.img = img_size
         self.grid = img_size // self.patch
         self.N = self.grid * self.grid
+        self.Np = -(-self.N // 8) * 8        # row pitch of the unfused attention's score / probability matrices
         if precision not in ("bf16", "fp16", "fp32"):
             raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.precision = precision
@@ -762,16 +777,22 @@ class Engine:
                      heads, dh, 0.0 if prescaled else scale)   # scale <= 0: q carries dh^-0.5 * log2(e) already
             return
         assert not prescaled
-        scores = self._shared("scores", B * heads * N * N)
+        # Np > N (a token count that is not a multiple of the GEMM's 16-byte chunk; forward-only configurations): the score and
+        # probability matrices get Np columns.  The extra score columns are products with the rows BEHIND this image's keys (the next
+        # image's first tokens, or the zeroed pad rows of the qkv buffer), the softmax writes zeros there, and the PV product multiplies
+        # those zeros with the (finite) rows behind this image's values.
+        Np = N if N % 8 == 0 else -(-N // 8) * 8
+        assert Np == N or probs is None
+        scores = self._shared("scores", B * heads * N * Np)
         if probs is None:
-            probs = self._shared("probs", B * heads * N * N, self.tdt)
+            probs = self._shared("probs", B * heads * N * Np, self.tdt)
         es = qkv.element_size()
         self._gemm(ops, self.code, OP_ROW, OP_ROW, A=qkv.data_ptr(), B=qkv.data_ptr() + Dm * es, C=scores.data_ptr(),
-                   lda=3 * Dm, ldb=3 * Dm, ldc=N, M=N, N=N, K=dh, nbatch=B * heads, nb1=heads, sA0=N * 3 * Dm, sA1=dh,
-                   sB0=N * 3 * Dm, sB1=dh, sC0=heads * N * N, sC1=N * N, alpha=scale, out_bf16=0)
-        self._op(ops, self.L.countr_softmax_fwd, scores.data_ptr(), probs.data_ptr(), B * heads * N, N, int(self.code == BF16))
+                   lda=3 * Dm, ldb=3 * Dm, ldc=Np, M=N, N=Np, K=dh, nbatch=B * heads, nb1=heads, sA0=N * 3 * Dm, sA1=dh,
+                   sB0=N * 3 * Dm, sB1=dh, sC0=heads * N * Np, sC1=N * Np, alpha=scale, out_bf16=0)
+        self._op(ops, self.L.countr_softmax_fwd_ld, scores.data_ptr(), probs.data_ptr(), B * heads * N, N, Np, int(self.code == BF16))
         self._gemm(ops, self.code, OP_ROW, OP_COL, A=probs.data_ptr(), B=qkv.data_ptr() + 2 * Dm * es, C=out.data_ptr(),
-                   lda=N, ldb=3 * Dm, ldc=Dm, M=N, N=dh, K=N, nbatch=B * heads, nb1=heads, sA0=heads * N * N, sA1=N * N,
+                   lda=Np, ldb=3 * Dm, ldc=Dm, M=N, N=dh, K=Np, nbatch=B * heads, nb1=heads, sA0=heads * N * Np, sA1=N * Np,
                    sB0=N * 3 * Dm, sB1=dh, sC0=N * Dm, sC1=dh, out_bf16=int(self.code == BF16))
 
     def _attention_bwd(self, ops, qkv, probs, dout, dqkv, B, heads, Dm, N=None):
@@ -875,13 +896,17 @@ class Engine:
     # ------------------------------------------------------------------ plan construction
     def plan(self, B, S, train):
         key = (B, S, bool(train))
+        if train and self.forward_only:
+            raise _lib.CountrError("this configuration (patch %d on %d pixels, head_dim %d) runs forward-only: its density map is %d x %d, "
+                                   "which the reference's training loss (FSC_finetune_cross.py:294, against a %d x %d ground truth) cannot "
+                                   "consume either" % (self.patch, self.img, self.D // self.H, 16 * self.grid, 16 * self.grid, self.img, self.img))
         if key not in self.plans:
             # size the shared scratch for EVERY shot count and both modes of this batch size at once, so that building
             # another plan later never moves scratch that launch lists (and captured graphs) already point to
             self._sizing = True
             try:
                 for s_ in sorted({0, 1, 2, 3, S}):
-                    for tr in (False, True):
+                    for tr in ((False,) if self.forward_only else (False, True)):
                         self._build(B, s_, tr)
             finally:
                 self._sizing = False
@@ -904,7 +929,10 @@ class Engine:
         patches = A("patches", (rows, 3 * self.patch * self.patch), T)
         x = A("x", (rows, D), f32)
         xn = A("xn", (rows, D), T)
-        qkv = A("qkv", (rows, 3 * D), T)
+        pad = self.Np - N       # rows behind the last image's tokens that the padded attention products read (zeros, never written)
+        qkv = A("qkv", (rows + pad, 3 * D), T)
+        if pad and not self._sizing:
+            qkv[rows:].zero_()
         att = A("att", (rows, D), T)
         hid = A("hid", (rows, 4 * D), T)
         latent = A("latent", (rows, D), T)
@@ -1001,7 +1029,9 @@ class Engine:
             xin = xs[-1]
             d["n0"] = A(b + ".n0", (rows, Dd), T)
             d["m0"], d["r0"] = A(b + ".m0", (rows,), f32), A(b + ".r0", (rows,), f32)
-            d["qkv"] = A(b + ".qkv", (rows, 3 * Dd), T)
+            d["qkv"] = A(b + ".qkv", (rows + pad, 3 * Dd), T)
+            if pad and not self._sizing:
+                d["qkv"][rows:].zero_()
             fused = self._fused_attention(Dd // Hd)
             d["probs"] = A(b + ".probs", (B * Hd * N * N,), T) if (train and not fused) else None
             d["lse"] = A(b + ".lse", (B * Hd * N,), f32) if (train and fused) else None

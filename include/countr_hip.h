@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 5 (5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
+int countr_version(void);               /* ABI version, currently 6 (6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -213,6 +213,10 @@ int countr_attn_bwd(const void* qkv, const void* out, const void* dout, const fl
 
 /* -------- softmax rows for the unfused attention path (models_crossvit.py:87-88) */
 int countr_softmax_fwd(const float* s, void* p, int64_t rows, int n, int out_bf16, void* stream);
+/* The same with a row pitch ld >= n (ABI 6): columns n .. ld - 1 of p are written as zeros.  For token counts that are not a multiple of
+ * the GEMM's 16-byte chunk (mae_vit_huge_patch14, models_mae_cross.py:235-239: 27 x 27 = 729 tokens): the score / probability
+ * matrices are padded, nothing else is. */
+int countr_softmax_fwd_ld(const float* s, void* p, int64_t rows, int n, int ld, int out_bf16, void* stream);
 int countr_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,
                        void* stream);
 

@@ -20,6 +20,9 @@ CONFIGS = {
     "mae_vit_huge_patch14": (14, 1280, 32, 16, 512, 2, 16),
     # reduced-depth configuration used for fast CPU tests (not a reference factory)
     "tiny_test": (16, 768, 2, 12, 512, 1, 16),
+    # the odd shapes of mae_vit_huge_patch14 at a size a test can afford: patch 14 on 384 pixels (27 x 27 = 729 tokens, a 432 x 432 map),
+    # head_dim 320 / 4 = 80 (not a reference factory; pinned by tools/oracle/make_golden_patch14.py through the reference's own class)
+    "tiny_patch14": (14, 320, 2, 4, 512, 1, 16),
 }
 
 

@@ -217,18 +217,56 @@ def test_other_factories_fp32_match_oracle(name, tol):
     assert abs(got.sum() / 60 - ref.sum() / 60) < 0.5
 
 
-def test_unsupported_configuration_fails_loudly():
-    """mae_vit_huge_patch14 (models_mae_cross.py:235-239: patch 14, head_dim 80) keeps the reference's constructor and
-    state_dict schema but cannot run on the gfx950 kernels: the first forward raises a clear error instead of computing
-    something else.  (Same check on a small stand-in with the same patch size / head_dim, to keep the test light.)"""
+def test_patch14_head80_forward_matches_reference_golden():
+    """mae_vit_huge_patch14's odd shapes (models_mae_cross.py:235-239: patch 14 on 384 pixels -> 729 tokens and a 432 x 432 density map;
+    head_dim 80) run FORWARD in the fp32 parity mode -- generic fp32 GEMMs, attention scores padded to 736 columns
+    (countr_softmax_fwd_ld) -- against goldens the reference's own class produced at an affordable width (tests/golden/patch14.npz):
+    the north-star bar, 1e-3 of the map and +-0.5 counts.  The 16-bit modes and any training plan refuse with a clear message (the
+    reference cannot train it either: its loss compares the 432 x 432 map with a 384 x 384 ground truth)."""
     from functools import partial
     import torch.nn as nn
     from countr_amd import _lib
     from countr_amd.models_mae_cross import SupervisedMAE
-    m = SupervisedMAE(patch_size=14, embed_dim=160, depth=1, num_heads=2, decoder_embed_dim=512, decoder_depth=1,
-                      decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6)).to("cuda")
-    with pytest.raises(_lib.CountrError, match="not supported by the gfx950 kernels.*patch size 14.*head_dim 80"):
-        m(torch.rand(1, 3, 384, 384, device="cuda"), torch.rand(1, 3, 3, 64, 64, device="cuda"), 3)
+    name = "tiny_patch14"
+    p, D, depth, H, Dd, ddepth, Hd = W.CONFIGS[name]
+    g = np.load(os.path.join(G, "patch14.npz"))
+    meta = json.load(open(os.path.join(G, "patch14_meta.json")))
+    sd = W.make_state_dict(name, seed=5)
+    mk = lambda prec: SupervisedMAE(patch_size=p, embed_dim=D, depth=depth, num_heads=H, decoder_embed_dim=Dd, decoder_depth=ddepth,
+                                    decoder_num_heads=Hd, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), precision=prec)
+    m = mk("fp32")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to("cuda").eval()
+    imgs, boxes, _gt, _mask = W.make_inputs(batch=2, shots=3, seed=7)
+    with torch.no_grad():
+        out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3).cpu().numpy()
+        out0 = m(torch.from_numpy(imgs[:1]).cuda(), torch.from_numpy(boxes[:1]).cuda(), 0).cpu().numpy()
+        one = m(torch.from_numpy(imgs[1:]).cuda(), torch.from_numpy(boxes[1:]).cuda(), 3).cpu().numpy()
+    assert out.shape == (2, 432, 432) == tuple(meta["shape_b2_s3"])
+    assert rel(out, g["b2_s3"]) < 1e-3, rel(out, g["b2_s3"])
+    assert np.abs(out.reshape(2, -1).sum(1) / 60 - np.array(meta["count_b2_s3"])).max() < 0.5
+    assert np.abs(out0.sum(1) - g["b1_s0_colsum"]).max() <= 1e-3 * np.abs(g["b1_s0_colsum"]).max()
+    assert abs(out0.sum() / 60 - meta["count_b1_s0"][0]) < 0.5
+    # the image behind another one in the batch is not disturbed by the padded score columns (they read the NEXT image's first tokens)
+    assert rel(one[0], out[1]) < 1e-5
+    m.train()
+    with pytest.raises(_lib.CountrError, match="runs forward-only"):
+        m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3)
+    with pytest.raises(_lib.CountrError, match="fp32 mode only"):
+        mk("bf16").to("cuda").eval()(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3)
+
+
+def test_huge_patch14_factory_runs():
+    """The factory itself (645 M parameters, 32 blocks of width 1280, 16 heads of 80): one image forward in fp32 mode against the oracle."""
+    m, sd = build("fp32", seed=2, model="mae_vit_huge_patch14")
+    imgs, boxes, _gt, _mask = W.make_inputs(batch=1, shots=3, seed=13)
+    with torch.no_grad():
+        out = m(torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda(), 3).cpu().numpy()
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    ref = R.forward(sd, imgs, boxes, 3, "mae_vit_huge_patch14").numpy()
+    assert out.shape == ref.shape == (1, 432, 432)
+    assert rel(out, ref) < 1e-3, rel(out, ref)
+    assert abs(out.sum() / 60 - ref.sum() / 60) < 0.5
 
 
 def test_backward_after_overwriting_forward_is_refused():

@@ -134,3 +134,27 @@ def test_adamw_matches_torch():
         opt.step()
         p, m, v = R.adamw_step(p, gsteps, m, v, step, 1e-3)
         assert (p - w.detach()).abs().max() < 1e-12
+
+
+def test_oracle_patch14_head80_matches_reference_golden():
+    """The odd shapes of mae_vit_huge_patch14 (models_mae_cross.py:235-239) -- patch 14 on 384 pixels: timm's PatchEmbed conv leaves
+    27 x 27 = 729 tokens and the head a 432 x 432 map; head_dim 80 -- pinned through the reference's own SupervisedMAE class at an
+    affordable width (tools/oracle/make_golden_patch14.py -> tests/golden/patch14.npz, patch14_meta.json)."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from oracle import countr_ref as R, weights as W
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(G, "patch14.npz"))
+    meta = json.load(open(os.path.join(G, "patch14_meta.json")))
+    assert meta["huge_output_shape"] == [1, 432, 432] and meta["huge_pos_embed"] == [1, 729, 1280]
+    sd = W.make_state_dict("tiny_patch14", seed=5)
+    imgs, boxes, _gt, _mask = W.make_inputs(batch=2, shots=3, seed=7)
+    torch.set_num_threads(min(os.cpu_count(), 8))
+    out = R.forward(sd, imgs, boxes, 3, "tiny_patch14").numpy()
+    assert out.shape == (2, 432, 432)
+    assert np.abs(out - g["b2_s3"]).max() <= 2e-5 * np.abs(g["b2_s3"]).max()
+    out0 = R.forward(sd, imgs[:1], boxes[:1], 0, "tiny_patch14").numpy()
+    assert np.abs(out0.sum(1) - g["b1_s0_colsum"]).max() <= 2e-5 * np.abs(g["b1_s0_colsum"]).max()
+    assert abs(out0.sum() / 60 - meta["count_b1_s0"][0]) < 1e-2
