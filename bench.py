@@ -460,6 +460,13 @@ def other_workloads(args, dev, steps=10, warmup=3):
         "ms_per_step": d["ms_per_step"], "images_per_sec": d["value"], "batch": 16, "steps": steps, "final_loss": d["final_loss"],
         "step_tflops": d["step_tflops"],
         "workload": "MAE pretrain ViT-B/16 + 8x512-d decoder, mask_ratio 0.5: masking + fwd + all-patch MSE + full bwd + AdamW (child process)"}
+    if args.precision == "bf16":
+        # the headline step in the reference-numerics mode (precision="fp16": the reference's own autocast dtype, FSC_finetune_cross.py:273-275,
+        # 286; same kernels built with fp16 operands) beside the bf16 headline
+        d = child("--precision", "fp16", "--plain", "--reps", "3", "--steps", "30")
+        out["finetune_fp16"] = d if "error" in d else {
+            "ms_per_step": d["ms_per_step"], "images_per_sec": d["value"], "steps": 30,
+            "workload": "the headline finetune step with precision='fp16' (libcountr_hip_f16.so; static loss scale 2^16), child process"}
     d = child("--workload", "infer")
     out["infer"] = d if "error" in d else {
         "ms_per_32_windows": d["ms_per_step"], "frames_per_sec": d["value"], "windows_per_sec": d["windows_per_sec"], "steps": steps,
