@@ -192,7 +192,11 @@ def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=Tr
                             "2 x 16 MFMAs = 63 % of the matrix pipe, and that is the cost of the instruction stream itself: a replica of the step's "
                             "compute without any memory traffic (tools/ubench_fa_step.hip, profiles/r3_fa_step_microbench.txt) gives the younger "
                             "wave 1611 cycles -- 1024 matrix + ~590 cycles of exp / row-sum / pack / max VALU that two waves cannot hide under "
-                            "their MFMAs on this SIMD (v_exp_f32 alone: 210).",
+                            "their MFMAs on this SIMD (v_exp_f32 alone: 210).  Round 5 (counters in profiles/r5_attention_pmc.txt: matrix pipes "
+                            "26.9 % busy, 33.7 % of wave cycles waiting, traffic 1.005 x algorithmic): a persistent form has nothing to amortise "
+                            "at B = 8 (1728 strips for 2048 wave slots: one strip per wave), and at B = 32 the launch already is 3.75 rounds of "
+                            "workgroups with two per CU in different phases -- the overlap a persistent loop would schedule -- and reaches "
+                            "roofline_b32.frac = 0.25 against the loop's own 0.33 (DESIGN.md section 5).",
             "kernel": "fa_fwd_pipe_kernel<64>: encoder attention core (QK^T, softmax, PV), one launch per layer",
             "us_per_launch": us,
             "timing": "in-step, HIP events on the launch stream, %d encoder launches x %d eager forward passes: median of [attention + next launch] "
