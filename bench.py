@@ -650,7 +650,8 @@ def main():
                                    "frozen encoder fwd + decoder fwd/bwd + masked-MSE + AdamW" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                        "optimizer_update": ("deferred: AdamW of step k runs beside the frozen-encoder forward of step k + 1 (bit-identical "
-                                            "parameters; the last update of a timed block is flushed inside it)") if step.defer else "at the tail of its step"},
+                                            "parameters; the last update of a timed block is flushed inside it)")
+                                           if (step.defer and step.use_graph and (not step.sync.comm or step.sync.capturable)) else "at the tail of its step"},
             "final_loss": loss, "host_enqueue_ms_per_step": host_ms,
             "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "inputs": "pinned host memory, copied over PCIe every step" if args.host_inputs else "resident in HBM",

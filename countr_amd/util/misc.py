@@ -22,24 +22,44 @@ def is_main_process():
 
 
 def init_distributed_mode(args):
-    """Env-driven init (RANK / WORLD_SIZE / LOCAL_RANK as set by torch.distributed.run), backend nccl == RCCL."""
-    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
-        args.rank = int(os.environ["RANK"])
-        args.world_size = int(os.environ["WORLD_SIZE"])
-        args.gpu = int(os.environ.get("LOCAL_RANK", 0))
-        args.distributed = True
-        # COUNTR_DIST_BACKEND=gloo: dry run of an N-rank job on fewer GPUs (RCCL refuses two ranks per device); ranks then share devices
-        backend = os.environ.get("COUNTR_DIST_BACKEND", "nccl")
-        if backend != "nccl":
-            args.gpu %= max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(args.gpu)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size,
-                                rank=args.rank)
-        dist.barrier()
+    """The reference's three launcher conventions (util/misc.py:225-257), backend nccl == RCCL:
+    --dist_on_itp: OpenMPI (OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK, tcp://MASTER_ADDR:MASTER_PORT; the variables torchrun would have
+    set are exported like the reference does); RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run); SLURM_PROCID (gpu = rank modulo
+    the visible devices; the world size comes from --world_size, as in the reference).  Anything else: single process."""
+    env = os.environ
+    if getattr(args, "dist_on_itp", False):
+        args.rank = int(env["OMPI_COMM_WORLD_RANK"])
+        args.world_size = int(env["OMPI_COMM_WORLD_SIZE"])
+        args.gpu = int(env["OMPI_COMM_WORLD_LOCAL_RANK"])
+        args.dist_url = "tcp://%s:%s" % (env["MASTER_ADDR"], env["MASTER_PORT"])
+        env["LOCAL_RANK"], env["RANK"], env["WORLD_SIZE"] = str(args.gpu), str(args.rank), str(args.world_size)
+    elif "RANK" in env and "WORLD_SIZE" in env:
+        args.rank = int(env["RANK"])
+        args.world_size = int(env["WORLD_SIZE"])
+        args.gpu = int(env.get("LOCAL_RANK", 0))
+    elif "SLURM_PROCID" in env:
+        args.rank = int(env["SLURM_PROCID"])
+        args.world_size = int(getattr(args, "world_size", 1) or 1)
+        args.gpu = args.rank % max(torch.cuda.device_count(), 1)
     else:
         args.distributed = False
         args.rank, args.world_size, args.gpu = 0, 1, 0
+        return
+    if args.world_size <= 1:          # (a one-rank "job": nothing to exchange, no process group)
+        args.distributed = False
+        args.rank, args.world_size = 0, 1
+        torch.cuda.set_device(args.gpu % max(torch.cuda.device_count(), 1))
+        return
+    args.distributed = True
+    # COUNTR_DIST_BACKEND=gloo: dry run of an N-rank job on fewer GPUs (RCCL refuses two ranks per device); ranks then share devices
+    backend = env.get("COUNTR_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        args.gpu %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(args.gpu)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    print("| distributed init (rank %d): %s, gpu %d" % (args.rank, getattr(args, "dist_url", "env://"), args.gpu), flush=True)
+    dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size, rank=args.rank)
+    dist.barrier()
 
 
 def all_reduce_mean(x):

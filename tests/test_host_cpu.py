@@ -163,3 +163,39 @@ def test_philox_oracle_matches_random123_known_answers():
     assert abs(m0.mean() - 0.8) < 5e-3 and abs(m1.mean() - 0.8) < 5e-3          # sigma of the mean = 1.04e-3
     assert 0.15 < (m0 != m1).mean() < 0.5                                        # independent draws differ on 2 p (1 - p) = 32 %
     assert (loss_mask(8, 0) != m0).any()
+
+
+def test_init_distributed_mode_reads_the_three_launcher_conventions(monkeypatch):
+    """util/misc.py:225-257: --dist_on_itp (OpenMPI variables, tcp:// URL, torchrun's variables exported), RANK / WORLD_SIZE / LOCAL_RANK,
+    SLURM_PROCID (world size from --world_size, gpu = rank modulo the devices), none of them -> single process."""
+    import types
+    import torch.distributed as dist
+    from countr_amd.util import misc
+    calls = []
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: calls.append(kw))
+    monkeypatch.setattr(dist, "barrier", lambda: None)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("device", d)))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID", "OMPI_COMM_WORLD_RANK", "MASTER_ADDR", "MASTER_PORT", "COUNTR_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    a = types.SimpleNamespace(dist_on_itp=False, world_size=1, dist_url="env://")
+    misc.init_distributed_mode(a)
+    assert not a.distributed and (a.rank, a.world_size, a.gpu) == (0, 1, 0) and not calls
+    for k, v in (("OMPI_COMM_WORLD_RANK", "5"), ("OMPI_COMM_WORLD_SIZE", "8"), ("OMPI_COMM_WORLD_LOCAL_RANK", "5"), ("MASTER_ADDR", "10.0.0.1"), ("MASTER_PORT", "2345")):
+        monkeypatch.setenv(k, v)
+    a = types.SimpleNamespace(dist_on_itp=True, world_size=1, dist_url="env://")
+    misc.init_distributed_mode(a)
+    assert a.distributed and (a.rank, a.world_size, a.gpu, a.dist_url) == (5, 8, 5, "tcp://10.0.0.1:2345")
+    assert os.environ["RANK"] == "5" and os.environ["WORLD_SIZE"] == "8" and os.environ["LOCAL_RANK"] == "5"
+    assert calls[-1] == dict(backend="nccl", init_method="tcp://10.0.0.1:2345", world_size=8, rank=5) and ("device", 5) in calls
+    calls.clear()
+    monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("LOCAL_RANK", "3")
+    a = types.SimpleNamespace(dist_on_itp=False, world_size=1, dist_url="env://")
+    misc.init_distributed_mode(a)
+    assert a.distributed and (a.rank, a.world_size, a.gpu) == (3, 4, 3) and calls[-1]["init_method"] == "env://"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("SLURM_PROCID", "11")
+    a = types.SimpleNamespace(dist_on_itp=False, world_size=16, dist_url="tcp://head:1")
+    misc.init_distributed_mode(a)
+    assert a.distributed and (a.rank, a.world_size, a.gpu) == (11, 16, 3) and calls[-1]["rank"] == 11 and calls[-1]["world_size"] == 16
