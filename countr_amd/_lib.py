@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 LIB_PATH_F16 = os.environ.get("COUNTR_LIB_F16", os.path.join(_HERE, "libcountr_hip_f16.so"))
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 6
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 

@@ -207,25 +207,6 @@ int countr_check_launch(const char* what);
 const float* countr_zero_vec(int n);
 #define COUNTR_LAUNCH_CHECK(what) return countr_check_launch(what)
 
-// "Last block done": a reduction whose blocks leave partials folds its one-block finisher launch (~4.6 us each inside a replayed graph,
-// profiles/r5_finishers_ab.txt) into the block that arrives last.  Every block calls this -- all threads -- AFTER writing its partials;
-// it returns true in all threads of exactly one block, which may then read every block's partials (in a fixed order: results stay
-// deterministic).  *ticket must be zero before the first launch that uses it (caller-provided workspace memory) and is left zero.
-__device__ __forceinline__ bool countr_last_block(unsigned int* ticket, unsigned int nblocks) {
-  __shared__ unsigned int s_last;
-  __threadfence();                          // this thread's partials are visible device-wide ...
-  __syncthreads();                          // ... for every thread of the block, before its ticket is drawn
-  if (threadIdx.x == 0) {
-    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == nblocks - 1u) ? 1u : 0u;
-    if (t == nblocks - 1u) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const bool last = s_last != 0u;
-  if (last) __threadfence();                // the other blocks' partials are visible to this one
-  return last;
-}
-
 // K order of the 3x3 convolutions' implicit GEMMs in linear.hip / gemm256.hip (K = 9 taps x Cin, k-tile = 64 channels of one tap):
 // 1 = channel-chunk-major -- k-tile t is tap t % 9 of chunk t / 9, so nine consecutive k-tiles read the SAME 128-byte pieces of the
 // map's pixels (shifted by a row / a pixel): the working set of an XCD's 32 workgroups over those nine k-tiles is ~1.1 MB and stays in

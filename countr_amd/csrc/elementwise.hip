@@ -434,10 +434,9 @@ __global__ __launch_bounds__(256) void conv_shadows_kernel(const ConvShadowTable
 constexpr int MSE_BLOCKS = 64;
 __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                          const float* __restrict__ mask, float* __restrict__ dpred,
-                                                         float* __restrict__ ws /* [4: ticket][B][MSE_BLOCKS][3] */, float* __restrict__ sums,
-                                                         int B, int HW, float grad_scale) {
+                                                         float* __restrict__ partial /* [B][MSE_BLOCKS][3] */, int B, int HW,
+                                                         float grad_scale) {
   __shared__ float sm[4];
-  float* __restrict__ partial = ws + 4;
   const int b = blockIdx.y;
   float l = 0.f, sp = 0.f, sg = 0.f;
   const float inv = 1.f / ((float)HW * B);
@@ -472,19 +471,20 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict
     float* o = partial + ((int64_t)b * gridDim.x + blockIdx.x) * 3;
     o[0] = l * inv; o[1] = sp / 60.f; o[2] = sg / 60.f;
   }
-  // the block that arrives last sums the partials (one wave; lane = block partial index; fixed order: deterministic)
-  if (!countr_last_block(reinterpret_cast<unsigned int*>(ws), gridDim.x * gridDim.y) || threadIdx.x >= 64) return;
-  const int nblk = gridDim.x;
+}
+__global__ __launch_bounds__(64) void masked_mse_finish_kernel(const float* __restrict__ partial, float* __restrict__ sums, int B,
+                                                               int nblk) {
+  // one wave; lane = block partial index
   float loss = 0.f;
-  for (int bb = 0; bb < B; ++bb) {
-    float l2 = 0.f, sp2 = 0.f, sg2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float l = 0.f, sp = 0.f, sg = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 64) {
-      const float* o = partial + ((int64_t)bb * nblk + i) * 3;
-      l2 += __builtin_nontemporal_load(o); sp2 += __builtin_nontemporal_load(o + 1); sg2 += __builtin_nontemporal_load(o + 2);
+      const float* o = partial + ((int64_t)b * nblk + i) * 3;
+      l += o[0]; sp += o[1]; sg += o[2];
     }
-    l2 = wave_sum(l2); sp2 = wave_sum(sp2); sg2 = wave_sum(sg2);
-    loss += l2;
-    if (threadIdx.x == 0) { sums[1 + bb] = sp2; sums[1 + B + bb] = sg2; }
+    l = wave_sum(l); sp = wave_sum(sp); sg = wave_sum(sg);
+    loss += l;
+    if (threadIdx.x == 0) { sums[1 + b] = sp; sums[1 + B + b] = sg; }
   }
   if (threadIdx.x == 0) sums[0] = loss;
 }
@@ -527,14 +527,21 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
   if (gnorm_ws) {   // deterministic two-stage sum of squares of the (scaled) gradients: util/misc.py:289-301 get_grad_norm_
     sq = block_sum<4>(sq, red);
-    if (threadIdx.x == 0) gnorm_ws[2 + blockIdx.x] = sq;
-    // ws = [norm, ticket, partials (<= 2048)]: the block that arrives last adds them (fixed tree: eight per thread, then the block)
-    if (!countr_last_block(reinterpret_cast<unsigned int*>(gnorm_ws + 1), gridDim.x)) return;
-    float t = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __builtin_nontemporal_load(gnorm_ws + 2 + i);
-    __syncthreads();
-    t = block_sum<4>(t, red);
-    if (threadIdx.x == 0) gnorm_ws[0] = sqrtf(t);
+    if (threadIdx.x == 0) gnorm_ws[1 + blockIdx.x] = sq;
+  }
+}
+__global__ __launch_bounds__(1024) void gnorm_finish_kernel(float* __restrict__ ws, int nb) {   // nb <= 2048 partials: two independent loads per thread
+  __shared__ float part[16];
+  const int t = threadIdx.x;
+  const float a = t < nb ? ws[1 + t] : 0.f, b = t + 1024 < nb ? ws[1 + t + 1024] : 0.f;
+  const float s = wave_sum(a + b);     // fixed summation tree: deterministic
+  if ((t & 63) == 0) part[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += part[k];
+    ws[0] = sqrtf(tot);
   }
 }
 
@@ -792,15 +799,16 @@ extern "C" int countr_conv_shadows(int n, const float* const* src, void* const* 
   COUNTR_LAUNCH_CHECK("countr_conv_shadows");
 }
 
-extern "C" int countr_masked_mse_workspace_floats(int B) { return 4 + B * MSE_BLOCKS * 3; }   // [ticket, 3 pad][B][MSE_BLOCKS][3]
+extern "C" int countr_masked_mse_workspace_floats(int B) { return B * MSE_BLOCKS * 3; }
 extern "C" int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
                                  float* workspace, int B, int HW, float grad_scale, void* stream) {
   if (!pred || !gt || !mask || !sums || !workspace) { countr_set_error("countr_masked_mse: null"); return -1; }
-  hipLaunchKernelGGL(masked_mse_kernel, dim3(MSE_BLOCKS, B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, workspace, sums, B, HW, grad_scale);
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(MSE_BLOCKS, B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, workspace, B, HW, grad_scale);
+  hipLaunchKernelGGL(masked_mse_finish_kernel, dim3(1), dim3(64), 0, STREAM(stream), workspace, sums, B, MSE_BLOCKS);
   COUNTR_LAUNCH_CHECK("countr_masked_mse");
 }
 
-extern "C" int countr_adamw_gnorm_floats(void) { return 2 + 2048; }   // [norm, ticket (zero before the first call), 2048 block partials]
+extern "C" int countr_adamw_gnorm_floats(void) { return 1 + 2048; }
 extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
                                  const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
                                  const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
@@ -818,6 +826,7 @@ extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, v
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   const int nb = nblocks(total, 256, 2048);
   hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev, gnorm_ws);
+  if (gnorm_ws) hipLaunchKernelGGL(gnorm_finish_kernel, dim3(1), dim3(1024), 0, STREAM(stream), gnorm_ws, nb);
   COUNTR_LAUNCH_CHECK("countr_adamw_step");
 }
 

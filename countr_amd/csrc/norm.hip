@@ -224,16 +224,10 @@ __device__ __forceinline__ void reduce_vec_same_chanvec(float (&v)[NV], float* s
   }
 }
 
-// workspace = [GN_TICKETS words: one ticket per image, zero before the first launch][partials ...]: the block of an image that arrives
-// last combines the image's split partials into {mean, rstd} (the former gn_stats_finalize_kernel launch, folded: common.hpp)
-constexpr int GN_TICKETS = 256;
-__device__ __forceinline__ void gn_stats_finalize(const float* __restrict__ part, float* __restrict__ stats, int b, int HW, int G, int ns, float eps);
-
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ ws /* [tickets][B][ns][G][2] */,
-                                                       float* __restrict__ stats, float eps, int HW, int G) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part /* [B][ns][G][2] */,
+                                                       int HW, int G) {
   __shared__ float sm[128];
-  float* __restrict__ part = ws + GN_TICKETS;
   const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
   const int per = (HW + ns - 1) / ns;
   const int p0 = split * per, p1 = min(HW, p0 + per);
@@ -269,41 +263,38 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     o[0] = m;
     o[1] = fmaxf(gq - gs * m, 0.f);  // M2 about the split mean
   }
-  if (countr_last_block(reinterpret_cast<unsigned int*>(ws) + b, ns)) gn_stats_finalize(part, stats, b, HW, G, ns, eps);
 }
 
-// Per-(image, group) mean / rstd from the split partials {mean_s, M2_s}: one wave per group (the block's four waves take the groups in
-// turn), lanes over the splits, the exact two-pass combination  mean = sum n_s mean_s / N,  M2 = sum (M2_s + n_s (mean_s - mean)^2).
-__device__ __forceinline__ void gn_stats_finalize(const float* __restrict__ part, float* __restrict__ stats /* [B][G][2] */, int b, int HW, int G,
-                                                  int ns, float eps) {
-  const int lane = threadIdx.x & 63;
+// Per-(image, group) mean / rstd from the split partials {mean_s, M2_s}: one wave per group, lanes over the splits, the exact
+// two-pass combination  mean = sum n_s mean_s / N,  M2 = sum (M2_s + n_s (mean_s - mean)^2)  (all loads in flight at once).
+__global__ void gn_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats /* [B][G][2] */, int HW, int G,
+                                         int ns, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per = (HW + ns - 1) / ns;
   const float cpg = (float)(GN_C / G);
-  for (int g = threadIdx.x >> 6; g < G; g += 4) {
-    float nsum = 0.f, msum = 0.f;
-    for (int s = lane; s < ns; s += 64) {
-      const float n = (float)max(min(HW, (s + 1) * per) - s * per, 0) * cpg;
-      if (n > 0.f) {   // an empty split's partial is never written
-        nsum += n;
-        msum += n * __builtin_nontemporal_load(part + (((int64_t)b * ns + s) * G + g) * 2);
-      }
+  float nsum = 0.f, msum = 0.f;
+  for (int s = lane; s < ns; s += 64) {
+    const float n = (float)max(min(HW, (s + 1) * per) - s * per, 0) * cpg;
+    if (n > 0.f) {   // an empty split's partial is never written
+      nsum += n;
+      msum += n * part[(((int64_t)b * ns + s) * G + g) * 2];
     }
-    const float ntot = wave_sum(nsum);
-    const float mean = wave_sum(msum) / ntot;
-    float m2 = 0.f;
-    for (int s = lane; s < ns; s += 64) {
-      const float n = (float)max(min(HW, (s + 1) * per) - s * per, 0) * cpg;
-      if (n > 0.f) {
-        const float* o = part + (((int64_t)b * ns + s) * G + g) * 2;
-        const float d = __builtin_nontemporal_load(o) - mean;
-        m2 += __builtin_nontemporal_load(o + 1) + n * d * d;
-      }
+  }
+  const float ntot = wave_sum(nsum);
+  const float mean = wave_sum(msum) / ntot;
+  float m2 = 0.f;
+  for (int s = lane; s < ns; s += 64) {
+    const float n = (float)max(min(HW, (s + 1) * per) - s * per, 0) * cpg;
+    if (n > 0.f) {
+      const float* o = part + (((int64_t)b * ns + s) * G + g) * 2;
+      const float d = o[0] - mean;
+      m2 += o[1] + n * d * d;
     }
-    m2 = wave_sum(m2);
-    if (lane == 0) {
-      stats[((int64_t)b * G + g) * 2] = mean;
-      stats[((int64_t)b * G + g) * 2 + 1] = rsqrtf(m2 / ntot + eps);
-    }
+  }
+  m2 = wave_sum(m2);
+  if (lane == 0) {
+    stats[((int64_t)b * G + g) * 2] = mean;
+    stats[((int64_t)b * G + g) * 2 + 1] = rsqrtf(m2 / ntot + eps);
   }
 }
 
@@ -356,9 +347,6 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
   }
 }
 
-__device__ __forceinline__ void gn_bwd_finalize(const float* __restrict__ partial, const float* __restrict__ gamma, float* __restrict__ gm,
-                                                float* __restrict__ per_image, int b, int HW, int G, int ns);
-
 // Backward pass 1: per-channel sums of g = dy * 1[y>0] and g * xhat over a pixel split.
 // dy is either a tensor (T) or, for the fused 1x1 head, d1[b,p] * w1[c].
 // partial layout: [B][ns][3][C] = {sum g, sum g*xhat, sum d1*y (dw1, head only)}
@@ -367,8 +355,7 @@ __global__ __launch_bounds__(NT) void gn_relu_bwd_reduce_kernel(const T* __restr
                                                                  const float* __restrict__ d1, const float* __restrict__ w1,
                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ partial,
-                                                                 unsigned int* __restrict__ tickets, float* __restrict__ gm,
-                                                                 float* __restrict__ per_image, int HW, int G) {
+                                                                 int HW, int G) {
   constexpr int NW = NT / 64, SLOTS = NT / 32;
   __shared__ float smv[NW * 32 * 8];
   const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
@@ -424,32 +411,30 @@ __global__ __launch_bounds__(NT) void gn_relu_bwd_reduce_kernel(const T* __restr
       o[2 * GN_C + cv * 8 + e] = w1 ? sw[e] : 0.f;
     }
   }
-  // pass 1b in the image's last block (its first 256 threads: one per channel)
-  if (countr_last_block(tickets + b, ns) && threadIdx.x < 256) gn_bwd_finalize(partial, gamma, gm, per_image, b, HW, G, ns);
 }
 
-// Backward pass 1b (the last block of an image): per-(image, group) means of g*gamma and g*gamma*xhat from the split partials.
-__device__ __forceinline__ void gn_bwd_finalize(const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                float* __restrict__ gm /* [B][G][2] */,
-                                                float* __restrict__ per_image /* [B][3][C]: the image's split sums */,
-                                                int b, int HW, int G, int ns) {
-  const int c = threadIdx.x;  // 256 channels
+// Backward pass 1b (one block per image): per-(image, group) means of g*gamma and g*gamma*xhat from the split partials.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                              float* __restrict__ gm /* [B][G][2] */,
+                                                              float* __restrict__ per_image /* [B][3][C]: the image's split sums */,
+                                                              int HW, int G, int ns) {
+  const int b = blockIdx.x, c = threadIdx.x;  // 256 channels
   float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, w4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: the loop is load-latency bound
   int s = 0;
   for (; s + 4 <= ns; s += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float* o = partial + ((int64_t)b * ns + s + u) * 3 * GN_C;
-      a4[u] += __builtin_nontemporal_load(o + c);
-      q4[u] += __builtin_nontemporal_load(o + GN_C + c);
-      w4[u] += __builtin_nontemporal_load(o + 2 * GN_C + c);
+      a4[u] += o[c];
+      q4[u] += o[GN_C + c];
+      w4[u] += o[2 * GN_C + c];
     }
   }
   for (; s < ns; ++s) {
     const float* o = partial + ((int64_t)b * ns + s) * 3 * GN_C;
-    a4[0] += __builtin_nontemporal_load(o + c);
-    q4[0] += __builtin_nontemporal_load(o + GN_C + c);
-    w4[0] += __builtin_nontemporal_load(o + 2 * GN_C + c);
+    a4[0] += o[c];
+    q4[0] += o[GN_C + c];
+    w4[0] += o[2 * GN_C + c];
   }
   float a = (a4[0] + a4[1]) + (a4[2] + a4[3]), q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
   // the parameter gradients {dbeta, dgamma, dw1} are sums over ALL images and splits: hand the per-image sums on, so that whoever
@@ -994,7 +979,7 @@ static int gn_splits(int HW) {
 extern "C" int countr_groupnorm_nsplit(int HW) { return gn_splits(HW); }
 // float offset, inside countr_groupnorm_relu_bwd's workspace, of the per-image sums [B][3][C] = {sum g, sum g*xhat, sum d1*y} its
 // finalize pass leaves behind (the workspace therefore needs B*ns*3*C + 64 + 16*B + B*3*C floats)
-extern "C" long long countr_groupnorm_bwd_image_sums_offset(int B, int HW) { return (long long)GN_TICKETS + (long long)B * gn_splits(HW) * 3 * GN_C + 64 + 16 * B; }
+extern "C" long long countr_groupnorm_bwd_image_sums_offset(int B, int HW) { return (long long)B * gn_splits(HW) * 3 * GN_C + 64 + 16 * B; }
 // forward statistics: their partials ({mean, M2} per group) are combined in parallel by gn_stats_finalize_kernel, so the big maps
 // can be cut finer than the backward's (whose finishers walk the splits): 144 pixels per block, at most 128 blocks per image
 static int gn_splits_fwd(int HW) {
@@ -1007,14 +992,16 @@ static int gn_splits_fwd(int HW) {
 extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
                                          const float* b1, float* out1, float* stats, float* workspace, int B, int HW, int C,
                                          int G, float eps, int dtype, void* stream) {
-  if (!x || !gamma || !beta || !stats || !workspace || C != GN_C || G > 16 || (GN_C / G) % 8 || (!y && !w1) || B > GN_TICKETS) { countr_set_error("countr_groupnorm_relu_fwd: bad args (C must be 256, G <= 16, B <= 256)"); return -1; }
+  if (!x || !gamma || !beta || !stats || !workspace || C != GN_C || G > 16 || (GN_C / G) % 8 || (!y && !w1)) { countr_set_error("countr_groupnorm_relu_fwd: bad args (C must be 256, G <= 16)"); return -1; }
   const int ns = gn_splits_fwd(HW);
   const int nblk = min((HW + 7) / 8, 512);
   if (dtype == COUNTR_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, stats, eps, HW, G);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, HW, G);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(B), dim3(64 * G), 0, STREAM(stream), workspace, stats, HW, G, ns, eps);
     hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, gamma, beta, (bf16_t*)y, w1, b1, out1, stats, HW, G, ns, eps);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, stats, eps, HW, G);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, HW, G);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(B), dim3(64 * G), 0, STREAM(stream), workspace, stats, HW, G, ns, eps);
     hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, gamma, beta, (float*)y, w1, b1, out1, stats, HW, G, ns, eps);
   }
   COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_fwd");
@@ -1025,23 +1012,23 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
                                          const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta,
                                          float* dw1, float* db1, float* workspace, int B, int HW, int C, int G, int dtype,
                                          int accumulate, void* stream) {
-  if (!x || !stats || !gamma || !beta || !dx || !workspace || C != GN_C || (!dy && !(d1 && w1)) || B > GN_TICKETS) { countr_set_error("countr_groupnorm_relu_bwd: bad args (C == 256, B <= 256)"); return -1; }
+  if (!x || !stats || !gamma || !beta || !dx || !workspace || C != GN_C || (!dy && !(d1 && w1))) { countr_set_error("countr_groupnorm_relu_bwd: bad args"); return -1; }
   const int ns = gn_splits(HW);
   const int nblk = min((HW + 7) / 8, 512);
-  unsigned int* tickets = reinterpret_cast<unsigned int*>(workspace);   // [GN_TICKETS]: zero before the first call, left zero
-  float* partial = workspace + GN_TICKETS;
-  float* gmean = partial + (int64_t)B * ns * 3 * GN_C + 64;    // [B][G][2] behind the partials and the d1 sums
+  float* gmean = workspace + (int64_t)B * ns * 3 * GN_C + 64;  // [B][G][2] behind the partials and the d1 sums
   float* per_image = gmean + 16 * B;                           // [B][3][C] behind that (countr_groupnorm_bwd_image_sums_offset)
   if (G != 8) { countr_set_error("countr_groupnorm_relu_bwd: G must be 8"); return -1; }
   if (dtype == COUNTR_BF16) {
     // threads per block of the reduction pass: 512 (16 pixel slots) keeps more loads in flight per CU than 256 (96x96: 31.6 -> 20.8 us,
     // 48x48 and 24x24: 17.4 -> 11.6 us); 1024 falls off a cliff (step +230 us: 128-VGPR budget)
     const int nt = w1 ? 256 : 512;   // (the fused-head form -- 192x192, x only -- is better off with 256: 41.4 vs 44.4 us)
-    if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, partial, tickets, gmean, per_image, HW, G);
-    else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, partial, tickets, gmean, per_image, HW, G);
+    if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);
   } else {
-    hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<float, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, partial, tickets, gmean, per_image, HW, G);
+    hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<float, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)dy, d1, w1, stats, gamma, beta, gmean, (float*)dx, HW, G, ns);
   }
   // parameter gradients: partial[p] = {sum g (dbeta) [C], sum g*xhat (dgamma) [C], sum d1*y (dw1) [C]}
@@ -1052,7 +1039,7 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
                        (int64_t)3 * GN_C, accumulate);
   }
   if (db1 && d1) {  // the reduce/apply kernels are done with the first 64 floats of row 0's third plane only via dw1: use the tail
-    float* part = partial + (int64_t)B * ns * 3 * GN_C;    // 64 extra floats behind the partials
+    float* part = workspace + (int64_t)B * ns * 3 * GN_C;  // 64 extra floats behind the partials
     hipLaunchKernelGGL(sum_all_kernel, dim3(64), dim3(256), 0, STREAM(stream), d1, (int64_t)B * HW, part);
     hipLaunchKernelGGL(colsum_partials_kernel, dim3(1), dim3(256), 0, STREAM(stream), part, db1, 64, 1, (int64_t)1, accumulate);
   }

@@ -247,7 +247,6 @@ class Engine:
         self._ln_checked = False     # check_ln_fold() has looked at the activations this weight set produces
         self.ln_fold_ratio = None    # ... and this is the largest |mean| / sigma it saw at a folded LayerNorm's input
         self._ws = {}
-        self._zero_ws = set()
         self._need = {}
         self._sizing = False
         self.reduce_vec4 = True      # 16-byte loads in the deferred-sum kernel
@@ -401,15 +400,12 @@ class Engine:
         plan.buf[key] = t
         return t
 
-    def _shared(self, key, numel, dtype=torch.float32, zero=False):
+    def _shared(self, key, numel, dtype=torch.float32):
         """Scratch shared by all plans.  A sizing pass records the maximum request; the real pass then finds
-        the buffer already large enough, so pointers baked into launch lists stay valid.  zero: the buffer starts zero-filled
-        (workspaces that begin with last-block-done tickets: csrc/common.hpp::countr_last_block)."""
+        the buffer already large enough, so pointers baked into launch lists stay valid."""
         if self._sizing:
             old = self._need.get(key, (0, dtype))
             self._need[key] = (max(old[0], int(numel)), dtype)
-            if zero:
-                self._zero_ws.add(key)
             return _Fake(dtype)
         cur = self._ws[key]
         assert cur.numel() >= numel and cur.dtype == dtype, key
@@ -420,7 +416,7 @@ class Engine:
         for key, (numel, dtype) in self._need.items():
             cur = self._ws.get(key)
             if cur is None or cur.numel() < numel or cur.dtype != dtype:
-                self._ws[key] = (torch.zeros if key in self._zero_ws else torch.empty)(max(numel, 1), device=self.device, dtype=dtype)
+                self._ws[key] = torch.empty(max(numel, 1), device=self.device, dtype=dtype)
                 grew = True
         if grew and self.plans:
             self.plans.clear()  # launch lists of older plans hold pointers into the replaced scratch
@@ -1078,7 +1074,7 @@ class Engine:
         hc, hstats = [], []
         # GroupNorm workspace: the C side places the per-image sums behind the per-split partials (their count follows the map size and
         # COUNTR_GN_SPLIT_CAP), so size it from the library's own offset, the largest over the four head maps
-        gn_ws = self._shared("gn", max(int(L.countr_groupnorm_bwd_image_sums_offset(B, h * h)) for h in hs) + B * 3 * 256, zero=True)
+        gn_ws = self._shared("gn", max(int(L.countr_groupnorm_bwd_image_sums_offset(B, h * h)) for h in hs) + B * 3 * 256)
         o1 = A("o1", (B, hs[3] * hs[3]), f32)
         out = A("out", (B, 2 * hs[3], 2 * hs[3]), f32)
         # (GroupNorm-apply + ReLU + bilinear x2 as ONE kernel was built in round 4: 75 us for the three stages against 78.5 for the two-
@@ -1137,7 +1133,7 @@ class Engine:
                 # layer's own workspace and are summed by the table launch that finishes the layer's conv wgrad anyway (they used to
                 # be 2-3 colsum launches of 16 workgroups each: ~80 us per step of latency-bound finishers)
                 defer = self.defer_reduce
-                gws = self._shared("gnbw%d" % i, int(L.countr_groupnorm_bwd_image_sums_offset(B, HW)) + B * 3 * 256, zero=True) if defer else gn_ws
+                gws = self._shared("gnbw%d" % i, B * 64 * 3 * 256 + 64 + 16 * B + B * 3 * 256) if defer else gn_ws
                 if defer:
                     self._claim(gws.data_ptr())
                 gpar = lambda n: None if defer else self._gp(n)

@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 7 (7: the GroupNorm, masked-MSE and AdamW gradient-norm workspaces start with last-block-done tickets and must be zero-filled by the caller before their first use -- sizes from the *_floats / *_offset helpers; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
+int countr_version(void);               /* ABI version, currently 6 (6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -165,13 +165,9 @@ int countr_colsum_partials(const float* partial, float* out, int nparts, int C, 
 
 /* -------- GroupNorm(8, 256) + ReLU on NHWC maps (decode_head*: models_mae_cross.py:80-100).
  * With w1 != NULL the 1x1 conv 256->1 of decode_head3 (:99) is fused: out1[b,p] = sum_c y*w1[c] + b1 and
- * y may be NULL.  stats: fp32 [B][G][2] (mean, rstd) output.  B <= 256.
- * workspace (ABI 7): fp32 >= countr_groupnorm_bwd_image_sums_offset(B, HW) + B*3*256 for both directions, ZERO-FILLED BY THE CALLER before
- * its first use: its first 256 words are "last block done" tickets, one per image -- the block of an image's reduction that arrives
- * last combines the image's split partials (the finalize launches of ABI <= 6, folded) -- which the kernels leave zero; the rest is
- * scratch: the split partials, then (backward) the per-image sums [B][3][256] = {sum g, sum g*xhat, sum d1*y} at float offset
- * countr_groupnorm_bwd_image_sums_offset(B, HW), for callers that finish dbeta / dgamma / dw1 themselves.  A workspace may serve
- * launches of different B and HW one after the other (the tickets sit at its start), not two at once. */
+ * y may be NULL.  stats: fp32 [B][G][2] (mean, rstd) output.  workspace: fp32 >= B*nsplit*3*256 + 64 + 16*B (forward),
+ * + B*3*256 (backward: behind the split partials its finalize pass leaves the per-image sums [B][3][256] = {sum g, sum g*xhat,
+ * sum d1*y} at float offset countr_groupnorm_bwd_image_sums_offset(B, HW), for callers that finish dbeta / dgamma / dw1 themselves). */
 int countr_groupnorm_nsplit(int HW);
 long long countr_groupnorm_bwd_image_sums_offset(int B, int HW);
 int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
@@ -279,8 +275,7 @@ int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co
 
 /* -------- loss + optimizer (FSC_finetune_cross.py:290-303, :235) */
 /* sums (fp32 [1+2B]) = {loss, pred counts[B], gt counts[B]}; dpred optional (= dloss/dpred * grad_scale);
- * workspace: fp32 [countr_masked_mse_workspace_floats(B)], zero-filled by the caller before its first use (ABI 7: it starts with the
- * last-block-done ticket that folded the finisher launch; the kernel leaves it zero).  Deterministic two-stage reduction. */
+ * workspace: fp32 [countr_masked_mse_workspace_floats(B)].  Deterministic two-stage reduction. */
 /* both permuted shadows (OHWI and dgrad form, see countr_cast_permute modes 1 and 2) of up to 32 weights in ONE launch;
  * the arrays are HOST arrays of n device pointers / shapes (the optimiser step refreshes all shadows at once).  wf[i] may be NULL
  * (only wd is written); with taps = 1 a weight is an nn.Linear matrix [co][ci] and wd its TRANSPOSE [ci][co] -- the K-contiguous
@@ -297,9 +292,8 @@ int countr_masked_mse(const float* pred, const float* gt, const float* mask, flo
  * unused in this iteration but had a gradient before).  hyper_dev (optional, device fp32[8] = {lr, bc1[0], bc2[0], grad_scale,
  * bc1[1], bc2[1], bc1[2], bc2[2]}, bc = 1 - beta^t of the group) overrides the scalars so a captured graph can be replayed with
  * new values; without it every group uses `step`.  shadow_bf16 (optional) receives bf16(p).  gnorm_ws (optional,
- * countr_adamw_gnorm_floats() floats, zero-filled by the caller before its first use -- ABI 7: [norm, ticket, block partials]):
- * gnorm_ws[0] = L2 norm of the (scaled) gradients of the stepped ranges (get_grad_norm_, util/misc.py:289-301), written by the block
- * of the launch that arrives last. */
+ * countr_adamw_gnorm_floats() floats): gnorm_ws[0] = L2 norm of the (scaled) gradients of the stepped ranges
+ * (get_grad_norm_, util/misc.py:289-301). */
 int countr_adamw_gnorm_floats(void);
 int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
                       const int64_t* starts, const int64_t* ends, const float* wds, const int* groups, const int* zero_grad,

@@ -84,9 +84,7 @@ def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
     b1 = torch.tensor([0.05])
     d1 = rnd((B, HW), 10)
     ns = hip.countr_groupnorm_nsplit(HW)
-    # (zero-filled: the workspace starts with the last-block-done tickets of the folded finalize passes -- ABI 7)
-    ws = torch.zeros(int(hip.countr_groupnorm_bwd_image_sums_offset(B, HW)) + B * 3 * Cc, device="cuda")
-    assert ns >= 1
+    ws = torch.empty(B * ns * 3 * Cc + 64 + 16 * B + B * 3 * Cc, device="cuda")
     stats = torch.empty((B, G, 2), device="cuda")
     xd, gd, bd = x.cuda(), g.cuda(), b.cuda()
     y = torch.empty((B, HW, Cc), device="cuda", dtype=tdt)
@@ -367,7 +365,7 @@ def test_masked_mse_and_adamw(hip):
     pd, gd, md = pred.cuda(), gt.cuda(), mask.cuda()
     dp = torch.empty_like(pd)
     sums = torch.empty(1 + 2 * B, device="cuda")
-    ws = torch.zeros(hip.countr_masked_mse_workspace_floats(B), device="cuda")
+    ws = torch.empty(hip.countr_masked_mse_workspace_floats(B), device="cuda")
     _lib.check(hip.countr_masked_mse(P(pd), P(gd), P(md), P(dp), P(sums), P(ws), B, HW, 1.0, st()))
     pr = pred.double().requires_grad_(True)
     loss = R.masked_mse_loss(pr.reshape(B, 384, 384), gt.double().reshape(B, 384, 384), mask.double().reshape(384, 384))
@@ -376,14 +374,6 @@ def test_masked_mse_and_adamw(hip):
     assert relerr(dp, pr.grad) < 1e-5
     assert relerr(sums[1:1 + B], R.counts(pred.double())) < 1e-5
     assert relerr(sums[1 + B:], R.counts(gt.double())) < 1e-5
-    # the finisher is folded into the block that arrives last (ticket at the start of the workspace, self-resetting): repeated calls and
-    # a graph replay give the same bits
-    first = sums.clone()
-    for _ in range(3):
-        sums.fill_(float("nan"))
-        _lib.check(hip.countr_masked_mse(P(pd), P(gd), P(md), P(dp), P(sums), P(ws), B, HW, 1.0, st()))
-        torch.cuda.synchronize()
-        assert torch.equal(sums, first) and float(ws[0].item()) == 0.0
     # AdamW vs the real torch.optim.AdamW (FSC_finetune_cross.py:235): two weight-decay groups; the second range joins at step 2
     # (its gradient was None before -> skipped, own step counter) and gets a zero gradient at step 4 (torch 1.13 zero_grad()
     # semantics: zero tensor, still stepped); scalars and device-hyper forms; gradient norm (util/misc.py:289-301)
