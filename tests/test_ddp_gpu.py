@@ -198,6 +198,10 @@ def test_bench_self_launch_two_ranks():
                   dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["value"] > 0
+    # the timed step object is checked against the oracle outside the timed regions -- at N > 1 the all-reduced flat gradient against
+    # the SUM of the oracle's per-rank gradients (what the collective carried)
+    assert j["parity_checked"] is True and j["parity"]["gradient_tensors"] >= 55 and "sum of the oracle" in j["parity"]["gradients"]
+    assert j["parity"]["min_cos"] > 0.999 and j["parity"]["loss_rel_err"] < 1e-2
 
 
 @pytest.mark.parametrize("what", ["finetune", "pretrain"])
@@ -229,4 +233,5 @@ def test_bench_rccl_one_rank():
                    "--master-port", str(free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
     r = run_retry(cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1"))
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert j["n_gpus"] == 1 and j["value"] > 0
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["parity_checked"] is True
+    assert j["config"]["optimizer_update"].startswith("deferred")        # captured collectives + the deferred optimizer: one graph per step
