@@ -85,10 +85,11 @@ def parity_check(model, step, world, rank, B, NB, dev):
     rc = R.counts(out).numpy()
     rel_cnt = float((abs(sums[1:1 + B].cpu().numpy() - rc) / abs(rc)).max())
     worst_cos, worst_norm, worst_cnn, checked = 1.0, 0.0, 1.0, 0
+    loss_scale = step.loss_scale                  # (fp16 mode: the flat buffer holds loss_scale x gradient)
     for k, ref in total.items():
         if ref.norm() < 1e-3:
             continue
-        got = step.eng.gview(k).detach().cpu().double() / step.loss_scale       # (fp16 mode: the flat buffer holds loss_scale x gradient)
+        got = step.eng.gview(k).detach().cpu().double() / loss_scale
         cos = ((got * ref).sum() / (got.norm() * ref.norm())).item()
         ratio = (got.norm() / ref.norm()).item()
         if k.startswith("decoder_proj"):

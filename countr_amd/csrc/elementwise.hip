@@ -435,8 +435,9 @@ constexpr int MSE_BLOCKS = 64;
 __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                          const float* __restrict__ mask, float* __restrict__ dpred,
                                                          float* __restrict__ partial /* [B][MSE_BLOCKS][3] */, int B, int HW,
-                                                         float grad_scale) {
+                                                         float grad_scale, const float* __restrict__ amp) {
   __shared__ float sm[4];
+  if (amp) grad_scale *= amp[0];      // dynamic loss scale (fp16 mode: countr_amp_* below)
   const int b = blockIdx.y;
   float l = 0.f, sp = 0.f, sg = 0.f;
   const float inv = 1.f / ((float)HW * B);
@@ -503,9 +504,14 @@ struct AdamRanges {
 };
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              bf16_t* __restrict__ shadow, AdamRanges R, float lr, float b1, float b2, float eps, float bc1s,
-                             float bc2s, float grad_scale, const float* __restrict__ hyper, float* __restrict__ gnorm_ws) {
+                             float bc2s, float grad_scale, const float* __restrict__ hyper, float* __restrict__ gnorm_ws,
+                             const float* __restrict__ amp) {
   __shared__ float red[4];
   if (hyper) { lr = hyper[0]; grad_scale = hyper[3]; }  // graph-replay safe
+  if (amp) {                      // fp16 mode (GradScaler semantics, util/misc.py:260-286): a non-finite gradient skips the whole update
+    if (amp[2] != 0.f) return;
+    grad_scale /= amp[0];         // unscale
+  }
   float sq = 0.f;
   for (int r = 0; r < R.n; ++r) {
     const float wd = R.wd[r];
@@ -530,9 +536,26 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     if (threadIdx.x == 0) gnorm_ws[1 + blockIdx.x] = sq;
   }
 }
-__global__ __launch_bounds__(1024) void gnorm_finish_kernel(float* __restrict__ ws, int nb) {   // nb <= 2048 partials: two independent loads per thread
+// amp = {scale, good steps, found_inf (set by amp_check_kernel), skipped steps, growth interval}: torch.cuda.amp.GradScaler's update():
+// found_inf -> scale *= 0.5, good = 0; else ++good == interval -> scale *= 2, good = 0 (util/misc.py:264,278: GradScaler() defaults)
+__device__ __forceinline__ void amp_update(float* __restrict__ amp, float* __restrict__ norm_out) {
+  if (amp[2] != 0.f) {
+    amp[0] *= 0.5f; amp[1] = 0.f; amp[3] += 1.f;
+    if (norm_out) *norm_out = INFINITY;            // (what get_grad_norm_ returns for a non-finite gradient)
+  } else {
+    amp[1] += 1.f;
+    if (amp[1] >= amp[4]) { amp[0] *= 2.f; amp[1] = 0.f; }
+  }
+  amp[2] = 0.f;
+}
+__global__ __launch_bounds__(1024) void gnorm_finish_kernel(float* __restrict__ ws, int nb, float* __restrict__ amp) {   // nb <= 2048 partials: two independent loads per thread
   __shared__ float part[16];
   const int t = threadIdx.x;
+  if (amp && amp[2] != 0.f) {     // skipped update: no partials were written
+    __syncthreads();
+    if (t == 0) amp_update(amp, ws);
+    return;
+  }
   const float a = t < nb ? ws[1 + t] : 0.f, b = t + 1024 < nb ? ws[1 + t + 1024] : 0.f;
   const float s = wave_sum(a + b);     // fixed summation tree: deterministic
   if ((t & 63) == 0) part[t >> 6] = s;
@@ -542,7 +565,27 @@ __global__ __launch_bounds__(1024) void gnorm_finish_kernel(float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 16; ++k) tot += part[k];
     ws[0] = sqrtf(tot);
+    if (amp) amp_update(amp, nullptr);
   }
+}
+__global__ __launch_bounds__(64) void amp_update_kernel(float* __restrict__ amp) { if (threadIdx.x == 0) amp_update(amp, nullptr); }
+
+// found_inf of GradScaler.unscale_: amp[2] = 1 if any gradient element of the ranges the update will read is non-finite.  (Plain stores of
+// the same value from every block that finds one: no atomics.)  After a gradient all-reduce every rank sees the same flag: inf / nan
+// survive the sum.
+__global__ __launch_bounds__(256) void amp_check_kernel(const float* __restrict__ g, AdamRanges R, float* __restrict__ amp) {
+  bool bad = false;
+  for (int r = 0; r < R.n; ++r) {
+    if (R.zero[r]) continue;
+    for (int64_t i = R.start[r] + (int64_t)blockIdx.x * 256 + threadIdx.x; i < R.end[r]; i += (int64_t)gridDim.x * 256 * 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = i + (int64_t)u * gridDim.x * 256;
+        if (k < R.end[r]) bad |= !isfinite(g[k]);
+      }
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) amp[2] = 1.f;
 }
 
 }  // namespace
@@ -800,19 +843,36 @@ extern "C" int countr_conv_shadows(int n, const float* const* src, void* const* 
 }
 
 extern "C" int countr_masked_mse_workspace_floats(int B) { return B * MSE_BLOCKS * 3; }
+extern "C" int countr_masked_mse_amp(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
+                                     float* workspace, int B, int HW, float grad_scale, const float* amp, void* stream);
 extern "C" int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
                                  float* workspace, int B, int HW, float grad_scale, void* stream) {
+  return countr_masked_mse_amp(pred, gt, mask, dpred, sums, workspace, B, HW, grad_scale, nullptr, stream);
+}
+extern "C" int countr_masked_mse_amp(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
+                                     float* workspace, int B, int HW, float grad_scale, const float* amp, void* stream) {
   if (!pred || !gt || !mask || !sums || !workspace) { countr_set_error("countr_masked_mse: null"); return -1; }
-  hipLaunchKernelGGL(masked_mse_kernel, dim3(MSE_BLOCKS, B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, workspace, B, HW, grad_scale);
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(MSE_BLOCKS, B), dim3(256), 0, STREAM(stream), pred, gt, mask, dpred, workspace, B, HW, grad_scale, amp);
   hipLaunchKernelGGL(masked_mse_finish_kernel, dim3(1), dim3(64), 0, STREAM(stream), workspace, sums, B, MSE_BLOCKS);
   COUNTR_LAUNCH_CHECK("countr_masked_mse");
 }
 
 extern "C" int countr_adamw_gnorm_floats(void) { return 1 + 2048; }
+extern "C" int countr_adamw_step_amp(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
+                                     const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
+                                     const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                     const float* hyper_dev, float* gnorm_ws, float* amp, void* stream);
 extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
                                  const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
                                  const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                                  const float* hyper_dev, float* gnorm_ws, void* stream) {
+  return countr_adamw_step_amp(p, g, m, v, shadow_bf16, nranges, starts, ends, wds, groups, zero_grad, lr, beta1, beta2, eps, step, grad_scale,
+                               hyper_dev, gnorm_ws, nullptr, stream);
+}
+extern "C" int countr_adamw_step_amp(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
+                                     const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
+                                     const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                     const float* hyper_dev, float* gnorm_ws, float* amp, void* stream) {
   if (!p || !g || !m || !v || nranges < 1 || nranges > 16 || (step < 1 && !hyper_dev)) { countr_set_error("countr_adamw_step: bad args (1..16 ranges, step >= 1)"); return -1; }
   AdamRanges R;
   R.n = nranges;
@@ -825,8 +885,10 @@ extern "C" int countr_adamw_step(float* p, const float* g, float* m, float* v, v
   }
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   const int nb = nblocks(total, 256, 2048);
-  hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev, gnorm_ws);
-  if (gnorm_ws) hipLaunchKernelGGL(gnorm_finish_kernel, dim3(1), dim3(1024), 0, STREAM(stream), gnorm_ws, nb);
+  if (amp) hipLaunchKernelGGL(amp_check_kernel, dim3(nblocks(total, 1024, 2048)), dim3(256), 0, STREAM(stream), g, R, amp);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, STREAM(stream), p, g, m, v, (bf16_t*)shadow_bf16, R, lr, beta1, beta2, eps, bc1, bc2, grad_scale, hyper_dev, gnorm_ws, amp);
+  if (gnorm_ws) hipLaunchKernelGGL(gnorm_finish_kernel, dim3(1), dim3(1024), 0, STREAM(stream), gnorm_ws, nb, amp);
+  else if (amp) hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, STREAM(stream), amp);
   COUNTR_LAUNCH_CHECK("countr_adamw_step");
 }
 

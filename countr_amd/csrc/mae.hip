@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const TS* __restrict__
 template <typename TD>
 __global__ __launch_bounds__(256) void patch_mse_kernel(const float* __restrict__ pred, const float* __restrict__ imgs, TD* __restrict__ dpred,
                                                         float* __restrict__ partial, int rows, int H, int W, int p, int norm_pix,
-                                                        float gscale) {
+                                                        float gscale, const float* __restrict__ amp) {
+  if (amp) gscale *= amp[0];      // dynamic loss scale (fp16 mode: countr_amp_*, elementwise.hip)
   __shared__ float sm[4];
   const int row = blockIdx.x, gw = W / p, L = (H / p) * gw, F = 3 * p * p;
   const int b = row / L, l = row % L, ph = l / gw, pw = l % gw;
@@ -134,16 +135,20 @@ extern "C" int countr_gather_rows(const void* src, const int* idx, void* dst, co
 }
 
 extern "C" int countr_patch_mse_workspace_floats(int B, int H, int W, int patch) { return B * (H / patch) * (W / patch); }
-extern "C" int countr_patch_mse(const float* pred, const float* imgs, void* dpred, float* loss, float* workspace, int B, int H, int W,
-                                int patch, int norm_pix, float grad_scale, int dpred_dtype, void* stream) {
+extern "C" int countr_patch_mse_amp(const float* pred, const float* imgs, void* dpred, float* loss, float* workspace, int B, int H, int W,
+                                    int patch, int norm_pix, float grad_scale, int dpred_dtype, const float* amp, void* stream) {
   if (!pred || !imgs || !loss || !workspace || patch < 1 || H % patch || W % patch || 3 * patch * patch > 1024) {
     countr_set_error("countr_patch_mse: bad args (H, W multiples of patch; 3*patch^2 <= 1024)"); return -1;
   }
   const int rows = B * (H / patch) * (W / patch), F = 3 * patch * patch;
   if (dpred_dtype == COUNTR_BF16)
-    hipLaunchKernelGGL(patch_mse_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), pred, imgs, (bf16_t*)dpred, workspace, rows, H, W, patch, norm_pix, grad_scale);
+    hipLaunchKernelGGL(patch_mse_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), pred, imgs, (bf16_t*)dpred, workspace, rows, H, W, patch, norm_pix, grad_scale, amp);
   else
-    hipLaunchKernelGGL(patch_mse_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), pred, imgs, (float*)dpred, workspace, rows, H, W, patch, norm_pix, grad_scale);
+    hipLaunchKernelGGL(patch_mse_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), pred, imgs, (float*)dpred, workspace, rows, H, W, patch, norm_pix, grad_scale, amp);
   hipLaunchKernelGGL(patch_mse_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), workspace, loss, rows, 1.f / ((float)F * (float)rows));
   COUNTR_LAUNCH_CHECK("countr_patch_mse");
+}
+extern "C" int countr_patch_mse(const float* pred, const float* imgs, void* dpred, float* loss, float* workspace, int B, int H, int W,
+                                int patch, int norm_pix, float grad_scale, int dpred_dtype, void* stream) {
+  return countr_patch_mse_amp(pred, imgs, dpred, loss, workspace, B, H, W, patch, norm_pix, grad_scale, dpred_dtype, nullptr, stream);
 }

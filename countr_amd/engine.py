@@ -1310,7 +1310,7 @@ class Engine:
         return self.layout.adam_plan(weight_decay, skip, zero)
 
     def adamw_launch(self, S, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, lr=0.0, step=0, grad_scale=1.0, hyper_dev=None, skip=None,
-                     zero=(), gnorm=False, stream=None):
+                     zero=(), gnorm=False, stream=None, amp=None):
         """Enqueue the fused AdamW (+ shadow refresh).  hyper_dev: device fp32[8] {lr, bc1[0], bc2[0], grad_scale, bc1[1], bc2[1],
         bc1[2], bc2[2]} read by the kernel at run time, so a captured launch can be replayed with new values.  skip=None: the
         shot_num rule of adam_ranges (parameters without a gradient for S are skipped)."""
@@ -1331,10 +1331,12 @@ class Engine:
             self.gnorm = torch.zeros(self.L.countr_adamw_gnorm_floats(), device=self.device, dtype=torch.float32)
         lay = self.layout
         shadow = (self.Wt.data_ptr() + 2 * lay.train_start) if self.half else None
-        _lib.check(self.L.countr_adamw_step(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                            shadow, n, starts, ends, wds, groups, zeros, lr, betas[0], betas[1], eps, step, grad_scale,
-                                            hyper_dev.data_ptr() if hyper_dev is not None else None,
-                                            self.gnorm.data_ptr() if gnorm else None, stream if stream is not None else self._stream()), "adamw")
+        # amp (fp16 mode): device fp32[8] of the dynamic loss scale -- non-finite gradients skip the update (countr_adamw_step_amp)
+        _lib.check(self.L.countr_adamw_step_amp(self.P.data_ptr() + 4 * lay.train_start, self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                shadow, n, starts, ends, wds, groups, zeros, lr, betas[0], betas[1], eps, step, grad_scale,
+                                                hyper_dev.data_ptr() if hyper_dev is not None else None,
+                                                self.gnorm.data_ptr() if gnorm else None, amp.data_ptr() if amp is not None else None,
+                                                stream if stream is not None else self._stream()), "adamw")
         self._refresh_conv_shadows(stream)
 
     def adamw_step(self, S, lr, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):

@@ -255,12 +255,12 @@ class MaeEngine(Engine):
                                              self._stream()), "mae_indices")
         return ids_restore
 
-    def loss_launch(self, p, B, norm_pix, grad_scale=1.0, with_grad=True):
+    def loss_launch(self, p, B, norm_pix, grad_scale=1.0, with_grad=True, amp=None):
         ws = self._ws["mse"]
         dp = p.buf["dpred"].data_ptr() if with_grad else None
-        _lib.check(self.L.countr_patch_mse(p.buf["pred"].data_ptr(), p.buf["img"].data_ptr(), dp, p.buf["loss"].data_ptr(), ws.data_ptr(),
-                                           B, self.img, self.img, self.patch, int(bool(norm_pix)), float(grad_scale), self.code,
-                                           self._stream()), "patch_mse")
+        _lib.check(self.L.countr_patch_mse_amp(p.buf["pred"].data_ptr(), p.buf["img"].data_ptr(), dp, p.buf["loss"].data_ptr(), ws.data_ptr(),
+                                               B, self.img, self.img, self.patch, int(bool(norm_pix)), float(grad_scale), self.code,
+                                               amp.data_ptr() if amp is not None else None, self._stream()), "patch_mse")
 
     def forward(self, imgs, ids_shuffle, len_keep, train=False, norm_pix=False):
         """-> (loss [1], pred [B, N, F], mask [B, N]) buffers of the plan (overwritten by the next call)."""

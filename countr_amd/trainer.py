@@ -132,12 +132,14 @@ class _GraphStep:
         self._pc_hyper = None          # ... and its scalars {lr, bias corrections, grad_scale}
         self._cur_pc = None
         self.grad_scale = 1.0 / self.accum
-        # fp16 mode: the loss gradient is multiplied by a constant before the 16-bit backward and divided out again inside the fused
-        # AdamW (its grad_scale scalar) -- the reference's GradScaler (util/misc.py:260-286) with its INITIAL scale 65536 held fixed:
-        # dL/dout of this loss is ~1e-9 per pixel (2 (out - gt) / (384^2 B)), far below fp16's normal range, and at most ~2e-5, so
-        # 2^16 cannot overflow.  Not reproduced: GradScaler's skip-and-halve on a non-finite gradient (the CLI stops on a non-finite
-        # loss instead).  bf16 / fp32: 1.
-        self.loss_scale = 65536.0 if self.eng.precision == "fp16" else 1.0
+        # fp16 mode: torch.cuda.amp.GradScaler as the reference uses it (util/misc.py:260-286; GradScaler() defaults: scale 65536, growth
+        # x 2 every 2000 clean steps, x 0.5 and NO optimizer step on a non-finite gradient), kept on the device so that the captured step
+        # needs no host decision: amp = {scale, clean steps, found_inf, skipped steps, growth interval}.  The loss kernel multiplies dL/dout
+        # by amp[0] (it is ~1e-9 per pixel: below fp16's normal range), the fused AdamW checks the (all-reduced) gradient, skips or
+        # unscales, and updates the scale (countr_*_amp).  One deviation: the host-side bias-correction counters also advance on a
+        # skipped step (torch's do not) -- they differ by the number of overflows so far (`skipped_steps()`).  bf16 / fp32: no scaling.
+        self.amp = (torch.tensor([65536.0, 0.0, 0.0, 0.0, 2000.0, 0.0, 0.0, 0.0], device=self.eng.device, dtype=torch.float32)
+                    if self.eng.precision == "fp16" else None)
 
     def _make_sync(self, process_group):
         return GradSync(self.eng.G, self.bucket0, self.bucket_rest, process_group)
@@ -243,7 +245,17 @@ class _GraphStep:
 
     def _phase_c(self, key, stream=None):
         skip, zero = key
-        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip, zero=zero, gnorm=True, stream=stream)
+        self.eng.adamw_launch(1, self.wd, self.betas, self.eps, hyper_dev=self.eng.hyper, skip=skip, zero=zero, gnorm=True, stream=stream, amp=self.amp)
+
+    @property
+    def loss_scale(self):
+        """The factor the flat gradient buffer currently carries (fp16 mode: the dynamic loss scale, read back from the device -- a host
+        sync; 1 otherwise)."""
+        return float(self.amp[0].item()) if self.amp is not None else 1.0
+
+    def skipped_steps(self):
+        """fp16 mode: optimizer steps skipped so far because a gradient was not finite (GradScaler semantics); host sync."""
+        return int(self.amp[3].item()) if self.amp is not None else 0
 
     def flush(self):
         """defer_optimizer mode: apply the optimizer update that is still pending (the last step's), so that the parameters, the AdamW
@@ -335,7 +347,7 @@ class _GraphStep:
                 eng.group_steps[grp] += 1
         h = self.pro.hyper
         h[0] = self.lr
-        h[3] = self.grad_scale / self.world / self.loss_scale
+        h[3] = self.grad_scale / self.world          # (fp16 mode: the AdamW kernel divides by the device-side loss scale itself)
         for grp, (i1, i2) in enumerate(((1, 2), (4, 5), (6, 7))):
             t = max(eng.group_steps[grp], 1)
             h[i1] = 1.0 - self.betas[0] ** t
@@ -605,8 +617,9 @@ class FinetuneStep(_GraphStep):
             self.sums[S] = torch.zeros(1 + 2 * self.B, device=eng.device)
         sums = self.sums[S]
         HW = eng.img * eng.img
-        _lib.check(eng.L.countr_masked_mse(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
-                                           sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, float(self.loss_scale), eng._stream()), "masked_mse")
+        _lib.check(eng.L.countr_masked_mse_amp(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
+                                               sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0,
+                                               self.amp.data_ptr() if self.amp is not None else None, eng._stream()), "masked_mse")
         eng.run(self._lists(p, acc).bwd_head)
 
     def _prologue_mask(self):
@@ -782,7 +795,7 @@ class PretrainStep(_GraphStep):
         p = eng.plan(self.B, K, True)
         self._prologue_launch()
         eng.run(p.fwd)
-        eng.loss_launch(p, self.B, self.model.norm_pix_loss, grad_scale=float(self.loss_scale))
+        eng.loss_launch(p, self.B, self.model.norm_pix_loss, amp=self.amp)
         eng.run(self._lists(p, acc).bwd_dec)
 
     def _make_sync(self, process_group):

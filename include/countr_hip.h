@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 6 (6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
+int countr_version(void);               /* ABI version, currently 7 (7: countr_masked_mse_amp / countr_patch_mse_amp / countr_adamw_step_amp added, no layout change; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -294,6 +294,22 @@ int countr_masked_mse(const float* pred, const float* gt, const float* mask, flo
  * new values; without it every group uses `step`.  shadow_bf16 (optional) receives bf16(p).  gnorm_ws (optional,
  * countr_adamw_gnorm_floats() floats): gnorm_ws[0] = L2 norm of the (scaled) gradients of the stepped ranges
  * (get_grad_norm_, util/misc.py:289-301). */
+/* Dynamic loss scaling of the fp16 mode (ABI 7) = torch.cuda.amp.GradScaler as the reference uses it (util/misc.py:260-286: scale the
+ * loss, unscale_, skip the optimizer step on a non-finite gradient, update()), on the device so that a captured step needs no host
+ * decision.  amp: device fp32[8] owned by the caller = {scale (GradScaler's initial 65536), steps since the last change, found_inf,
+ * skipped steps so far, growth interval (GradScaler's 2000), reserved x 3}.
+ *   countr_masked_mse_amp / countr_patch_mse_amp: the loss gradient is multiplied by grad_scale * amp[0];
+ *   countr_adamw_step_amp: amp[2] <- any non-finite gradient in the ranges it reads (after an all-reduce every rank sees the same);
+ *     if set: parameters, moments and shadows are left untouched, gnorm_ws[0] = inf, scale *= 0.5, amp[3] += 1; otherwise the gradients
+ *     are divided by amp[0] on the fly, and after `interval` updates without a skip scale *= 2.  amp == NULL: countr_adamw_step. */
+int countr_masked_mse_amp(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
+                          float* workspace, int B, int HW, float grad_scale, const float* amp, void* stream);
+int countr_patch_mse_amp(const float* pred, const float* imgs, void* dpred, float* loss, float* workspace, int B, int H, int W,
+                         int patch, int norm_pix, float grad_scale, int dpred_dtype, const float* amp, void* stream);
+int countr_adamw_step_amp(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
+                          const int64_t* starts, const int64_t* ends, const float* wds, const int* groups,
+                          const int* zero_grad, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                          const float* hyper_dev, float* gnorm_ws, float* amp, void* stream);
 int countr_adamw_gnorm_floats(void);
 int countr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int nranges,
                       const int64_t* starts, const int64_t* ends, const float* wds, const int* groups, const int* zero_grad,

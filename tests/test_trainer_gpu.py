@@ -474,3 +474,50 @@ def test_deferred_optimizer_is_bit_identical(precision, accum):
     assert a[6]["countr_amd"] == b[6]["countr_amd"]
     moved = sum(float((a[1][k].cpu() - torch.from_numpy(sd[k])).abs().max()) > 0 for k in a[1] if k.startswith(("decoder", "decode_head", "shot_token")) and "pos_embed" not in k)
     assert moved >= 40
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_fp16_dynamic_loss_scale_follows_gradscaler(defer):
+    """fp16 mode = the reference's AMP loop (FSC_finetune_cross.py:286,313; util/misc.py:260-286: GradScaler().scale(loss).backward(),
+    unscale_, step skipped on a non-finite gradient, update()) with the scaler's state on the device.  Started from an absurd scale (2^40:
+    every 16-bit gradient overflows) with growth interval 3: while the gradient is not finite the parameters and moments do not move
+    (bit for bit), the logged norm is inf and the scale halves; from the first finite gradient on the parameters move, and the scale
+    follows GradScaler's rule step by step (x 2 after 3 clean steps, x 0.5 on an overflow)."""
+    from countr_amd.trainer import FinetuneStep
+    m, sd = make("fp16")
+    step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=True, defer_optimizer=defer, mask_seed=3)
+    step.amp[0], step.amp[4] = 2.0 ** 40, 3.0
+    p0 = {k: p.detach().clone() for k, p in m.named_parameters()}
+    scale, good, skipped, first_clean = 2.0 ** 40, 0, 0, None
+    for it in range(60):
+        imgs, boxes, gt, _mask = W.make_inputs(batch=2, shots=3, seed=300 + it % 4)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt)), None, 3)
+        loss = step.step(3)[0].item()
+        gn = step.grad_norm().item()                   # (flushes a deferred update)
+        assert np.isfinite(loss)
+        now, nskip = step.loss_scale, step.skipped_steps()
+        if nskip > skipped:                            # this step's gradient was not finite
+            assert gn == float("inf") and now == scale * 0.5
+            scale, good, skipped = scale * 0.5, 0, nskip
+            if first_clean is None:
+                for k, p in m.named_parameters():
+                    assert torch.equal(p.detach(), p0[k]), k
+                assert float(step.eng.M.abs().max()) == 0.0 and float(step.eng.V.abs().max()) == 0.0
+        else:
+            assert np.isfinite(gn) and gn > 0
+            good += 1
+            if good == 3:
+                scale, good = scale * 2.0, 0
+            assert now == scale, (it, now, scale)
+            if first_clean is None:
+                first_clean = it
+                moved = sum(float((p.detach() - p0[k]).abs().max()) > 0 for k, p in m.named_parameters() if k.startswith(("decoder", "decode_head")) and "pos_embed" not in k)
+                assert moved >= 40
+                # the unscaled gradient of that step against the oracle at the untouched initial parameters
+                _, _, rg = R.loss_and_grads(sd, imgs, boxes, gt, step.mask.cpu().numpy(), 3, NAME)
+                k = "decode_head0.0.weight"
+                got = step.eng.gview(k).detach().cpu().double() / (now if good else now / 2.0)
+                ref = rg[k].double()
+                assert ((got * ref).sum() / (got.norm() * ref.norm())).item() > 0.999
+    assert first_clean is not None and 10 <= first_clean <= 45, first_clean       # 2^40 -> the first scale whose backward stays finite
+    assert skipped >= first_clean and all(torch.isfinite(p).all() for p in m.parameters())
