@@ -1,3 +1,7 @@
+#!/bin/bash
+# Same-box, interleaved, unprofiled A/B of an older tree against the working tree (profiles/r5_ab_r4_tree.txt).  Prepare once in the build
+# container:  mkdir _r4tree && git archive b61323b | tar -x -C _r4tree && (cd _r4tree && python -m countr_amd.build)   (_r4tree/ is not tracked)
+# then:       gpurun -- 'bash tools/ab_r4_r5.sh'
 cd $GRAFT_REPO_ROOT
 run() { (cd $1; python bench.py --plain --reps 3 $2 2>/dev/null | python -c "
 import json,sys
