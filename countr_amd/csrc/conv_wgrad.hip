@@ -264,6 +264,184 @@ __device__ __forceinline__ void cwg_body(const CwgArgs& g, const int v) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Form 3 (round 5): the THREE taps of one kernel row per workgroup.  For maps whose rows are whole k-tiles (W % 64 == 0: the 192 x 192
+// layer, 43 of the head's 58 GF) the 64 pixels of a k-tile lie in one image row, so the im2col operands of the taps (dy, -1), (dy, 0),
+// (dy, +1) are ONE row segment of the input map read at three pixel offsets.  The segment is staged once -- 72 pixel rows: the k-tile's
+// 64 + a 4-row piece on either side for the +-1 neighbours (80 rows are issued so that every loader wave issues the same count; the
+// last 8 are lanes outside the descriptor) -- in the same 256-byte-row / XOR-slot image as the other forms, and the three B fragments
+// of a k-step are transposing reads at row offsets 3, 4, 5 with the slot XOR following the row ((rr + dx) & 3: the 16-lane group still
+// touches four consecutive rows, so the reads stay conflict-free).  Tile = 128 (Cout) x 128 (Cin) x 3 taps: 36 KB staged per 192
+// MFMAs (form 2: 48 KB per 128) and a dy fragment serves three MFMAs.  8 compute waves (64 x 32 x 3 taps each: 96 accumulator
+// registers) + 4 loader waves, 3-stage ring of 36 KB.  Padding: image rows outside [0, H) and pixels outside [0, W) are lanes pushed
+// outside the descriptor, as everywhere.  Bias gradient: 12 waves on a CU leave a wave 168 registers, which the 96 accumulators + two
+// fragment sets fill, so the row sums of dy are taken by the LOADER waves (idle between their issue and the next barrier): the
+// k-tiles of a (slab, tile_m) are dealt round-robin to its tilesN workgroups, whose loader wave w multiplies rows [32 w, +32) of the
+// staged dy tile by a ones fragment (4 MFMAs in 1 of tilesN k-tiles), each workgroup writing its own slab.
+constexpr int C3_A = 64 * 256, C3_B = 80 * 256, C3_STAGE = C3_A + C3_B, C3_STAGES = 3;
+
+struct Frag5 { Frag f[5]; };   // a0, a1 (two 32-row tiles of dy), b(-1), b(0), b(+1)
+template <int PENDING> __device__ __forceinline__ void frag_wait5(Frag5& s) {
+  asm volatile("s_waitcnt lgkmcnt(%10)"
+               : "+v"(s.f[0].lo), "+v"(s.f[0].hi), "+v"(s.f[1].lo), "+v"(s.f[1].hi), "+v"(s.f[2].lo), "+v"(s.f[2].hi), "+v"(s.f[3].lo), "+v"(s.f[3].hi),
+                 "+v"(s.f[4].lo), "+v"(s.f[4].hi)
+               : "n"(PENDING));
+}
+
+__device__ __forceinline__ void cwg3_body(const CwgArgs& g, const int v) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 8;
+  const int cw = loader ? wv - 8 : wv;
+  const int z = v / g.tiles, lt = v - z * g.tiles;
+  const int tile_m = lt / g.tilesN, tile_n = lt - tile_m * g.tilesN;
+  const int nci = g.Cin >> 7;
+  const int row3 = tile_n / nci, ci0 = (tile_n - row3 * nci) * 128;
+  const int dyt = row3 - 1, m0 = tile_m * 128;
+  const int kt0 = min(z * g.per, g.nkt), kt1 = min(kt0 + g.per, g.nkt);
+  const int ntiles = kt1 - kt0;
+
+  if (loader) {
+    const int krow = lane >> 4, c8 = (lane & 15) ^ (krow << 2);
+    const uint32_t voffA = (uint32_t)(((cw * 4 + krow) * g.lda + c8 * 8) * 2);
+    const uint32_t voffB = (uint32_t)(((cw * 4 + krow) * g.ldb + c8 * 8) * 2);
+    const int64_t cshift = (int64_t)(g.Wd + 8) * g.ldb * 2;          // descriptor base in front of the map: every shift (dy W - 4 pixels) >= 0
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.dy + ((int64_t)kt0 * 64 * g.lda + m0) * 2), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.x + ((int64_t)kt0 * 64 * g.ldb + ci0) * 2 - cshift), 0, 0x7ffffff0, 0x00020000);
+    const uint32_t tapoff = (uint32_t)(cshift + (int64_t)(dyt * g.Wd - 4) * g.ldb * 2);
+    const uint32_t passA = (uint32_t)g.lda * 32u, passB = (uint32_t)g.ldb * 32u, tileA = (uint32_t)g.lda * 128u, tileB = (uint32_t)g.ldb * 128u;
+    int x0 = (int)(((int64_t)kt0 * 64) % g.Wd), y = (int)((((int64_t)kt0 * 64) / g.Wd) % g.H);      // of the NEXT tile to be issued
+    auto issue = [&](int t, int slot_) {      // called with t = 0, 1, 2, ... in order
+      char* dst = smem + slot_ * C3_STAGE + cw * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * 4096), 16, voffA, t * tileA + i * passA, 0, 0);
+      const bool rowok = (unsigned)(y + dyt) < (unsigned)g.H;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int r = 16 * i + 4 * cw + krow, xx = x0 - 4 + r;
+        const bool ok = rowok && r < 72 && (unsigned)xx < (unsigned)g.Wd;
+        const uint32_t vo = ok ? voffB : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + C3_A + i * 4096), 16, vo, tapoff + t * tileB + i * passB, 0, 0);
+      }
+      x0 += 64;
+      if (x0 >= g.Wd) { x0 = 0; y = (y + 1 == g.H) ? 0 : y + 1; }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < C3_STAGES - 1; ++s_)
+      if (s_ < ntiles) issue(s_, s_);
+    constexpr int PER = 9;
+    const int l15 = lane & 15, q16 = (lane >> 4) & 1, lh = lane >> 5, rr = l15 >> 2, bb = l15 & 3;
+    const uint32_t offR = (uint32_t)((lh * 8 + rr) * 256 + (((cw * 4 + q16 * 2 + (bb >> 1)) ^ (rr << 2)) << 4) + (bb & 1) * 8);
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR));
+    const bool want_rs = g.rowsum != nullptr;
+    f32x16_t accb;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+    int islot = C3_STAGES - 1, slot = 0, tmod = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + C3_STAGES - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C3_STAGES - 2) * PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + C3_STAGES - 1 < ntiles) issue(t + C3_STAGES - 1, islot);
+      islot = (islot + 1 == C3_STAGES) ? 0 : islot + 1;
+      if (want_rs && tmod == tile_n) {       // (stage `slot` is complete behind the barrier and is overwritten only behind the next one)
+        const uint32_t sb = lds_u32(smem) + slot * C3_STAGE + offR;
+        Frag f0, f1, f2, f3;
+        f0.lo = ds_tr<0>(sb); f0.hi = ds_tr<1024>(sb);
+        f1.lo = ds_tr<4096>(sb); f1.hi = ds_tr<4096 + 1024>(sb);
+        f2.lo = ds_tr<8192>(sb); f2.hi = ds_tr<8192 + 1024>(sb);
+        f3.lo = ds_tr<12288>(sb); f3.hi = ds_tr<12288 + 1024>(sb);
+        Frag fr4[4] = {f0, f1, f2, f3};
+        frag_wait<0>(fr4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) accb = COUNTR_MFMA_32X32X16(frag_bits(fr4[kk]), ones, accb, 0, 0, 0);
+      }
+      tmod = (tmod + 1 == g.tilesN) ? 0 : tmod + 1;
+      slot = (slot + 1 == C3_STAGES) ? 0 : slot + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (want_rs && (lane & 31) == 0) {
+      float* rs = g.rowsum + (int64_t)(z * g.tilesN + tile_n) * g.Cout + m0 + cw * 32 + 4 * lh;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rs[(e & 3) + 8 * (e >> 2)] = accb[e];
+    }
+    return;
+  }
+
+  // ---- compute waves: wave (wm, wn) owns rows [64 wm, +64) of the tile's Cout and channels [32 wn, +32) of its Cin, for the three taps
+  const int wm = cw >> 2, wn = cw & 3;
+  const int l15 = lane & 15, q16 = (lane >> 4) & 1, lh = lane >> 5, rr = l15 >> 2, bb = l15 & 3;
+  uint32_t offA[2], offB[3];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int ca = wm * 8 + t2 * 4 + q16 * 2 + (bb >> 1);
+    offA[t2] = (uint32_t)((lh * 8 + rr) * 256 + ((ca ^ (rr << 2)) << 4) + (bb & 1) * 8);
+  }
+  const int cb = wn * 4 + q16 * 2 + (bb >> 1);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {      // dx = d - 1: staged row 4 + dx + (k within the tile)
+    const int row = 3 + d + lh * 8 + rr, sw = (rr + d + 3) & 3;
+    offB[d] = (uint32_t)(C3_A + row * 256 + ((cb ^ (sw << 2)) << 4) + (bb & 1) * 8);
+  }
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[d][tm][e] = 0.f;
+  Frag5 fs[2];
+#define C3_RD(SET, KK)                                                                                                    \
+  { fs[SET].f[0].lo = ds_tr<(KK) * 4096>(sb + offA[0]); fs[SET].f[0].hi = ds_tr<(KK) * 4096 + 1024>(sb + offA[0]);         \
+    fs[SET].f[1].lo = ds_tr<(KK) * 4096>(sb + offA[1]); fs[SET].f[1].hi = ds_tr<(KK) * 4096 + 1024>(sb + offA[1]);         \
+    fs[SET].f[2].lo = ds_tr<(KK) * 4096>(sb + offB[0]); fs[SET].f[2].hi = ds_tr<(KK) * 4096 + 1024>(sb + offB[0]);         \
+    fs[SET].f[3].lo = ds_tr<(KK) * 4096>(sb + offB[1]); fs[SET].f[3].hi = ds_tr<(KK) * 4096 + 1024>(sb + offB[1]);         \
+    fs[SET].f[4].lo = ds_tr<(KK) * 4096>(sb + offB[2]); fs[SET].f[4].hi = ds_tr<(KK) * 4096 + 1024>(sb + offB[2]); }
+#define C3_MM(SET)                                                                                                        \
+  { _Pragma("unroll") for (int d = 0; d < 3; ++d) { _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                         \
+      acc[d][tm] = COUNTR_MFMA_32X32X16(frag_bits(fs[SET].f[tm]), frag_bits(fs[SET].f[2 + d]), acc[d][tm], 0, 0, 0); } }
+  int slot = 0;
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < ntiles; ++t) {
+    const uint32_t sb = lds_u32(smem) + slot * C3_STAGE;
+    C3_RD(0, 0);
+    C3_RD(1, 1); frag_wait5<10>(fs[0]); C3_MM(0);
+    C3_RD(0, 2); frag_wait5<10>(fs[1]); C3_MM(1);
+    C3_RD(1, 3); frag_wait5<10>(fs[0]); C3_MM(0);
+    frag_wait5<0>(fs[1]); C3_MM(1);
+    slot = (slot + 1 == C3_STAGES) ? 0 : slot + 1;
+    __builtin_amdgcn_s_barrier();
+  }
+#undef C3_RD
+#undef C3_MM
+  // ---- raw fp32 partial sums: accumulator register e of lane (l31, lh) = row (e & 3) + 8 (e >> 2) + 4 lh, column l31 of its 32x32 tile
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float* out = g.part + (int64_t)z * g.Cout * g.N + (int64_t)(m0 + wm * 64 + 4 * lh) * g.N + (row3 * 3 + d) * g.Cin + ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[(int64_t)(tm * 32 + (e & 3) + 8 * (e >> 2)) * g.N] = acc[d][tm][e];
+  }
+}
+
+__global__ __launch_bounds__(768) void cwg3_kernel(const CwgArgs g) { cwg3_body(g, cwg_virtual_index()); }
+
+int launch_cwg3(const CwgArgs& a, hipStream_t s) {
+  constexpr int lds = C3_STAGES * C3_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cwg3_kernel, dim3(a.tiles * a.Z), dim3(768), lds, s, a);
+  COUNTR_LAUNCH_CHECK("countr_gemm(conv wgrad, three taps per workgroup)");
+}
+
 template <int WNB, bool LIN>
 __global__ __launch_bounds__(256 * WNB + 256, (4 * WNB + 4) / 4) void cwg_kernel(const CwgArgs g) {
   cwg_body<WNB, LIN>(g, cwg_virtual_index());
@@ -311,7 +489,11 @@ int launch_cwg(const CwgArgs& a, hipStream_t s) {
   COUNTR_LAUNCH_CHECK("countr_gemm(lean conv wgrad)");
 }
 
-// form: 0 = does not qualify, 1 = 128x128 tiles, 2 = 128x256 tiles.  lin: the (COL, COL) launch of an nn.Linear weight gradient
+// Contributors that share the bias-gradient of one (slab, row block) = rowsum slabs per split-K slab
+static int cwg_contributors(const countr_gemm_args* a, int form) { return form == 3 ? 3 * (a->Cin / 128) : a->N / 128; }
+
+// form: 0 = does not qualify, 1 = 128x128 tiles, 2 = 128x256 tiles, 3 = 128 x 128 x the three taps of a kernel row (conv only).
+// lin: the (COL, COL) launch of an nn.Linear weight gradient
 int cwg_form(const countr_gemm_args* a, bool lin) {
   { const char* e = getenv("COUNTR_LEAN"); if (e && atoi(e) == 0) return 0; }
   { const char* e = getenv(lin ? "COUNTR_LEAN_LWGRAD" : "COUNTR_LEAN_WGRAD"); if (e && atoi(e) == 0) return 0; }
@@ -326,7 +508,6 @@ int cwg_form(const countr_gemm_args* a, bool lin) {
     if ((int64_t)(a->K + 2 * a->W + 2) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->K * a->M * 2 >= (int64_t)0x7f000000ll) return 0;
   }
   if ((((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->partial) & 15)) return 0;
-  if (a->rowsum_partial && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1) * (a->N / 128)) return 0;   // caller sized the legacy layout
   // 128 x 256 tiles (a whole tap of a 256-channel map per workgroup: 48 KB staged per 32 MFMAs instead of 32 KB per 16) when the
   // operand has the columns for it AND a chip-filling split still leaves every workgroup >= 8 k-tiles -- 192x192: 316 vs 391 us with
   // the slab count that fills the chip in either form (countr_gemm_tiles() is what a caller divides 256 by),
@@ -334,9 +515,17 @@ int cwg_form(const countr_gemm_args* a, bool lin) {
   const int wide = lin ? a->N : a->Cin;
   const long t256 = (long)(a->M / 128) * (a->N / 256);
   int form = ((wide % 256) == 0 && t256 > 0 && (long)(a->K / 64) * t256 >= 8 * 256) ? 2 : 1;
+  // three taps of a kernel row per workgroup (conv only) where the map's rows are whole k-tiles and the k-range is long enough that
+  // 12 Cout Cin / 128^2 tiles x a chip-filling split leave >= 16 k-tiles each: the 192 x 192 layer
+  bool can3 = !lin && (a->W % 64) == 0;
+  { const char* e = getenv("COUNTR_LEAN_WGRAD3"); if (e && atoi(e) == 0) can3 = false; }      // (A/B switch: the round-4 selection)
+  if (can3 && (long)(a->K / 64) * (a->M / 128) * 3 * (a->Cin / 128) >= 16 * 256) form = 3;
   { const char* e = getenv("COUNTR_LEAN_WGRAD_FORM"); if (e) form = atoi(e); }
+  if (form == 3 && !can3) form = 2;
   if (form == 2 && (wide % 256)) form = 1;
-  return form == 2 ? 2 : 1;
+  if (form < 1 || form > 3) form = 1;
+  if (a->rowsum_partial && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1) * cwg_contributors(a, form)) return 0;   // caller sized another layout
+  return form;
 }
 
 }  // namespace
@@ -344,12 +533,12 @@ int cwg_form(const countr_gemm_args* a, bool lin) {
 // Slabs of rowsum_partial a (COL, IM2COL) / (COL, COL) bf16 split-K launch writes ([slabs][M]): splitk on the generic kernel, splitk x NC here.
 int countr_lean_wgrad_rowsum_slabs(const countr_gemm_args* a, int lin) {
   countr_gemm_args b = *a;
-  b.rowsum_slabs = (a->splitk > 1 ? a->splitk : 1) * (a->N / 128);
+  b.rowsum_partial = nullptr;       // (the layout check is what this call answers)
   if (!b.partial) b.partial = reinterpret_cast<float*>(16);   // (a sizing call may come before the workspace exists)
   const int form = cwg_form(&b, lin != 0);
   const int sk = a->splitk > 1 ? a->splitk : 1;
   if (!form) return sk;
-  return sk * (a->N / 128);     // NC = tilesN * SUBN / 2 = (N / (128 WNB)) * WNB
+  return sk * cwg_contributors(a, form);     // forms 1, 2: NC = tilesN * SUBN / 2 = (N / (128 WNB)) * WNB; form 3: tilesN
 }
 
 // Output tiles (workgroups per split-K slab) of such a launch: what the caller divides the CU count by to pick splitk.
@@ -359,6 +548,7 @@ int countr_lean_wgrad_tiles(const countr_gemm_args* a, int lin) {
   if (!b.partial) b.partial = reinterpret_cast<float*>(16);
   const int form = cwg_form(&b, lin != 0);
   if (!form) return ((a->M + 127) / 128) * ((a->N + 127) / 128);
+  if (form == 3) return (a->M / 128) * 3 * (a->Cin / 128);
   return (a->M / 128) * (a->N / (128 * form));
 }
 
@@ -366,7 +556,7 @@ static void cwg_fill(CwgArgs& g, const countr_gemm_args* a, bool lin, int form) 
   g.dy = (const char*)a->A; g.x = (const char*)a->B; g.part = a->partial; g.rowsum = a->rowsum_partial;
   g.Cout = a->M; g.Cin = lin ? 0 : a->Cin; g.H = lin ? 0 : a->H; g.Wd = lin ? 0 : a->W; g.N = a->N;
   g.lda = lin ? (int)a->lda : a->M; g.ldb = lin ? (int)a->ldb : a->Cin;
-  g.tilesN = a->N / (128 * form); g.tiles = (a->M / 128) * g.tilesN;
+  g.tilesN = form == 3 ? 3 * (a->Cin / 128) : a->N / (128 * form); g.tiles = (a->M / 128) * g.tilesN;
   g.nkt = a->K / 64; g.Z = a->splitk > 1 ? a->splitk : 1;
   g.per = (g.nkt + g.Z - 1) / g.Z;
 }
@@ -414,5 +604,6 @@ int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s) {
   CwgArgs g;
   cwg_fill(g, a, lin != 0, form);
   if (lin) return form == 2 ? launch_cwg<2, true>(g, s) : launch_cwg<1, true>(g, s);
+  if (form == 3) return launch_cwg3(g, s);
   return form == 2 ? launch_cwg<2, false>(g, s) : launch_cwg<1, false>(g, s);
 }

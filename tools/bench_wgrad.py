@@ -1,4 +1,4 @@
-"""Conv weight-gradient GEMM (COL, IM2COL) timing: lean kernel (conv_wgrad.hip) forms 1 / 2 against gemm_kernel, on the density-head shapes
+"""Conv weight-gradient GEMM (COL, IM2COL) timing: lean kernel (conv_wgrad.hip) forms 1 / 2 / 3 against gemm_kernel, on the density-head shapes
 of the B = 8 finetune step.  python tools/bench_wgrad.py"""
 import ctypes as C
 import os
@@ -19,7 +19,10 @@ for (B, H, W, Cin, Cout) in shapes:
     x = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
     P, N = B * H * W, 9 * Cin
     for name, env, bias in [("generic", dict(COUNTR_LEAN_WGRAD="0"), True), ("lean", dict(COUNTR_LEAN_WGRAD="1"), True),
+                            ("lean-form2", dict(COUNTR_LEAN_WGRAD="1", COUNTR_LEAN_WGRAD_FORM="2"), True),
+                            ("lean-form3", dict(COUNTR_LEAN_WGRAD="1", COUNTR_LEAN_WGRAD_FORM="3"), True),
                             ("lean-nobias", dict(COUNTR_LEAN_WGRAD="1"), False)]:
+        os.environ.pop("COUNTR_LEAN_WGRAD_FORM", None)
         os.environ.update(env)
         a = _lib.GemmArgs()
         a.A, a.B = dy.data_ptr(), x.data_ptr()
