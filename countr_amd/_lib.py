@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 LIB_PATH_F16 = os.environ.get("COUNTR_LIB_F16", os.path.join(_HERE, "libcountr_hip_f16.so"))
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
@@ -124,6 +124,7 @@ _SIGS = {
     "countr_patch_mse_workspace_floats": [_i, _i, _i, _i],
     "countr_patch_mse": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "countr_conv_shadows": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "countr_transpose16": [_i, _vp, _vp, _vp, _vp, _vp],
     "countr_masked_mse_workspace_floats": [_i],
     "countr_masked_mse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "countr_masked_mse_amp": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp],

@@ -842,6 +842,66 @@ extern "C" int countr_conv_shadows(int n, const float* const* src, void* const* 
   COUNTR_LAUNCH_CHECK("countr_conv_shadows");
 }
 
+// Transposes of up to 96 16-bit matrices in ONE launch (blockIdx.y = matrix): dst[c][r] = src[r][c].  The refresh of the W^T shadows
+// behind AdamW, which has just written the 16-bit shadow W itself: reading THAT instead of the fp32 master halves the bytes read, and the
+// tiles move as 16-byte chunks both ways (64 x 64 elements through LDS: 128-byte runs in, 128-byte runs out).  The bits are those of
+// countr_conv_shadows' taps = 1 form (a cast of the same fp32 value, transposed).
+constexpr int TR_MAX = 96, TR_PITCH = 72;      // LDS row pitch in elements: 144 bytes, 16-byte aligned rows, odd multiple of 16 bytes
+struct TransposeTable {
+  const uint16_t* src[TR_MAX];
+  uint16_t* dst[TR_MAX];
+  int rows[TR_MAX], cols[TR_MAX];
+};
+__global__ __launch_bounds__(256) void transpose16_kernel(const TransposeTable t) {
+  __shared__ __attribute__((aligned(16))) uint16_t tt[64 * TR_PITCH];
+  const int e = blockIdx.y;
+  const int R = t.rows[e], Cn = t.cols[e];
+  const uint16_t* __restrict__ src = t.src[e];
+  uint16_t* __restrict__ dst = t.dst[e];
+  const int tc = Cn >> 6, nt = (R >> 6) * tc;
+  for (int tl = blockIdx.x; tl < nt; tl += gridDim.x) {
+    const int r0 = (tl / tc) * 64, c0 = (tl - (tl / tc) * tc) * 64;
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int idx = threadIdx.x + 256 * ps, r = idx >> 3, c8 = idx & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * Cn + c0 + c8 * 8);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tt[(c8 * 8 + 2 * j) * TR_PITCH + r] = (uint16_t)(w[j] & 0xffffu);
+        tt[(c8 * 8 + 2 * j + 1) * TR_PITCH + r] = (uint16_t)(w[j] >> 16);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int idx = threadIdx.x + 256 * ps, c = idx >> 3, r8 = idx & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(tt + c * TR_PITCH + r8 * 8);
+      *reinterpret_cast<uint4*>(dst + (int64_t)(c0 + c) * R + r0 + r8 * 8) = v;
+    }
+  }
+}
+
+extern "C" int countr_transpose16(int n, const void* const* src, void* const* dst, const int* rows, const int* cols, void* stream) {
+  if (n < 1 || n > TR_MAX || !src || !dst || !rows || !cols) { countr_set_error("countr_transpose16: 1..96 matrices"); return -1; }
+  TransposeTable t;
+  int64_t big = 0;
+  for (int i = 0; i < TR_MAX; ++i) {
+    const int k = i < n ? i : 0;
+    if (!src[k] || !dst[k] || rows[k] < 64 || cols[k] < 64 || (rows[k] % 64) || (cols[k] % 64) ||
+        (((uintptr_t)src[k] | (uintptr_t)dst[k]) & 15)) {
+      countr_set_error("countr_transpose16: rows and cols multiples of 64, 16-byte aligned matrices"); return -1;
+    }
+    t.src[i] = (const uint16_t*)src[k]; t.dst[i] = (uint16_t*)dst[k]; t.rows[i] = rows[k]; t.cols[i] = cols[k];
+    const int64_t m = (int64_t)rows[k] * cols[k];
+    if (m > big) big = m;
+  }
+  const int gx = (int)((big / 4096 + 3) / 4);       // up to four tiles of the largest matrix per block
+  hipLaunchKernelGGL(transpose16_kernel, dim3(gx < 1 ? 1 : gx, n), dim3(256), 0, STREAM(stream), t);
+  COUNTR_LAUNCH_CHECK("countr_transpose16");
+}
+
 extern "C" int countr_masked_mse_workspace_floats(int B) { return B * MSE_BLOCKS * 3; }
 extern "C" int countr_masked_mse_amp(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
                                      float* workspace, int B, int HW, float grad_scale, const float* amp, void* stream);

@@ -303,7 +303,7 @@ class Engine:
                                              BF16, st), "cast")
             if (self.prescale_q or self.ln_fold) and not trainable_only and stream is None:
                 self._pack_prescaled_q()
-        self._refresh_conv_shadows()
+        self._refresh_conv_shadows(st)      # (the W^T shadows are taken from the 16-bit shadow the cast above wrote on this stream)
 
     def _pack_prescaled_q(self):
         """Frozen encoder, bf16 mode, weight-packing time only (load_state_dict / .to()): a few torch ops on the engine's stream.
@@ -1345,12 +1345,23 @@ class Engine:
         self.adamw_launch(S, weight_decay, betas, eps, lr=lr, step=self.step_count, grad_scale=grad_scale)
 
     def _refresh_conv_shadows(self, stream=None):
-        """OHWI + dgrad-form shadows of every conv weight, one launch (the table of pointers is built once)."""
+        """OHWI + dgrad-form shadows of every conv weight in one launch (fp32 master -> both permuted forms), and the W^T shadows of the
+        Linear weights in another (16-bit modes: a transpose of the 16-bit shadow W that AdamW / sync_weights has just written -- the same
+        bits as a cast of the master, half the bytes read).  The tables of pointers are built once."""
         if not self.conv_names and not self.WtT:
             return
         if getattr(self, "_shadow_tab", None) is None:
-            lin = list(self.WtT)                      # Linear weights [N][K]: taps = 1, only the transposed form
-            names = self.conv_names + lin
+            lin = list(self.WtT)                      # Linear weights [N][K]: only the transposed form
+            from16 = self.half and os.environ.get("COUNTR_TRANSPOSE16", "1") != "0" and all(self.layout.shapes[c][0] % 64 == 0 and self.layout.shapes[c][1] % 64 == 0 for c in lin)
+            self._lin_tab = None
+            if lin and from16:
+                m = len(lin)
+                shp = [self.layout.shapes[c] for c in lin]
+                self._lin_tab = (m, (C.c_void_p * m)(*[self.Wt.data_ptr() + 2 * self.layout.off[c] for c in lin]),
+                                 (C.c_void_p * m)(*[self.WtT[c].data_ptr() for c in lin]),
+                                 (C.c_int * m)(*[s_[0] for s_ in shp]), (C.c_int * m)(*[s_[1] for s_ in shp]))
+                lin = []
+            names = self.conv_names + lin             # (fp32 mode keeps no W^T shadows; a 16-bit shape outside the tiles goes the fp32 way)
             n = len(names)
             shp = [self.layout.shapes[c] for c in names]
             self._shadow_tab = (n, (C.c_void_p * n)(*[self._pp(c) for c in names]),
@@ -1358,10 +1369,17 @@ class Engine:
                                 (C.c_void_p * n)(*([self.Wd[c].data_ptr() for c in self.conv_names] + [self.WtT[c].data_ptr() for c in lin])),
                                 (C.c_int * n)(*[s_[0] for s_ in shp]), (C.c_int * n)(*[s_[1] for s_ in shp]),
                                 (C.c_int * n)(*[(s_[2] * s_[3] if len(s_) == 4 else 1) for s_ in shp]))
+        st = stream if stream is not None else self._stream()
         n, src, wf, wd, co, ci, taps = self._shadow_tab
         vp, ip = C.c_void_p, C.c_int
         for i0 in range(0, n, 32):           # the launch takes 32 entries
             m = min(32, n - i0)
             off = lambda arr, ty: C.cast(C.byref(arr, i0 * C.sizeof(ty)), C.POINTER(ty))
             _lib.check(self.L.countr_conv_shadows(m, off(src, vp), off(wf, vp), off(wd, vp), off(co, ip), off(ci, ip), off(taps, ip),
-                                                  self.code, stream if stream is not None else self._stream()), "conv_shadows")
+                                                  self.code, st), "conv_shadows")
+        if self._lin_tab is not None:
+            m, s16, d16, rows, cols = self._lin_tab
+            for i0 in range(0, m, 96):       # the launch takes 96 matrices
+                k = min(96, m - i0)
+                off = lambda arr, ty: C.cast(C.byref(arr, i0 * C.sizeof(ty)), C.POINTER(ty))
+                _lib.check(self.L.countr_transpose16(k, off(s16, vp), off(d16, vp), off(rows, ip), off(cols, ip), st), "transpose16")

@@ -42,7 +42,7 @@ extern "C" {
 
 /* -------- library management -------- */
 int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
-int countr_version(void);               /* ABI version, currently 7 (7: countr_masked_mse_amp / countr_patch_mse_amp / countr_adamw_step_amp added, no layout change; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
+int countr_version(void);               /* ABI version, currently 8 (8: countr_transpose16 added, no layout change; 7: countr_masked_mse_amp / countr_patch_mse_amp / countr_adamw_step_amp added, no layout change; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -282,6 +282,10 @@ int countr_cast_permute(const float* src, void* dst, int64_t n, int mode, int Co
  * B operand that turns the input gradient dx = dy W (autograd of models_crossvit.py:62-65, 84-92, 115-127) into a (ROW, ROW) GEMM. */
 int countr_conv_shadows(int n, const float* const* src, void* const* wf, void* const* wd, const int* co, const int* ci,
                         const int* taps, int dtype, void* stream);
+/* ABI 8: dst[i][c][r] = src[i][r][c] for up to 96 matrices of 16-bit elements (rows, cols multiples of 64; 16-byte aligned) in ONE launch:
+ * the W^T shadows (see countr_conv_shadows, taps = 1) taken from the 16-bit shadow W that countr_adamw_step has just written instead of
+ * from the fp32 master -- same bits, half the bytes read.  Host arrays of n device pointers / shapes. */
+int countr_transpose16(int n, const void* const* src, void* const* dst, const int* rows, const int* cols, void* stream);
 int countr_masked_mse_workspace_floats(int B);
 int countr_masked_mse(const float* pred, const float* gt, const float* mask, float* dpred, float* sums,
                       float* workspace, int B, int HW, float grad_scale, void* stream);

@@ -539,6 +539,43 @@ def test_conv_shadows_transposes_linear_weights(hip):
     assert torch.equal(cd, cw.reshape(64, 32, 9).flip(2).permute(1, 2, 0).to(torch.bfloat16))
 
 
+def test_transpose16_many_matrices_one_launch(hip):
+    """countr_transpose16 (ABI 8): the W^T shadows from the 16-bit shadow W -- 82 matrices of the MAE model's shapes (and 96, the table's
+    size) in one launch, bit-identical to torch's transpose of the same 16-bit values and to what countr_conv_shadows (taps = 1) makes
+    of the fp32 master; shapes that are not multiples of 64 and more than 96 matrices are refused."""
+    import ctypes as C
+    shapes = ([(2304, 768), (768, 768), (3072, 768), (768, 3072)] * 12 + [(1536, 512), (512, 512), (2048, 512), (512, 2048)] * 8 + [(512, 768), (768, 512)])[:82]
+    shapes += [(64, 64), (128, 192)] * 7
+    assert len(shapes) == 96
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (82, 96, 1):
+        sh = shapes[:n]
+        ws = [torch.randn(r, c, device="cuda") for r, c in sh]
+        w16 = [w.to(torch.bfloat16) for w in ws]
+        wt = [torch.full((c, r), float("nan"), device="cuda", dtype=torch.bfloat16) for r, c in sh]
+        vp, ip = C.c_void_p * n, C.c_int * n
+        _lib.check(hip.countr_transpose16(n, vp(*[w.data_ptr() for w in w16]), vp(*[w.data_ptr() for w in wt]), ip(*[s_[0] for s_ in sh]),
+                                          ip(*[s_[1] for s_ in sh]), st), "transpose16")
+        torch.cuda.synchronize()
+        for w, t in zip(w16, wt):
+            assert torch.equal(t, w.t().contiguous())
+        if n == 82:      # against the fp32 route, 32 at a time
+            m = 32
+            old = [torch.full((c, r), float("nan"), device="cuda", dtype=torch.bfloat16) for r, c in sh[:m]]
+            vpm, ipm = C.c_void_p * m, C.c_int * m
+            _lib.check(hip.countr_conv_shadows(m, vpm(*[w.data_ptr() for w in ws[:m]]), vpm(*([None] * m)), vpm(*[w.data_ptr() for w in old]),
+                                               ipm(*[s_[0] for s_ in sh[:m]]), ipm(*[s_[1] for s_ in sh[:m]]), ipm(*([1] * m)), 1, st), "conv_shadows")
+            torch.cuda.synchronize()
+            for a, b in zip(old, wt[:m]):
+                assert torch.equal(a, b)
+    a = torch.zeros(40, 64, device="cuda", dtype=torch.bfloat16)
+    b = torch.zeros(64, 40, device="cuda", dtype=torch.bfloat16)
+    one_p, one_i = C.c_void_p * 1, C.c_int * 1
+    assert hip.countr_transpose16(1, one_p(a.data_ptr()), one_p(b.data_ptr()), one_i(40), one_i(64), st) != 0
+    assert b"multiples of 64" in hip.countr_last_error()
+    assert hip.countr_transpose16(97, None, None, None, None, st) != 0
+
+
 def test_copy_multi(hip):
     """countr_copy_multi: several dense device-to-device copies in one launch (the staging of a batch), sizes from 16 bytes to 14 MB,
     nothing outside the destinations touched."""
