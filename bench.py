@@ -480,6 +480,39 @@ def other_workloads(args, dev, steps=10, warmup=3):
     return out
 
 
+class _Watchdog:
+    """Multi-GPU runs replay RCCL all-reduces as nodes of the step's hipGraph -- a path no multi-GPU box has run here yet.  An exception
+    there is handled by the trainer (every rank falls back to host-issued collectives); a HANG cannot be.  So the communicating bench
+    first measures the step in the host-issued mode (plain RCCL calls between per-phase graphs), keeps that line, and runs everything
+    behind it under this watchdog: no progress for `idle` seconds -> rank 0 prints the kept line (marked as the fallback), every rank
+    leaves with os._exit(0).  kick() at every milestone; cancel() when the real line is about to be printed."""
+
+    def __init__(self, idle, rank, line_fn):
+        import threading
+        self.idle, self.rank, self.line_fn = idle, rank, line_fn
+        self.last, self.what = time.monotonic(), "start"
+        self.done = threading.Event()
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def kick(self, what):
+        self.last, self.what = time.monotonic(), what
+
+    def cancel(self):
+        self.done.set()
+
+    def _run(self):
+        while not self.done.wait(1.0):
+            if time.monotonic() - self.last > self.idle:
+                if self.rank == 0:
+                    sys.stdout.write(json.dumps(self.line_fn(self.what)) + "\n")
+                    sys.stdout.flush()
+                sys.stderr.write("bench.py: rank %d made no progress for %d s in '%s' (captured RCCL collectives); leaving with the "
+                                 "host-issued measurement\n" % (self.rank, self.idle, self.what))
+                sys.stderr.flush()
+                os._exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -585,15 +618,50 @@ def main():
             dt = t.item()
         return dt, sums
 
+    wd = None
+    if step.sync.comm and getattr(step.sync, "capturable", False) and not args.no_graph:
+        step.sync.capturable = False
+        with step.on_stream():
+            for k in range(max(args.warmup, 2)):
+                one(k, 3)
+        dt_safe, sums_safe = timed([3] * args.steps)
+        loss_safe = sums_safe[0].item()
+        step.sync.capturable = True
+
+        def safe_line(where, dt_safe=dt_safe, loss_safe=loss_safe):
+            return {"metric": "images/sec (384x384, 3 exemplars) FSC147 finetune step", "value": world * B * args.steps / dt_safe,
+                    "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_safe / args.steps,
+                    "timed_blocks": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                    "data": "synthetic",
+                    "config": {"workload": "FSC147 finetune ViT-B/16 (mae_vit_base_patch16), batch=%d per GPU, 384x384, shot_num=3, "
+                                           "frozen encoder fwd + decoder fwd/bwd + masked-MSE + AdamW" % B,
+                               "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": True,
+                               "optimizer_update": "at the tail of its step"},
+                    "final_loss": loss_safe, "parity_checked": False, "inputs": "resident in HBM",
+                    "step_tflops": GF_STEP_PER_IMG * world * B * args.steps / dt_safe / 1e12,
+                    "multi_gpu": {"collectives": "issued by the host between per-phase graph replays",
+                                  "fallback": "the captured-collective form (RCCL all-reduces as nodes of the step's hipGraph) made no "
+                                              "progress for %d s in '%s'; this line is the host-issued measurement taken before it" % (wd.idle, where)}}
+        wd = _Watchdog(int(os.environ.get("COUNTR_BENCH_WATCHDOG_S", "240")), rank, safe_line)
+    kick = (lambda what: wd.kick(what)) if wd is not None else (lambda what: None)
+    kick("warm-up: capture of the communicating step")
     with step.on_stream():
         for k in range(max(args.warmup, 2)):   # the first two steps build the plan and capture the graphs
             one(k, 3)
+    torch.cuda.synchronize()
+    if os.environ.get("COUNTR_BENCH_FAKE_HANG") == "1" and wd is not None:      # (tests/test_ddp_gpu.py: the watchdog's exit path)
+        time.sleep(3600)
+    kick("parity check")
     # (after the warm-up: the checked step REPLAYS the captured graph the timed blocks replay)
     parity = None if (args.plain or args.no_parity) else parity_check(model, step, world, rank, B, NB, dev)
     step.sync.profile = world > 1 or step.sync.comm
     # box-to-box and run-to-run spread (5.3-5.55 ms over the boxes of round 2) is larger than most single optimisations: the block of
     # --steps steps is timed --reps times (each bracketed by barrier + synchronize, max over ranks) and the MEDIAN block is the value
-    blocks = [timed([3] * args.steps) for _ in range(max(args.reps, 1))]
+    kick("timed blocks")
+    blocks = []
+    for _ in range(max(args.reps, 1)):
+        blocks.append(timed([3] * args.steps))
+        kick("timed blocks")
     host_ms = 1e3 * host_dt[0] / args.steps
     dts = sorted(b[0] for b in blocks)
     dt, sums = dts[len(dts) // 2], blocks[-1][1]
@@ -605,6 +673,7 @@ def main():
             # the headline blocks replayed ONE graph per step with the RCCL all-reduces as nodes of it: nothing to bracket.  The exposed
             # communication is measured on a short extra run in the per-phase-graph mode (host-issued collectives between the phases),
             # whose step time is reported beside it
+            kick("host-issued mode: exposed communication")
             step.sync.capturable = False
             with step.on_stream():
                 for k in range(3):
@@ -622,11 +691,14 @@ def main():
             print(json.dumps({"metric": "images/sec (384x384, 3 exemplars) FSC147 finetune step", "value": world * B * args.steps / dt, "unit": "images/sec",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "plain": True, "host_enqueue_ms_per_step": host_ms,
                               "hipgraph": not args.no_graph, "dtype": args.precision, "data": "synthetic"}))
+        if wd is not None:
+            wd.cancel()
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
     from countr_amd.parallel import shared_shot_num
+    kick("shot mix: capture of the other shot counts")
     mix = [shared_shot_num(i, seed=0) for i in range(args.steps)]
     with step.on_stream():
         for S in sorted(set(mix) | {0, 1, 2}):
@@ -640,6 +712,9 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, me)
         ranks_seen = gathered
+    if rank != 0 and wd is not None:
+        wd.cancel()          # (this rank's GPU work is over: what is left is rank 0's own roofline passes, then the closing barrier)
+    kick("roofline passes (rank 0)")
     if rank == 0:
         ips = world * B * args.steps / dt
         line = {
@@ -692,7 +767,14 @@ def main():
             line["other_workloads"] = other_workloads(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if wd is not None:
+            wd.cancel()
+            line["multi_gpu_safe_mode"] = {"ms_per_step_host_issued_first": 1e3 * dt_safe / args.steps,
+                                           "note": "measured before the captured-collective form was tried (bench.py::_Watchdog)"}
         print(json.dumps(line))
+        sys.stdout.flush()
+    if wd is not None:
+        wd.cancel()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -235,3 +235,18 @@ def test_bench_rccl_one_rank():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["parity_checked"] is True
     assert j["config"]["optimizer_update"].startswith("deferred")        # captured collectives + the deferred optimizer: one graph per step
+    assert j["multi_gpu_safe_mode"]["ms_per_step_host_issued_first"] > 0  # the host-issued form was measured first (the watchdog's line)
+
+
+def test_bench_watchdog_prints_the_host_issued_line_when_captured_collectives_hang():
+    """A hang in the captured-collective form cannot be caught as an exception: bench.py keeps the line it measured in the host-issued form
+    first and a watchdog prints it when nothing moves for COUNTR_BENCH_WATCHDOG_S seconds (COUNTR_BENCH_FAKE_HANG=1 puts the main thread
+    to sleep behind the capture); every rank leaves with exit code 0, so the driver's scaling run still gets a valid line."""
+    import json
+    cmd = lambda: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                   "--master-port", str(free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    r = run_retry(cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1",
+                            COUNTR_BENCH_FAKE_HANG="1", COUNTR_BENCH_WATCHDOG_S="5"))
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["steps"] == 3 and j["parity_checked"] is False
+    assert "made no progress for 5 s" in j["multi_gpu"]["fallback"] and "issued by the host" in j["multi_gpu"]["collectives"]
