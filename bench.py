@@ -15,6 +15,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (the pool's driver supports dmabuf IPC only: RCCL across processes needs this)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
