@@ -279,7 +279,10 @@ __device__ __forceinline__ void cwg_body(const CwgArgs& g, const int v) {
 // fragment sets fill, so the row sums of dy are taken by the LOADER waves (idle between their issue and the next barrier): the
 // k-tiles of a (slab, tile_m) are dealt round-robin to its tilesN workgroups, whose loader wave w multiplies rows [32 w, +32) of the
 // staged dy tile by a ones fragment (4 MFMAs in 1 of tilesN k-tiles), each workgroup writing its own slab.
-constexpr int C3_A = 64 * 256, C3_B = 80 * 256, C3_STAGE = C3_A + C3_B, C3_STAGES = 3;
+// KS = k-steps (16 pixels) per k-tile: 4 (W % 64 == 0) or 6 (W % 96 == 0: the 96 x 96 layer, one image row per k-tile)
+constexpr int C3_STAGES = 3;
+constexpr int c3_stage_bytes(int ks) { return ks * 16 * 256 + (ks * 16 + 16) * 256; }
+template <int PENDING> __device__ __forceinline__ void frag_wait1(Frag& f) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(PENDING)); }
 
 struct Frag5 { Frag f[5]; };   // a0, a1 (two 32-row tiles of dy), b(-1), b(0), b(+1)
 template <int PENDING> __device__ __forceinline__ void frag_wait5(Frag5& s) {
@@ -289,7 +292,9 @@ template <int PENDING> __device__ __forceinline__ void frag_wait5(Frag5& s) {
                : "n"(PENDING));
 }
 
+template <int KS>
 __device__ __forceinline__ void cwg3_body(const CwgArgs& g, const int v) {
+  constexpr int KT = KS * 16, C3_A = KT * 256, C3_STAGE = c3_stage_bytes(KS);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,31 +313,31 @@ __device__ __forceinline__ void cwg3_body(const CwgArgs& g, const int v) {
     const uint32_t voffA = (uint32_t)(((cw * 4 + krow) * g.lda + c8 * 8) * 2);
     const uint32_t voffB = (uint32_t)(((cw * 4 + krow) * g.ldb + c8 * 8) * 2);
     const int64_t cshift = (int64_t)(g.Wd + 8) * g.ldb * 2;          // descriptor base in front of the map: every shift (dy W - 4 pixels) >= 0
-    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.dy + ((int64_t)kt0 * 64 * g.lda + m0) * 2), 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.x + ((int64_t)kt0 * 64 * g.ldb + ci0) * 2 - cshift), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.dy + ((int64_t)kt0 * KT * g.lda + m0) * 2), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.x + ((int64_t)kt0 * KT * g.ldb + ci0) * 2 - cshift), 0, 0x7ffffff0, 0x00020000);
     const uint32_t tapoff = (uint32_t)(cshift + (int64_t)(dyt * g.Wd - 4) * g.ldb * 2);
-    const uint32_t passA = (uint32_t)g.lda * 32u, passB = (uint32_t)g.ldb * 32u, tileA = (uint32_t)g.lda * 128u, tileB = (uint32_t)g.ldb * 128u;
-    int x0 = (int)(((int64_t)kt0 * 64) % g.Wd), y = (int)((((int64_t)kt0 * 64) / g.Wd) % g.H);      // of the NEXT tile to be issued
+    const uint32_t passA = (uint32_t)g.lda * 32u, passB = (uint32_t)g.ldb * 32u, tileA = (uint32_t)g.lda * (2u * KT), tileB = (uint32_t)g.ldb * (2u * KT);
+    int x0 = (int)(((int64_t)kt0 * KT) % g.Wd), y = (int)((((int64_t)kt0 * KT) / g.Wd) % g.H);      // of the NEXT tile to be issued
     auto issue = [&](int t, int slot_) {      // called with t = 0, 1, 2, ... in order
       char* dst = smem + slot_ * C3_STAGE + cw * 1024;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < KS; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_vptr_t)(dst + i * 4096), 16, voffA, t * tileA + i * passA, 0, 0);
       const bool rowok = (unsigned)(y + dyt) < (unsigned)g.H;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < KS + 1; ++i) {
         const int r = 16 * i + 4 * cw + krow, xx = x0 - 4 + r;
-        const bool ok = rowok && r < 72 && (unsigned)xx < (unsigned)g.Wd;
+        const bool ok = rowok && r < KT + 8 && (unsigned)xx < (unsigned)g.Wd;
         const uint32_t vo = ok ? voffB : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_vptr_t)(dst + C3_A + i * 4096), 16, vo, tapoff + t * tileB + i * passB, 0, 0);
       }
-      x0 += 64;
+      x0 += KT;
       if (x0 >= g.Wd) { x0 = 0; y = (y + 1 == g.H) ? 0 : y + 1; }
     };
 #pragma unroll
     for (int s_ = 0; s_ < C3_STAGES - 1; ++s_)
       if (s_ < ntiles) issue(s_, s_);
-    constexpr int PER = 9;
+    constexpr int PER = 2 * KS + 1;
     const int l15 = lane & 15, q16 = (lane >> 4) & 1, lh = lane >> 5, rr = l15 >> 2, bb = l15 & 3;
     const uint32_t offR = (uint32_t)((lh * 8 + rr) * 256 + (((cw * 4 + q16 * 2 + (bb >> 1)) ^ (rr << 2)) << 4) + (bb & 1) * 8);
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR, COUNTR_H16_ONE_PAIR));
@@ -349,15 +354,17 @@ __device__ __forceinline__ void cwg3_body(const CwgArgs& g, const int v) {
       islot = (islot + 1 == C3_STAGES) ? 0 : islot + 1;
       if (want_rs && tmod == tile_n) {       // (stage `slot` is complete behind the barrier and is overwritten only behind the next one)
         const uint32_t sb = lds_u32(smem) + slot * C3_STAGE + offR;
-        Frag f0, f1, f2, f3;
-        f0.lo = ds_tr<0>(sb); f0.hi = ds_tr<1024>(sb);
-        f1.lo = ds_tr<4096>(sb); f1.hi = ds_tr<4096 + 1024>(sb);
-        f2.lo = ds_tr<8192>(sb); f2.hi = ds_tr<8192 + 1024>(sb);
-        f3.lo = ds_tr<12288>(sb); f3.hi = ds_tr<12288 + 1024>(sb);
-        Frag fr4[4] = {f0, f1, f2, f3};
-        frag_wait<0>(fr4);
+        Frag fb[KS];
+        fb[0].lo = ds_tr<0>(sb); fb[0].hi = ds_tr<1024>(sb);
+        fb[1].lo = ds_tr<4096>(sb); fb[1].hi = ds_tr<4096 + 1024>(sb);
+        fb[2].lo = ds_tr<8192>(sb); fb[2].hi = ds_tr<8192 + 1024>(sb);
+        fb[3].lo = ds_tr<12288>(sb); fb[3].hi = ds_tr<12288 + 1024>(sb);
+        if constexpr (KS == 6) {
+          fb[4].lo = ds_tr<16384>(sb); fb[4].hi = ds_tr<16384 + 1024>(sb);
+          fb[5].lo = ds_tr<20480>(sb); fb[5].hi = ds_tr<20480 + 1024>(sb);
+        }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) accb = COUNTR_MFMA_32X32X16(frag_bits(fr4[kk]), ones, accb, 0, 0, 0);
+        for (int kk = 0; kk < KS; ++kk) { frag_wait1<0>(fb[kk]); accb = COUNTR_MFMA_32X32X16(frag_bits(fb[kk]), ones, accb, 0, 0, 0); }
       }
       tmod = (tmod + 1 == g.tilesN) ? 0 : tmod + 1;
       slot = (slot + 1 == C3_STAGES) ? 0 : slot + 1;
@@ -411,6 +418,10 @@ __device__ __forceinline__ void cwg3_body(const CwgArgs& g, const int v) {
     C3_RD(1, 1); frag_wait5<10>(fs[0]); C3_MM(0);
     C3_RD(0, 2); frag_wait5<10>(fs[1]); C3_MM(1);
     C3_RD(1, 3); frag_wait5<10>(fs[0]); C3_MM(0);
+    if constexpr (KS == 6) {
+      C3_RD(0, 4); frag_wait5<10>(fs[1]); C3_MM(1);
+      C3_RD(1, 5); frag_wait5<10>(fs[0]); C3_MM(0);
+    }
     frag_wait5<0>(fs[1]); C3_MM(1);
     slot = (slot + 1 == C3_STAGES) ? 0 : slot + 1;
     __builtin_amdgcn_s_barrier();
@@ -429,16 +440,18 @@ __device__ __forceinline__ void cwg3_body(const CwgArgs& g, const int v) {
   }
 }
 
-__global__ __launch_bounds__(768) void cwg3_kernel(const CwgArgs g) { cwg3_body(g, cwg_virtual_index()); }
+template <int KS>
+__global__ __launch_bounds__(768) void cwg3_kernel(const CwgArgs g) { cwg3_body<KS>(g, cwg_virtual_index()); }
 
+template <int KS>
 int launch_cwg3(const CwgArgs& a, hipStream_t s) {
-  constexpr int lds = C3_STAGES * C3_STAGE;
+  constexpr int lds = C3_STAGES * c3_stage_bytes(KS);     // 108 KB (KS = 4), 156 KB (KS = 6)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwg3_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(cwg3_kernel, dim3(a.tiles * a.Z), dim3(768), lds, s, a);
+  hipLaunchKernelGGL((cwg3_kernel<KS>), dim3(a.tiles * a.Z), dim3(768), lds, s, a);
   COUNTR_LAUNCH_CHECK("countr_gemm(conv wgrad, three taps per workgroup)");
 }
 
@@ -489,6 +502,9 @@ int launch_cwg(const CwgArgs& a, hipStream_t s) {
   COUNTR_LAUNCH_CHECK("countr_gemm(lean conv wgrad)");
 }
 
+// k-tile of form 3 in pixels: a divisor of the map's width (64 where it divides, else 96)
+static int cwg3_ktile(int W) { return (W % 64) == 0 ? 64 : 96; }
+
 // Contributors that share the bias-gradient of one (slab, row block) = rowsum slabs per split-K slab
 static int cwg_contributors(const countr_gemm_args* a, int form) { return form == 3 ? 3 * (a->Cin / 128) : a->N / 128; }
 
@@ -517,7 +533,7 @@ int cwg_form(const countr_gemm_args* a, bool lin) {
   int form = ((wide % 256) == 0 && t256 > 0 && (long)(a->K / 64) * t256 >= 8 * 256) ? 2 : 1;
   // three taps of a kernel row per workgroup (conv only) where the map's rows are whole k-tiles and the k-range is long enough that
   // 12 Cout Cin / 128^2 tiles x a chip-filling split leave >= 16 k-tiles each: the 192 x 192 layer
-  bool can3 = !lin && (a->W % 64) == 0;
+  bool can3 = !lin && ((a->W % 64) == 0 || (a->W % 96) == 0);
   { const char* e = getenv("COUNTR_LEAN_WGRAD3"); if (e && atoi(e) == 0) can3 = false; }      // (A/B switch: the round-4 selection)
   if (can3 && (long)(a->K / 64) * (a->M / 128) * 3 * (a->Cin / 128) >= 16 * 256) form = 3;
   { const char* e = getenv("COUNTR_LEAN_WGRAD_FORM"); if (e) form = atoi(e); }
@@ -557,7 +573,7 @@ static void cwg_fill(CwgArgs& g, const countr_gemm_args* a, bool lin, int form) 
   g.Cout = a->M; g.Cin = lin ? 0 : a->Cin; g.H = lin ? 0 : a->H; g.Wd = lin ? 0 : a->W; g.N = a->N;
   g.lda = lin ? (int)a->lda : a->M; g.ldb = lin ? (int)a->ldb : a->Cin;
   g.tilesN = form == 3 ? 3 * (a->Cin / 128) : a->N / (128 * form); g.tiles = (a->M / 128) * g.tilesN;
-  g.nkt = a->K / 64; g.Z = a->splitk > 1 ? a->splitk : 1;
+  g.nkt = a->K / (form == 3 ? cwg3_ktile(a->W) : 64); g.Z = a->splitk > 1 ? a->splitk : 1;
   g.per = (g.nkt + g.Z - 1) / g.Z;
 }
 
@@ -604,6 +620,6 @@ int countr_lean_wgrad(const countr_gemm_args* a, int lin, hipStream_t s) {
   CwgArgs g;
   cwg_fill(g, a, lin != 0, form);
   if (lin) return form == 2 ? launch_cwg<2, true>(g, s) : launch_cwg<1, true>(g, s);
-  if (form == 3) return launch_cwg3(g, s);
+  if (form == 3) return cwg3_ktile(a->W) == 64 ? launch_cwg3<4>(g, s) : launch_cwg3<6>(g, s);
   return form == 2 ? launch_cwg<2, false>(g, s) : launch_cwg<1, false>(g, s);
 }

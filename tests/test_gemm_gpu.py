@@ -568,7 +568,7 @@ def test_lean_conv3x3_matches_fp64_and_generic(hip, monkeypatch, Bsz, H, W, Cin,
 @pytest.mark.parametrize("Bsz,H,W,Cin,Cout,sk,with_bias", [(2, 96, 96, 256, 256, 7, True), (4, 48, 48, 256, 256, 5, True), (8, 24, 24, 512, 256, 3, True),
                                                           (3, 32, 48, 128, 128, 2, False), (1, 64, 64, 256, 384, 40, True), (2, 8, 16, 128, 128, 1, True),
                                                           (2, 64, 128, 128, 256, 5, True), (3, 5, 64, 256, 128, 4, True), (1, 192, 192, 256, 256, 21, True),
-                                                          (2, 3, 192, 128, 128, 1, False)])
+                                                          (2, 3, 192, 128, 128, 1, False), (1, 4, 96, 128, 128, 3, True), (2, 2, 96, 256, 128, 1, True)])
 def test_lean_conv_wgrad_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H, W, Cin, Cout, sk, with_bias):
     """Weight (+ bias) gradient of the 3x3 convolutions as the (COL, IM2COL) split-K GEMM: the lean kernel of conv_wgrad.hip (both maps
     staged K-major by LDS-DMA, transposing fragment reads, bias-gradient MFMAs dealt over the waves) against torch fp64 autograd on the
@@ -576,7 +576,8 @@ def test_lean_conv_wgrad_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H
     spanning image boundaries, 128x128 and 128x256 tiles, more slabs than k-tiles per slab allow (sk = 40 of 64 k-tiles: empty slabs
     must come out as zeros), a single slab, Cin = 128 / 512.  Form 3 (the three taps of a kernel row per workgroup, one staged row
     segment read at three offsets; the loader waves take the bias gradient) applies where W % 64 == 0 -- one, two and three k-tiles per
-    image row, images of 3 and 5 rows (every k-tile next to a padded row), the 192 x 192 layer itself -- and falls back elsewhere."""
+    image row, images of 3 and 5 rows (every k-tile next to a padded row), the 192 x 192 layer itself -- and, with 96-pixel k-tiles (six
+    k-steps, one image row per k-tile), where W % 96 == 0: the 96 x 96 layer, 2- and 4-row images; it falls back elsewhere."""
     dy = _mk((Bsz, H, W, Cout), torch.bfloat16, 71)
     x = _mk((Bsz, H, W, Cin), torch.bfloat16, 72)
     P, N = Bsz * H * W, 9 * Cin
@@ -599,7 +600,7 @@ def test_lean_conv_wgrad_matches_fp64_and_generic(hip, monkeypatch, form, Bsz, H
         a.alpha = 1.0
         a.nbatch = 1; a.nb1 = 1; a.splitk = sk
         slabs = hip.countr_gemm_rowsum_slabs(C.byref(a), 1, 1, 3)
-        per_slab = 3 * (Cin // 128) if (form == "3" and W % 64 == 0) else N // 128
+        per_slab = 3 * (Cin // 128) if (form == "3" and (W % 64 == 0 or W % 96 == 0)) else N // 128
         assert slabs == (sk * per_slab if lean == "1" else sk)
         part = torch.full((sk, Cout, N), float("nan"), device="cuda", dtype=torch.float32)
         rs = torch.full((slabs, Cout), float("nan"), device="cuda", dtype=torch.float32)
