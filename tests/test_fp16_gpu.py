@@ -99,6 +99,49 @@ def test_flash_attention_fp16_fwd_bwd(hip16, B, N, Hh, dh):
         assert relerr(dqkv[:, :, slot], x.grad[:, :, slot]) < 4e-3, name      # bf16 build: 2.5e-2
 
 
+@pytest.mark.parametrize("form", ["2", "3"])
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout,sk", [(1, 64, 64, 256, 256, 4), (2, 6, 96, 128, 128, 2), (1, 48, 48, 128, 256, 3)])
+def test_conv_wgrad_fp16(hip16, monkeypatch, form, Bsz, H, W, Cin, Cout, sk):
+    """Weight + bias gradient of a 3x3 convolution in the fp16 build: the lean kernels of conv_wgrad.hip (128 x 256 tiles; the three
+    taps of a kernel row per workgroup with 64- and 96-pixel k-tiles, and its fall-back on a 48-wide map) against fp64 autograd on the
+    same fp16 maps -- the partial sums are fp32, so the bar is the accumulation's."""
+    monkeypatch.setenv("COUNTR_LEAN_WGRAD_FORM", form)
+    dy = rnd((Bsz, H, W, Cout), 5).to(H16).cuda()
+    x = rnd((Bsz, H, W, Cin), 6).to(H16).cuda()
+    Pn, N = Bsz * H * W, 9 * Cin
+    wz = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    bz = torch.zeros(Cout, dtype=torch.float64, device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wz, bz, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    ref_w, ref_b = wz.grad.permute(0, 2, 3, 1).reshape(Cout, N), bz.grad
+    a = _lib.GemmArgs()
+    a.A, a.B = dy.data_ptr(), x.data_ptr()
+    a.lda, a.ldc = Cout, N
+    a.M, a.N, a.K, a.H, a.W, a.Cin = Cout, N, Pn, H, W, Cin
+    a.alpha, a.nbatch, a.nb1, a.splitk = 1.0, 1, 1, sk
+    slabs = hip16.countr_gemm_rowsum_slabs(C.byref(a), _lib.BF16, 1, 3)
+    part = torch.full((sk, Cout, N), float("nan"), device="cuda")
+    rs = torch.full((slabs, Cout), float("nan"), device="cuda")
+    a.partial, a.rowsum_partial, a.rowsum_slabs = part.data_ptr(), rs.data_ptr(), slabs
+    _lib.check(hip16.countr_gemm(C.byref(a), _lib.BF16, 1, 3, st()), "wgrad")
+    torch.cuda.synchronize()
+    assert (part.double().sum(0) - ref_w).abs().max().item() <= 2e-5 * ref_w.abs().max().item()
+    assert (rs.double().sum(0) - ref_b).abs().max().item() <= 2e-5 * ref_b.abs().max().item()
+
+
+def test_transpose16_fp16(hip16):
+    """countr_transpose16 moves 16-bit words: the fp16 build's W^T shadows are the bits of the fp16 shadow, transposed."""
+    sh = [(768, 2304), (512, 512), (128, 64)]
+    ws = [rnd(s_, 7 + i).to(H16).cuda() for i, s_ in enumerate(sh)]
+    wt = [torch.zeros(c, r, device="cuda", dtype=H16) for r, c in sh]
+    n = len(sh)
+    vp, ip = C.c_void_p * n, C.c_int * n
+    _lib.check(hip16.countr_transpose16(n, vp(*[w.data_ptr() for w in ws]), vp(*[w.data_ptr() for w in wt]), ip(*[s_[0] for s_ in sh]),
+                                        ip(*[s_[1] for s_ in sh]), st()), "transpose16")
+    torch.cuda.synchronize()
+    for w, t in zip(ws, wt):
+        assert torch.equal(t, w.t().contiguous())
+
+
 def test_layernorm_and_cast_fp16(hip16):
     rows, D = 1157, 768
     x = (rnd((rows, D), 1, 2.0) + 0.3).cuda()
