@@ -250,3 +250,17 @@ def test_bench_watchdog_prints_the_host_issued_line_when_captured_collectives_ha
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["steps"] == 3 and j["parity_checked"] is False
     assert "made no progress for 5 s" in j["multi_gpu"]["fallback"] and "issued by the host" in j["multi_gpu"]["collectives"]
+
+
+@pytest.mark.parametrize("warmup", [3, 5, 8])
+def test_bench_parity_guard_holds_behind_any_warmup(warmup):
+    """bench.py's own parity check runs behind the caller's warm-up steps, on a torch-initialised model whose count swings through zero
+    while the first steps move the last bias (-30 after three steps, +530 after five): relative to the count itself a 2-count bf16 error
+    read 9.7 % after --warmup 3 and failed the run; 54 instead of 58 tensors carried a judgeable gradient after --warmup 8.  The guard
+    measures counts against the density map's mass and accepts >= 40 tensors.  --warmup 5 --steps 20 is the driver's command."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20" if warmup == 5 else "3", "--warmup", str(warmup), "--reps", "1",
+                        "--no-other", "--no-cpu-baseline", "--no-families", "--no-b32"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["parity_checked"] is True and j["parity"]["count_rel_err"] < 5e-2 and j["parity"]["gradient_tensors"] >= 40
