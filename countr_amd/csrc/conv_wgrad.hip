@@ -19,6 +19,9 @@
 // would cost a wave 25 %, so the k-tiles of a (z, 32-row block) are dealt round-robin to the NC = tilesN * WNB waves that hold that
 // block's fragments anyway (+1.4 % each); every one writes its own slab: rowsum_partial[z * NC + i][Cout]
 // (countr_gemm_rowsum_slabs() tells the caller how many slabs a launch writes).
+// Round 5, the big maps (cwg3_body below): where the rows of the map are whole k-tiles (W % 64 == 0, or W % 96 == 0 with 96-pixel k-tiles)
+// a workgroup computes the THREE taps of one kernel row from ONE staged row segment of the input map -- a third fewer staged bytes and
+// a sixth fewer fragment reads per MFMA; the 192 x 192 and 96 x 96 layers of the density head.
 #include "common.hpp"
 #include "../../include/countr_hip.h"
 #include <stdlib.h>
