@@ -96,6 +96,8 @@ def main(args):
         # in the LR schedule with zeroed moments would be a silent restart of the bias correction)
         step.load_optimizer_state(ckpt["optimizer"])
         args.start_epoch = ckpt["epoch"] + 1
+        if "scaler" in ckpt:                      # util/misc.py:418-419 (fp16 mode: the GradScaler's scale / growth count; else ignored)
+            step.load_scaler_state(ckpt["scaler"])
         print("With optim & sched!")
     from countr_amd.data import fsc147
     loader = val_loader = None
@@ -166,8 +168,11 @@ def main(args):
                     loss = misc.all_reduce_mean(float(s[0]))                                # :319
                     if not np.isfinite(loss):
                         raise SystemExit("Loss is %s, stopping training" % loss)            # :308-310
+                    # grad_norm() applies a deferred AdamW update (flush): EVERY rank does it at the log step, so that all ranks keep
+                    # replaying the same graph keys in step -- a flush on rank 0 alone would send only rank 0 through an eager update and
+                    # (the first time) a late capture while its peers replay captured RCCL nodes
+                    gn = step.grad_norm()
                     if misc.is_main_process():
-                        gn = step.grad_norm()
                         print(json.dumps({"epoch": epoch, "it": it + 1, "loss": loss, "lr": lr, "shot_num": S,
                                           "batch_MAE": float(np.abs(s[1:1 + B] - s[1 + B:1 + 2 * B]).mean()),
                                           "grad_norm": float(gn.item()) if gn is not None else None}))
@@ -176,12 +181,13 @@ def main(args):
         val = evaluate(model, val_loader, n_val, B, device, val_rng, seed, epoch)
         train_mae, train_mse = (train_acc / n_iter).tolist()
         opt_state = step.optimizer_state()
+        sc_state = step.scaler_state()            # fp16: GradScaler.state_dict() of the device-side scaler; None otherwise (key omitted)
         if args.output_dir and (epoch % 50 == 0 or epoch + 1 == args.epochs) and epoch != 0:      # :408-412
-            misc.save_model(args, epoch, model, opt_state, suffix="finetuning_%d" % epoch)
-        misc.save_model(args, epoch, model, opt_state, suffix="finetuning_last")                  # :413-415
+            misc.save_model(args, epoch, model, opt_state, suffix="finetuning_%d" % epoch, scaler_state=sc_state)
+        misc.save_model(args, epoch, model, opt_state, suffix="finetuning_last", scaler_state=sc_state)   # :413-415
         if args.output_dir and val["MAE"] < min_MAE:                                              # :416-420
             min_MAE = val["MAE"]
-            misc.save_model(args, epoch, model, opt_state, suffix="finetuning_minMAE")
+            misc.save_model(args, epoch, model, opt_state, suffix="finetuning_minMAE", scaler_state=sc_state)
         print("[Train Epoch #%d] - MAE: %5.2f, RMSE: %5.2f" % (epoch, train_mae, train_mse ** 0.5), flush=True)             # :422
         print("[Val Epoch #%d] - MAE: %5.2f, RMSE: %5.2f, NAE: %5.2f" % (epoch, val["MAE"], val["RMSE"], val["NAE"]), flush=True)  # :423
     print("Training time %.1fs" % (time.time() - t_start))

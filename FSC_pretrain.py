@@ -84,6 +84,8 @@ def main(args):
     if ckpt is not None and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:352-361
         step.load_optimizer_state(ckpt["optimizer"])      # torch.optim.AdamW state_dict (ours or the reference's) or the older flat form; raises otherwise
         args.start_epoch = ckpt["epoch"] + 1
+        if "scaler" in ckpt:                      # util/misc.py:359-360
+            step.load_scaler_state(ckpt["scaler"])
         print("With optim & sched!")
     from countr_amd.data import fsc147
     loader = None
@@ -124,7 +126,7 @@ def main(args):
                         print(json.dumps({"epoch": epoch, "it": it + 1, "loss": lv, "lr": lr}))
         opt_state = step.optimizer_state()
         if args.output_dir and (epoch % 100 == 0 or epoch + 1 == args.epochs):         # :327-329
-            misc.save_model(args, epoch, model, opt_state, suffix="pretraining_%d" % epoch)
+            misc.save_model(args, epoch, model, opt_state, suffix="pretraining_%d" % epoch, scaler_state=step.scaler_state())
         if args.output_dir and misc.is_main_process():
             os.makedirs(args.output_dir, exist_ok=True)
             with open(os.path.join(args.output_dir, "log.txt"), "a", encoding="utf-8") as f:

@@ -50,7 +50,7 @@ def cpu_baseline(batch=4, steps=4, threads=None):
             "sample": "%d finetune step(s) of batch %d (fwd + decoder bwd + AdamW), fp32, torch-CPU oracle" % (steps, batch)}
 
 
-def parity_check(model, step, world, rank, B, NB, dev):
+def parity_check(model, step, world, rank, B, NB, dev, kick=lambda what: None):
     """The timed object -- the same FinetuneStep, graph replay, batch k = 0 of every rank -- against the oracle, OUTSIDE every timed region
     (FSC_finetune_cross.py:286-316).  The oracle is the CHECKER here, never the thing measured.  Every rank steps once on its batch 0 with
     that batch's seeded loss mask; rank 0 evaluates the oracle at the parameters the engine held in front of the step for EVERY rank's
@@ -59,6 +59,9 @@ def parity_check(model, step, world, rank, B, NB, dev):
     exemplar CNN 0.95) and norm (3 % / 5 %).  These are GUARD bars: the check must hold behind any number of warm-up steps the caller
     asks for (measured over --warmup 2..12: min cos 0.99963-0.99988, norm error 0.4-1.4 %, exemplar CNN 0.976-0.979, counts 0.4-1.9 % of
     the map's mass); the tight bars on a fixed schedule are tests/test_trainer_gpu.py::test_finetune_step_at_the_real_config_matches_oracle's.
+    At N > 1 every rank evaluates the oracle for ITS OWN batch (in parallel: the check takes one oracle pass, not N) and hands the gradients
+    to rank 0 through files in a per-job directory under the node's /tmp (bench.py is a one-node program by contract) -- not through RCCL,
+    which is the thing being checked; rank 0 polls for them and kicks the hang watchdog while it waits.
     Raises on a miss; returns the dict reported as `parity` in the JSON line."""
     from countr_amd.synthetic import make_batch
     step.flush()                                    # (defer_optimizer: the parameters the checked step starts from)
@@ -68,21 +71,39 @@ def parity_check(model, step, world, rank, B, NB, dev):
         step.load(imgs, boxes, gt, mask, 3)
         sums = step.step(3).clone()
     torch.cuda.synchronize()
-    if rank != 0:
-        return None
     from oracle import countr_ref as R
+    import numpy as np
     t0 = time.time()
-    torch.set_num_threads(min(os.cpu_count(), 32))
-    total, mine = {}, None
-    for r in range(world):
-        b = [t.cpu().numpy() for t in make_batch(B, shots=3, seed=r * NB)]
-        out, rloss, rg = R.loss_and_grads(cur, b[0], b[1], b[2], b[3], 3)
-        if r == 0:
-            mine = (out, rloss)
-        for k, g in rg.items():
-            if g is not None:
-                total[k] = g.double() if k not in total else total[k] + g.double()
-    out, rloss = mine
+    torch.set_num_threads(max(1, min((os.cpu_count() or 1) // max(world, 1), 32)))
+    b = [t.cpu().numpy() for t in (imgs, boxes, gt, mask)]
+    out, rloss, rg = R.loss_and_grads(cur, b[0], b[1], b[2], b[3], 3)
+    total = {k: g.double() for k, g in rg.items() if g is not None}
+    if world > 1:
+        xdir = os.path.join("/tmp", "countr_bench_parity_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        os.makedirs(xdir, exist_ok=True)
+        if rank != 0:
+            tmp = os.path.join(xdir, "r%d.tmp.npz" % rank)
+            np.savez(tmp, **{k: g.float().numpy() for k, g in total.items()})
+            os.replace(tmp, os.path.join(xdir, "r%d.npz" % rank))          # (atomic: rank 0 never reads a partial file)
+            return None
+        limit = float(os.environ.get("COUNTR_BENCH_PARITY_WAIT_S", "900"))
+        for r in range(1, world):
+            path = os.path.join(xdir, "r%d.npz" % r)
+            while not os.path.exists(path):
+                if time.time() - t0 > limit:
+                    raise SystemExit("bench.py: parity check: rank %d's oracle gradients did not arrive within %.0f s" % (r, limit))
+                kick("parity check: waiting for the oracle pass of rank %d" % r)
+                time.sleep(0.5)
+            with np.load(path) as z:
+                for k in z.files:
+                    g = torch.from_numpy(z[k]).double()
+                    total[k] = g if k not in total else total[k] + g
+            os.remove(path)
+            kick("parity check")
+        try:
+            os.rmdir(xdir)
+        except OSError:
+            pass
     loss = sums[0].item()
     rel_loss = abs(loss - rloss.item()) / abs(rloss.item())
     rc = R.counts(out).numpy()
@@ -486,7 +507,7 @@ def other_workloads(args, dev, steps=10, warmup=3):
         d = child("--precision", "fp16", "--plain", "--reps", "3", "--steps", "30")
         out["finetune_fp16"] = d if "error" in d else {
             "ms_per_step": d["ms_per_step"], "images_per_sec": d["value"], "steps": 30,
-            "workload": "the headline finetune step with precision='fp16' (libcountr_hip_f16.so; static loss scale 2^16), child process"}
+            "workload": "the headline finetune step with precision='fp16' (libcountr_hip_f16.so; dynamic loss scale on the device -- GradScaler semantics, initial 2^16), child process"}
     d = child("--workload", "infer")
     out["infer"] = d if "error" in d else {
         "ms_per_32_windows": d["ms_per_step"], "frames_per_sec": d["value"], "windows_per_sec": d["windows_per_sec"], "steps": steps,
@@ -668,7 +689,7 @@ def main():
         time.sleep(3600)
     kick("parity check")
     # (after the warm-up: the checked step REPLAYS the captured graph the timed blocks replay)
-    parity = None if (args.plain or args.no_parity) else parity_check(model, step, world, rank, B, NB, dev)
+    parity = None if (args.plain or args.no_parity) else parity_check(model, step, world, rank, B, NB, dev, kick=kick)
     step.sync.profile = world > 1 or step.sync.comm
     # box-to-box and run-to-run spread (5.3-5.55 ms over the boxes of round 2) is larger than most single optimisations: the block of
     # --steps steps is timed --reps times (each bracketed by barrier + synchronize, max over ranks) and the MEDIAN block is the value

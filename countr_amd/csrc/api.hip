@@ -17,11 +17,24 @@ std::mutex g_init_mu;
 std::atomic<float*> g_zero[MAX_DEV];
 }
 
+// Every nullptr return leaves its own message in countr_last_error(): a caller that turns the nullptr into a negative return code must
+// never surface a stale text of an earlier, unrelated failure.
 const float* countr_zero_vec(int n) {
   int d = -1;
-  if (n > COUNTR_ZERO_VEC_FLOATS || hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) return nullptr;
+  if (n > COUNTR_ZERO_VEC_FLOATS) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "bias-less launch with N = %d: the per-device vector of zeros holds %d floats", n, (int)COUNTR_ZERO_VEC_FLOATS);
+    countr_set_error(buf);
+    return nullptr;
+  }
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) {
+    (void)hipGetLastError();
+    countr_set_error("countr_zero_vec: hipGetDevice failed or the current device index is outside this library's table (64 devices)");
+    return nullptr;
+  }
   const float* z = g_zero[d].load(std::memory_order_acquire);
-  if (!z) countr_set_error("countr_init(device) has not been called for the current device (it allocates the per-device constants)");
+  if (!z) countr_set_error("countr_init(device) has not been called for the current device IN THIS LIBRARY (it allocates the per-device constants; "
+                           "libcountr_hip.so and libcountr_hip_f16.so each keep their own)");
   return z;
 }
 

@@ -80,6 +80,18 @@ class _Prologue:
                                               mask.data_ptr() if mask is not None else None, mask.numel() if mask is not None else 0,
                                               eng._stream()), "countr_step_prologue")
 
+    def resync(self):
+        """After an exception between fill() and executed(): the prologue may or may not have run on the device, so `seq` is re-read from
+        the device's own execution count -- otherwise every later step would fetch a stale ring record (old source pointers, lr and bias
+        corrections) without any error.  Best effort (the device may be unusable after a kernel fault); host sync."""
+        try:
+            torch.cuda.synchronize(self.eng.device)
+            self.seq = int(self.counter[0].item())
+            self.events = [None] * self.SLOTS
+        except Exception:  # noqa: BLE001 -- the original exception is the one to report
+            pass
+        self.keep = ()
+
     def executed(self, stream):
         """One execution (eager or replayed) of a phase that holds the prologue has been enqueued on `stream`."""
         k = self.seq % self.SLOTS
@@ -257,6 +269,34 @@ class _GraphStep:
         """fp16 mode: optimizer steps skipped so far because a gradient was not finite (GradScaler semantics); host sync."""
         return int(self.amp[3].item()) if self.amp is not None else 0
 
+    def scaler_state(self):
+        """fp16 mode: the checkpoint's 'scaler' entry -- a torch.cuda.amp.GradScaler.state_dict() of the device-side scaler (the reference
+        saves loss_scaler.state_dict() and reloads it under --do_resume: util/misc.py:316, :419), so a resumed run continues at the scale
+        and growth count it stopped at and the file loads into the reference's GradScaler.  None in bf16 / fp32 (no scaler: the key is
+        omitted -- GradScaler.load_state_dict({}) raises).  Host sync."""
+        if self.amp is None:
+            return None
+        self.flush()
+        a = self.amp.cpu().tolist()
+        return {"scale": float(a[0]), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": int(a[4]), "_growth_tracker": int(a[1])}
+
+    def load_scaler_state(self, sd):
+        """Restores a 'scaler' entry written by scaler_state() or by the reference's GradScaler (same keys).  Only the factors the device
+        kernel implements (x 2 growth, x 0.5 backoff) are accepted.  A no-op outside fp16 mode or for an empty / missing entry."""
+        if self.amp is None or not sd:
+            return False
+        if float(sd.get("growth_factor", 2.0)) != 2.0 or float(sd.get("backoff_factor", 0.5)) != 0.5:
+            raise ValueError("GradScaler state with growth_factor %r / backoff_factor %r: the device-side scaler implements 2.0 / 0.5"
+                             % (sd.get("growth_factor"), sd.get("backoff_factor")))
+        self.flush()
+        with torch.cuda.stream(self.stream):
+            self.amp[0] = float(sd["scale"])
+            self.amp[1] = float(int(sd.get("_growth_tracker", 0)))
+            self.amp[2] = 0.0
+            self.amp[4] = float(int(sd.get("growth_interval", 2000)))
+        torch.cuda.current_stream(self.eng.device).wait_stream(self.stream)
+        return True
+
     def flush(self):
         """defer_optimizer mode: apply the optimizer update that is still pending (the last step's), so that the parameters, the AdamW
         state and grad_norm() are those of a step that has completed.  A no-op otherwise."""
@@ -267,8 +307,12 @@ class _GraphStep:
             self.pro.hyper[:] = self._pc_hyper
             self.pro.fill([], False)
             self.pro.hyper[:] = keep
-            self._prologue_launch()                # (eager: the scalars reach eng.hyper)
-            self._phase_c(self._pc)
+            try:
+                self._prologue_launch()            # (eager: the scalars reach eng.hyper)
+                self._phase_c(self._pc)
+            except BaseException:
+                self.pro.resync()
+                raise
             self.pro.executed(self.stream)
         torch.cuda.current_stream(self.eng.device).wait_stream(self.stream)
         self._pc = self._pc_hyper = None
@@ -419,7 +463,7 @@ class _GraphStep:
                   dict(common, weight_decay=self.wd, params=list(range(len(nd), len(nd) + len(dc))))]
         return {"state": state, "param_groups": groups,
                 "countr_amd": {"format": "torch_adamw.v3", "step": eng.step_count, "group_steps": list(eng.group_steps),
-                               "seen_buckets": sorted(eng.opt_seen)}}
+                               "seen_buckets": sorted(eng.opt_seen), "mask_draws": int(self.pro.draws)}}
 
     def _moments(self):
         eng = self.eng
@@ -487,6 +531,7 @@ class _GraphStep:
         extra = opt.get("countr_amd")
         if isinstance(extra, dict):                   # our own files also carry the global counter (pinned-slot rotation only)
             eng.step_count = int(extra.get("step", eng.step_count))
+            self.pro.draws = int(extra.get("mask_draws", self.pro.draws))   # ... and the loss-mask stream's position (Philox counter)
         return True
 
     def _step(self, key):
@@ -528,41 +573,48 @@ class _GraphStep:
             self._cur_pc = pc
             pend, self._pending = self._pending, None
             self.pro.fill(list(zip(*pend[:3])) if pend is not None else [], self._draw_mask, keep=pend[3] if pend is not None else ())
-            if self.use_graph and not self.sync.comm:
-                # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
-                # costs ~20 us of idle GPU (4 launches per step before) -- and nothing else is launched between two replays
-                def whole(k, phases=phases):
-                    self._cur_pc = k[2]
-                    self._run_phases_merged(phases)
-                    if k[1] is not None:
-                        self._phase_c(k[1])
-                self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), None if defer else ckey, pc))
-            elif self.use_graph and self.sync.capturable:
-                # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
-                # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
-                def whole(k, phases=phases, cskip=cskip, zfill=zfill, apply_now=not defer):
-                    self._cur_pc = k[4]
-                    for i, (_name, fn, gkey) in enumerate(phases):
-                        fn(gkey)
-                        if k[1] is not None and i + 1 < len(phases):
-                            self.sync.start(i)
-                    if k[1] is not None:
-                        self._zero_buckets(zfill)
-                        self.sync.finish(skip=cskip)
-                        if apply_now:
+            # Between fill() and executed() the host's record count and the device's execution count must move together: an exception in
+            # here (a kernel or RCCL error, a failed late capture, KeyboardInterrupt) re-reads the device's count before it propagates.
+            try:
+                if self.use_graph and not self.sync.comm:
+                    # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
+                    # costs ~20 us of idle GPU (4 launches per step before) -- and nothing else is launched between two replays
+                    def whole(k, phases=phases):
+                        self._cur_pc = k[2]
+                        self._run_phases_merged(phases)
+                        if k[1] is not None:
                             self._phase_c(k[1])
-                gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else (), pc))
-                self._run_captured_comm(gk, whole)
-            else:
-                for i, (name, fn, gkey) in enumerate(phases):
-                    self._run_phase(name, fn, gkey)
-                    if last and i + 1 < len(phases):
-                        self.sync.start(i)
-                if last:
-                    if zfill:
-                        self._run_phase("z", self._zero_buckets, zfill)
-                    self.sync.finish(skip=cskip)
-                    self._run_phase("c", self._phase_c, ckey)
+                    self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), None if defer else ckey, pc))
+                elif self.use_graph and self.sync.capturable:
+                    # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
+                    # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
+                    def whole(k, phases=phases, cskip=cskip, zfill=zfill, apply_now=not defer):
+                        self._cur_pc = k[4]
+                        for i, (_name, fn, gkey) in enumerate(phases):
+                            fn(gkey)
+                            if k[1] is not None and i + 1 < len(phases):
+                                self.sync.start(i)
+                        if k[1] is not None:
+                            self._zero_buckets(zfill)
+                            self.sync.finish(skip=cskip)
+                            if apply_now:
+                                self._phase_c(k[1])
+                    gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else (), pc))
+                    self._run_captured_comm(gk, whole)
+                else:
+                    for i, (name, fn, gkey) in enumerate(phases):
+                        self._run_phase(name, fn, gkey)
+                        if last and i + 1 < len(phases):
+                            self.sync.start(i)
+                    if last:
+                        if zfill:
+                            self._run_phase("z", self._zero_buckets, zfill)
+                        self.sync.finish(skip=cskip)
+                        self._run_phase("c", self._phase_c, ckey)
+            except BaseException:
+                self.pro.resync()
+                self._cur_pc = None
+                raise
             self.pro.executed(self.stream)
             self._cur_pc = None
             if defer:

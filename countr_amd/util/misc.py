@@ -70,15 +70,20 @@ def all_reduce_mean(x):
     return float(x)
 
 
-def save_model(args, epoch, model_without_ddp, optimizer_state, suffix=""):
+def save_model(args, epoch, model_without_ddp, optimizer_state, suffix="", scaler_state=None):
     """Checkpoint dict {'model','optimizer','epoch','scaler','args'} named checkpoint__<suffix>.pth (util/misc.py:304-328).
-    bf16 needs no GradScaler; the key is kept (empty) so reference tooling can read the file."""
+    scaler_state: the step's GradScaler state_dict (fp16 mode: trainer.scaler_state()).  bf16 / fp32 have no scaler and the key is
+    OMITTED: the reference's resume reads it only `if 'scaler' in checkpoint` (util/misc.py:418-419) and its GradScaler.load_state_dict
+    raises on an empty dict, so an empty entry would make the file unloadable there."""
     if not is_main_process() or not args.output_dir:
         return None
     os.makedirs(args.output_dir, exist_ok=True)
     path = os.path.join(args.output_dir, "checkpoint%s.pth" % ("__" + suffix if suffix else ""))
-    torch.save({"model": {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
-                "optimizer": optimizer_state, "epoch": epoch, "scaler": {}, "args": vars(args)}, path)
+    ckpt = {"model": {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+            "optimizer": optimizer_state, "epoch": epoch, "args": vars(args)}
+    if scaler_state:
+        ckpt["scaler"] = dict(scaler_state)
+    torch.save(ckpt, path)
     return path
 
 

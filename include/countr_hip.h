@@ -41,7 +41,13 @@ extern "C" {
                                  INPUT here (the saved pre-activation, same layout and dtype as C) */
 
 /* -------- library management -------- */
-int countr_init(int device);            /* selects device, checks it is gfx950-class; 0 = ok   */
+int countr_init(int device);            /* selects device, checks it is gfx950-class, allocates the library's ONE per-device
+                                           constant (a vector of zeros that bias-less GEMM / convolution launches read); 0 = ok.
+                                           REQUIRED once per device and PER LIBRARY before any launch: libcountr_hip.so (bf16) and
+                                           libcountr_hip_f16.so (fp16) are separate images with separate state.  Idempotent and
+                                           thread-safe.  A bias-less countr_gemm / countr_conv launch on a device without it fails
+                                           with a negative code and a message naming countr_init (it does not allocate lazily:
+                                           no allocation inside a launch) */
 int countr_version(void);               /* ABI version, currently 8 (8: countr_transpose16 added, no layout change; 7: countr_masked_mse_amp / countr_patch_mse_amp / countr_adamw_step_amp added, no layout change; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 

@@ -199,3 +199,23 @@ def test_init_distributed_mode_reads_the_three_launcher_conventions(monkeypatch)
     a = types.SimpleNamespace(dist_on_itp=False, world_size=16, dist_url="tcp://head:1")
     misc.init_distributed_mode(a)
     assert a.distributed and (a.rank, a.world_size, a.gpu) == (11, 16, 3) and calls[-1]["rank"] == 11 and calls[-1]["world_size"] == 16
+
+
+def test_checkpoint_scaler_entry_is_a_gradscaler_state_or_absent(tmp_path):
+    """util/misc.py:312-318 saves loss_scaler.state_dict() under 'scaler' and :418-419 reloads it `if 'scaler' in checkpoint`; torch's
+    GradScaler.load_state_dict raises on an EMPTY dict.  So: fp16 steps hand save_model the device-side scaler's state (the GradScaler
+    keys), bf16 / fp32 steps hand it None and the key is omitted -- either way the reference's resume accepts the file."""
+    import types
+    from countr_amd.util import misc
+    args = types.SimpleNamespace(output_dir=str(tmp_path), lr=1e-5)
+    model = torch.nn.Linear(2, 2)
+    p = misc.save_model(args, 3, model, {"state": {}, "param_groups": []}, suffix="a")
+    ck = torch.load(p, map_location="cpu", weights_only=False)
+    assert "scaler" not in ck and ck["epoch"] == 3 and set(ck) == {"model", "optimizer", "epoch", "args"}
+    st = {"scale": 4096.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 17}
+    p = misc.save_model(args, 4, model, {"state": {}, "param_groups": []}, suffix="b", scaler_state=st)
+    ck = torch.load(p, map_location="cpu", weights_only=False)
+    assert ck["scaler"] == st
+    # the file's entry is what torch's own GradScaler writes (same key set)
+    ref = torch.amp.GradScaler("cpu", enabled=True)
+    assert set(ref.state_dict()) == set(st)

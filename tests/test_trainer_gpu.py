@@ -521,3 +521,37 @@ def test_fp16_dynamic_loss_scale_follows_gradscaler(defer):
                 assert ((got * ref).sum() / (got.norm() * ref.norm())).item() > 0.999
     assert first_clean is not None and 10 <= first_clean <= 45, first_clean       # 2^40 -> the first scale whose backward stays finite
     assert skipped >= first_clean and all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_fp16_scaler_state_roundtrips_through_the_checkpoint_and_gradscaler():
+    """the fp16 step's GradScaler lives on the device; its state must travel with the checkpoint like the reference's
+    (util/misc.py:316 saves loss_scaler.state_dict(), :419 reloads it).  The exported entry loads into a real torch GradScaler and back
+    into a fresh step (scale, growth tracker, interval), a scaler state written by torch loads too, the loss-mask stream's position rides
+    in the optimizer entry's extras, and a bf16 step exports None (key omitted)."""
+    from countr_amd.trainer import FinetuneStep
+    m, _sd = make("fp16")
+    step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=True, defer_optimizer=True, mask_seed=3)
+    step.amp[0], step.amp[4] = 2.0 ** 12, 5.0
+    for it in range(3):
+        imgs, boxes, gt, _mask = W.make_inputs(batch=2, shots=3, seed=310 + it)
+        step.load(*(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt)), None, 3)
+        step.step(3)
+    st = step.scaler_state()
+    assert set(st) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    assert st["growth_interval"] == 5 and st["scale"] == step.loss_scale and 0 <= st["_growth_tracker"] < 5
+    assert st["_growth_tracker"] + 5 * 0 == int(step.amp[1].item())
+    gs = torch.amp.GradScaler("cuda")
+    gs.load_state_dict(dict(st))                       # the reference's resume path (raises on a malformed / empty state)
+    assert gs.state_dict()["scale"] == st["scale"] and gs.state_dict()["_growth_tracker"] == st["_growth_tracker"]
+    opt = step.optimizer_state()
+    assert opt["countr_amd"]["mask_draws"] == 3
+    m2, _ = make("fp16")
+    step2 = FinetuneStep(m2, batch=2, lr=1e-3, eps=1e-4, use_graph=True, defer_optimizer=True, mask_seed=3)
+    assert step2.load_scaler_state(st) and step2.load_optimizer_state(opt)
+    assert step2.scaler_state() == st and step2.pro.draws == 3
+    assert step2.load_scaler_state(gs.state_dict())    # a state torch wrote
+    assert not step2.load_scaler_state({})
+    with pytest.raises(ValueError):
+        step2.load_scaler_state(dict(st, growth_factor=3.0))
+    mb, _ = make("bf16")
+    assert FinetuneStep(mb, batch=2, use_graph=False).scaler_state() is None
