@@ -35,6 +35,17 @@
 #ifndef COUNTR_FA_PRIO
 #define COUNTR_FA_PRIO 0
 #endif
+// Round 6: no running row max in the steady state.  P = exp2(S - m_ref) with m_ref = the row max of the FIRST key tile: a later score
+// that exceeds it by d just makes that P 2^d -- exact in fp32 / bfloat16 (a power-of-two factor that cancels in O / l) as long as
+// nothing overflows, and l >= max P tells afterwards whether anything could have.  So the loop carries no v_max3 chain, no cross-lane
+// max and no rescale test (13 % of a step's issue cycles, profiles/r3_fa_step_microbench.txt: 1611 -> 1398); after the last tile every
+// lane checks l < 2^64 and O finite, the workgroup ORs the verdicts through one LDS word, and a workgroup with a miss (a row whose
+// later scores exceed the first tile's max by more than 64 in the log2 domain, or non-finite data) runs its strip AGAIN on the exact
+// deferred-rescale loop below -- same result as before, twice the time, for inputs no trained attention produces.  bfloat16 build only:
+// an fp16 P overflows at 2^16, so the fp16 library keeps the running max.  -DCOUNTR_FA_NOMAX=0: the round-2..5 kernel.
+#ifndef COUNTR_FA_NOMAX
+#define COUNTR_FA_NOMAX (!COUNTR_HALF_FP16)
+#endif
 #include <stdlib.h>
 #include <utility>
 
@@ -60,20 +71,33 @@ template <int DH, bool DMA> struct FaCfg {
   static constexpr int OP = DH * 2 + 16;                                // pitch of the output staging rows
   static constexpr int OST = DMA ? 0 : NSLOT * STAGE;                   // DMA: the output staging aliases the (drained) ring
   static constexpr int LDS = DMA ? NSLOT * STAGE : NSLOT * STAGE + 4 * 32 * OP;
+  static constexpr int LDS_ALL = LDS + 16;                              // + the workgroup's "fast path overflowed" word (COUNTR_FA_NOMAX)
   static_assert(!DMA || (DH == 64 && 4 * 32 * OP <= NSLOT * STAGE), "DMA path is laid out for 128-byte rows");
 };
 
 // units of exp work (2 scores each) finished by the end of MFMA slot j; slots = 2*KS QK^T MFMAs then 4*DB PV MFMAs
-template <int DH> struct FaSched;
-template <> struct FaSched<64> {
+// NM (no running max, see COUNTR_FA_NOMAX): the slots MAX0 .. NS-1 carry no row-max work, so the exp units are spread over all slots
+// (deadlines: the PV MFMA of slot NQK + e reads units 4 (e / DB) .. +3, which must be complete by the end of the slot before it).
+template <int DH, bool NM> struct FaSched;
+template <> struct FaSched<64, false> {
   static constexpr int NS = 16, MAX0 = 12;   // row max of S(t+1) spread over slots MAX0 .. NS-1
   static constexpr int PRE = 2;              // units done under the latency of the first fragment reads, ahead of slot 0
   static constexpr int unit_end[16] = {3, 4, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 16, 16, 16, 16};
 };
-template <> struct FaSched<32> {
+template <> struct FaSched<64, true> {
+  static constexpr int NS = 16, MAX0 = 12;
+  static constexpr int PRE = 2;
+  static constexpr int unit_end[16] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 16};
+};
+template <> struct FaSched<32, false> {
   static constexpr int NS = 8, MAX0 = 6;
   static constexpr int PRE = 2;
   static constexpr int unit_end[8] = {4, 7, 10, 12, 14, 16, 16, 16};
+};
+template <> struct FaSched<32, true> {
+  static constexpr int NS = 8, MAX0 = 6;
+  static constexpr int PRE = 2;
+  static constexpr int unit_end[8] = {4, 6, 8, 10, 12, 14, 16, 16};
 };
 
 // Built with -fno-slp-vectorize -fno-honor-nans (countr_amd/build.py): plain -O3 SLP-packs adjacent fp32 adds into v_pk_add_f32
@@ -111,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
                                                              float* __restrict__ lse, int N, int H, float c /* scale*log2e */) {
   constexpr bool DMA = DH == 64;
   using C = FaCfg<DH, DMA>;
-  using SC = FaSched<DH>;
+  constexpr bool NOMAX = COUNTR_FA_NOMAX && !COUNTR_HALF_FP16 && (ABL == 0 || ABL == 7);
   constexpr int KS = DH / 16;        // QK^T k-steps (16 channels each)
   constexpr int DB = DH / 32;        // 32-channel blocks of O^T
   constexpr int CPR = DH / 8;        // 16-byte chunks per K/V row
@@ -131,6 +155,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
 
   const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  volatile int* const redo = reinterpret_cast<volatile int*>(smem + C::LDS);   // NOMAX: set by any lane whose fast-path sums left the safe range
+  if (NOMAX && tid == 0) *redo = 0;                                             // (published by the prologue's barriers)
   const int qblocks = (N + 127) >> 7;
   // XCD-aware mapping (speed only): all query blocks of one (batch, head) get workgroup ids congruent mod 8 so that its K/V
   // is fetched into ONE XCD's L2.
@@ -258,14 +284,17 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   }
 
   f32x16_t o[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float mref = 0.f, l0 = 0.f, l1 = 0.f;
   f32x16_t negm;     // PRE: -m_ref in every accumulator slot (all 16 scores of a lane belong to one query row)
+  auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+    mref = 0.f; l0 = 0.f; l1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+  };
 
   auto mask_tail = [&](f32x16_t (&S)[2], int tile) {   // keys >= N of the ragged last tile do not exist
 #pragma unroll
@@ -333,6 +362,9 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   // ================================================================ prologue: S(0) = K(0) Q^T, its row max
   // DMA: K(0) -> K area of slot 3 (stage "-1"), stages 0 and 1 -> slots 0, 1 (all in flight together; stage 1 stays in flight).
   // registers: K(0) -> K area of slot 1, {K(1), V(0)} -> slot 0 (all loads issued before the first wait).
+  f32x16_t SA[2], SB[2];
+  auto prologue = [&]() __attribute__((always_inline)) {
+  reset_state();
   const char* K0;
   if (DMA) {
     dma_tile(srdK, 0, koff, Kslot(3));
@@ -353,7 +385,6 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
     __syncthreads();
     K0 = Kslot(1);
   }
-  f32x16_t SA[2], SB[2];
   if (active) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
@@ -395,10 +426,14 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
   } else {
     __syncthreads();   // register path: the K area of slot 1 is rewritten at the end of step 0
   }
+  };   // prologue
 
   // ================================================================ one pipelined step (tile t, t + 1 < T)
-  // Sc = S(t) -> P, Sn = S(t+1) = K(t+1) Q^T, O += V(t)^T P^T, rescale decision for tile t + 1.  Reads stage t.
-  auto step = [&](const int t, f32x16_t (&Sc)[2], f32x16_t (&Sn)[2]) {
+  // Sc = S(t) -> P, Sn = S(t+1) = K(t+1) Q^T, O += V(t)^T P^T, rescale decision for tile t + 1 (NM: none -- m_ref stays the first
+  // tile's row max).  Reads stage t.
+  auto step = [&](auto NMt, const int t, f32x16_t (&Sc)[2], f32x16_t (&Sn)[2]) __attribute__((always_inline)) {
+    constexpr bool NM = decltype(NMt)::value;
+    using SC = FaSched<DH, NM>;
     const int slot = DMA ? (t & 3) : (t & 1);
     if (STAGING) {
       if (DMA) {
@@ -494,8 +529,10 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
         if constexpr (j >= SC::MAX0 && ABL != 9 && ABL != 10) {   // row max of S(t+1), a share per slot
           constexpr int PER = 16 / (SC::NS - SC::MAX0), r0 = (j - SC::MAX0) * PER;
           if (RAGGED && j == SC::MAX0 && t + 2 == T) mask_tail(Sn, t + 1);
+          if constexpr (!NM) {
 #pragma unroll
-          for (int r = r0; r < r0 + PER; ++r) mx = (r == 0) ? fmaxf(Sn[0][0], Sn[1][0]) : max3(mx, Sn[0][r], Sn[1][r]);
+            for (int r = r0; r < r0 + PER; ++r) mx = (r == 0) ? fmaxf(Sn[0][0], Sn[1][0]) : max3(mx, Sn[0][r], Sn[1][r]);
+          }
         }
 #if COUNTR_FA_NOPIN == 0
         __builtin_amdgcn_sched_barrier(0);
@@ -503,7 +540,9 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
         if constexpr ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // a pin every fourth slot only
 #endif
       });
-      if (ABL != 9 && ABL != 10) rescale_for(xor32_max(mx), Sn);
+      if constexpr (!NM) {
+        if (ABL != 9 && ABL != 10) rescale_for(xor32_max(mx), Sn);
+      }
     }
     if (ABL == 7) tb = __builtin_readcyclecounter();
     if (STAGING) {
@@ -521,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
     if (ABL == 7) { const uint64_t td = __builtin_readcyclecounter(); tkc += tb - ta; tks += tc - tb; tkb += td - tc; }
   };
   // ---- last tile: no next scores
-  auto tail = [&](const int t, f32x16_t (&Sc)[2]) {
+  auto tail = [&](const int t, f32x16_t (&Sc)[2]) __attribute__((always_inline)) {
     if (active) {
       const int slot = DMA ? (t & 3) : (t & 1);
       if (DMA) {
@@ -560,23 +599,44 @@ __global__ __launch_bounds__(256, 2) void fa_fwd_pipe_kernel(const bf16_t* __res
     }
   };
 
-  if (ABL == 7) tkp = __builtin_readcyclecounter();
-  int t = 0;
-  for (; t + 2 < T; t += 2) {
-    step(t, SA, SB);
-    step(t + 1, SB, SA);
-  }
-  if (t + 1 < T) {
-    step(t, SA, SB);
-    tail(t + 1, SB);
-  } else {
-    tail(t, SA);
-  }
-
+  auto attend = [&](auto NMt) __attribute__((always_inline)) {   // prologue + all key tiles
+    prologue();
+    if (ABL == 7) tkp = __builtin_readcyclecounter();
+    int t = 0;
+    for (; t + 2 < T; t += 2) {
+      step(NMt, t, SA, SB);
+      step(NMt, t + 1, SB, SA);
+    }
+    if (t + 1 < T) {
+      step(NMt, t, SA, SB);
+      tail(t + 1, SB);
+    } else {
+      tail(t, SA);
+    }
+  };
   uint64_t tke = 0;
-  if (ABL == 7) tke = __builtin_readcyclecounter();
-  // ---- epilogue: normalise, stage the wave's [32][DH] bf16 block through its private LDS rows, store whole rows (16-byte chunks)
-  if (DMA) __builtin_amdgcn_s_barrier();   // the staging rows alias the ring: every wave is done with the last V tile (no DMA pending)
+  if constexpr (NOMAX) {
+    attend(std::true_type{});
+    if (ABL == 7) tke = __builtin_readcyclecounter();
+    if (active) {   // did every P, l and O of this lane stay finite and far from the top of the fp32 range?
+      float z = 0.f;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z = __builtin_fmaf(o[d][i], 0.f, z);      // NaN iff some O is inf / NaN
+      if (!(l0 + l1 < 0x1p64f) || !(z == 0.f)) *redo = 1;
+    }
+    __syncthreads();   // publishes the verdict; also: every wave is done with the last V tile (the output staging aliases the ring)
+    if (*redo != 0) {  // workgroup-uniform: the strip again, on the exact loop (running max, deferred rescale)
+      attend(std::false_type{});
+      if (DMA) __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    attend(std::false_type{});
+    if (ABL == 7) tke = __builtin_readcyclecounter();
+    // ---- epilogue: normalise, stage the wave's [32][DH] bf16 block through its private LDS rows, store whole rows (16-byte chunks)
+    if (DMA) __builtin_amdgcn_s_barrier();   // the staging rows alias the ring: every wave is done with the last V tile (no DMA pending)
+  }
   if (active) {
     char* ost = smem + C::OST + wave * 32 * C::OP;
     const float lt = xor32_sum(l0 + l1);
@@ -616,19 +676,24 @@ int launch_fa_fwd_pipe(const void* qkv, void* out, float* lse, int B, int N, int
   dim3 grid(B * H * ((N + 127) / 128)), block(256);
 #ifdef COUNTR_FA_ABL_BUILD     // timing experiments (bash tools/exp_file.sh flash_attn_fwd abl<k> -DCOUNTR_FA_ABL_BUILD=<k>): results are wrong
   if (DH == 64 && N % 64 == 0) {
-    hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, COUNTR_FA_ABL_BUILD>), grid, block, (FaCfg<64, true>::LDS), s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pipe_kernel<64, false, COUNTR_FA_ABL_BUILD>), hipFuncAttributeMaxDynamicSharedMemorySize, FaCfg<64, true>::LDS_ALL);
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, COUNTR_FA_ABL_BUILD>), grid, block, (FaCfg<64, true>::LDS_ALL), s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
     COUNTR_LAUNCH_CHECK("countr_attn_fwd (ablation)");
   }
 #endif
+  // the dh = 64 ring is exactly 64 KiB; with the verdict word behind it the workgroup's LDS is a little over the default limit
   if (c <= 0.f) {   // pre-scaled q (see PRE): built for the encoder shape class only
     if (DH != 64 || N % 64) { countr_set_error("countr_attn_fwd: scale <= 0 (pre-scaled q) needs head_dim 64 and N % 64 == 0"); return -1; }
-    hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, 0, true>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, 1.f);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pipe_kernel<64, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<64, false, 0, true>), grid, block, C::LDS_ALL, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, 1.f);
     COUNTR_LAUNCH_CHECK("countr_attn_fwd");
   }
   if (N % 64) {
-    hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, true>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pipe_kernel<DH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, true>), grid, block, C::LDS_ALL, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
   } else {
-    hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, false>), grid, block, C::LDS, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pipe_kernel<DH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
+    hipLaunchKernelGGL((fa_fwd_pipe_kernel<DH, false>), grid, block, C::LDS_ALL, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, c);
   }
   COUNTR_LAUNCH_CHECK("countr_attn_fwd");
 }

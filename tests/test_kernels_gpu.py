@@ -470,6 +470,40 @@ def test_flash_attention_fwd_prescaled_q(hip, B, N, H):
     assert hip.countr_attn_fwd(P(qd), P(out), P(lse), B, N, H * 2, 32, 0.0, st()) != 0
 
 
+@pytest.mark.parametrize("N,H,dh,pre,spike", [(576, 12, 64, False, 40.0), (576, 12, 64, True, 40.0), (576, 12, 64, True, 250.0), (576, 16, 32, False, 60.0),
+                                              (200, 3, 64, False, 60.0), (288, 12, 64, False, 250.0)])
+def test_flash_attention_fwd_scores_far_above_the_first_key_tile(hip, N, H, dh, pre, spike):
+    """Round 6: the bf16 kernel's steady state keeps the FIRST key tile's row max as the softmax reference (no running max: a later score
+    d above it just makes P 2^d, exact while nothing overflows); every lane checks l < 2^64 and O finite at the end and a workgroup with
+    a miss runs its strip again on the exact running-max loop.  Here keys behind the first tile score tens (spike 40 / 60) to hundreds
+    (250: exp2 overflows to inf on the fast path) of log2 units above it for some query rows of ONE (batch, head) -- above AND below, the
+    scores are signed -- while the other heads stay ordinary: both paths inside one launch, each against fp64."""
+    B = 2
+    c = dh ** -0.5 * 1.4426950408889634
+    qkv = rnd((B, N, 3, H, dh), 57, 1.0)
+    g = torch.Generator().manual_seed(58)
+    sign = (torch.randint(0, 2, (dh,), generator=g) * 2 - 1).float()
+    for j in (70, N // 2 + 5, N - 2):                       # all behind key tile 0
+        qkv[0, j, 1, 1] = spike * sign
+    qkv[1, N - 1, 1, H - 1] = spike * sign                  # ... and the very last key of another (batch, head)
+    if pre:
+        qkv[:, :, 0] *= c
+    qkv = qkv.to(torch.bfloat16)
+    qd = qkv.cuda()
+    out = torch.full((B, N, H * dh), float("nan"), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty((B, H, N), device="cuda")
+    _lib.check(hip.countr_attn_fwd(P(qd), P(out), P(lse), B, N, H, dh, 0.0 if pre else dh ** -0.5, st()))
+    q = qkv[:, :, 0].double().permute(0, 2, 1, 3); k = qkv[:, :, 1].double().permute(0, 2, 1, 3)
+    v = qkv[:, :, 2].double().permute(0, 2, 1, 3)
+    sc = (q @ k.transpose(-1, -2)) * (0.6931471805599453 if pre else dh ** -0.5)
+    top = (sc[0, 1].max(-1).values - sc[0, 1, :, :64].max(-1).values) * 1.4426950408889634
+    assert (top > 64).sum() > 8 and (top < 1).sum() > 8        # rows that need the exact path, rows that do not
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * dh)
+    assert torch.isfinite(out.float()).all()
+    assert relerr(out, ref) < 1.5e-2
+    assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-4
+
+
 @pytest.mark.parametrize("B,N,H,dh", [(2, 576, 16, 32), (1, 576, 12, 64), (1, 200, 3, 32), (2, 64, 2, 64)])
 def test_flash_attention_bwd(hip, B, N, H, dh):
     """Fused attention backward (dq, dk, dv in one packed tensor) vs fp64 autograd of softmax(q k^T * scale) v."""
