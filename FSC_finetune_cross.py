@@ -90,7 +90,8 @@ def main(args):
     print("actual lr: %.2e, effective batch size: %d" % (args.lr, eff_batch))
     step = FinetuneStep(model, batch=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, betas=(0.9, 0.95),
                         accum_iter=args.accum_iter, per_rank_shot=args.per_rank_shot, mask_seed=seed,   # seed = args.seed + rank (:168)
-                        defer_optimizer=True)
+                        pipeline_encoder=True,      # the next batch's frozen-encoder forward beside this batch's decoder side (bit-identical)
+                        defer_optimizer=True)       # (what the step does where the pipelined form cannot run: fp32, host-issued collectives)
     if ckpt is not None and args.do_resume and "optimizer" in ckpt and "epoch" in ckpt:      # util/misc.py:415: all three, else skipped
         # (raises when the entry EXISTS and fits neither this model's torch.optim.AdamW layout nor the older flat form: continuing late
         # in the LR schedule with zeroed moments would be a silent restart of the bias correction)
@@ -132,18 +133,30 @@ def main(args):
         it_data = iter(loader) if loader is not None else None
         # the loop's own device work (mask draw, error sums) runs on the step's stream: from another stream every step pays two
         # cross-queue hand-overs (inputs ready -> step, step done -> caller), ~50 us of idle GPU per step on MI355X
+        # one batch of look-ahead: the step is told the NEXT batch's images (load(..., next_imgs=)) and runs their frozen-encoder forward
+        # beside this batch's decoder side; the DataLoader's workers have that batch ready anyway
+
+        def fetch(it):
+            if it >= n_iter:
+                return None
+            if it_data is not None:
+                return next(it_data)
+            return make_batch(B, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
+        ahead = fetch(0)
         with step.on_stream():
             for it in range(n_iter):
                 if it % args.accum_iter == 0:                                               # :270-271 (per accumulation window)
                     lr = lr_sched.adjust_learning_rate(None, it / n_iter + epoch, args)
+                item, ahead = ahead, fetch(it + 1)
+                next_imgs = ahead[0] if ahead is not None else None
                 if it_data is not None:
-                    imgs, gt, _n, boxes, _pos, m_flag, _ids = next(it_data)
+                    imgs, gt, _n, boxes, _pos, m_flag, _ids = item
                     # loss mask: Bernoulli(0.8) per pixel, one mask per batch (FSC_finetune_cross.py:290-292)
                     mask = None      # drawn by the step itself (FinetuneStep(mask_seed=seed): Philox stream keyed by seed + rank)
                     # host tensors go straight to load(): it stages them over PCIe on a copy stream while the previous step computes
                     mosaic = int(torch.as_tensor(m_flag).sum().item()) != 0
                 else:
-                    imgs, boxes, gt, mask = make_batch(B, shots=3, seed=seed * 100003 + epoch * n_iter + it, device=device)
+                    imgs, boxes, gt, mask = item
                     mosaic = False
                 world = misc.get_world_size()
                 mosaics = [mosaic] * world
@@ -158,7 +171,7 @@ def main(args):
                 else:                                    # one draw for all ranks, so the ban is shared too: any rank with a Type-2 mosaic
                     shots_all = None
                     S = shared_shot_num(epoch * n_iter + it, seed=args.seed, allow_zero=not any(mosaics))
-                step.load(imgs, boxes, gt, mask, S)
+                step.load(imgs, boxes, gt, mask, S, next_imgs=next_imgs)
                 sums = step.step(S, lr=lr, shots_all=shots_all)
                 err = (sums[1:1 + B] - sums[1 + B:1 + 2 * B]).abs().double()                # :296-304, no host sync
                 train_acc[0] += err.mean()

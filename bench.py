@@ -559,6 +559,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="no cross-iteration pipelining of the frozen encoder (FinetuneStep(pipeline_encoder=False): "
+                                                                "every step computes its own encoder forward before its decoder side)")
     ap.add_argument("--no-defer", action="store_true", help="optimizer update at the tail of its own step instead of beside the next step's "
                                                             "frozen-encoder forward (FinetuneStep(defer_optimizer=False))")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step (it runs outside the timed regions)")
@@ -613,7 +615,7 @@ def main():
     model.to(dev).train()
     B = args.batch
     step = FinetuneStep(model, batch=B, lr=1e-5, weight_decay=0.05, use_graph=not args.no_graph, process_group=None, mask_seed=1234 + rank,
-                        defer_optimizer=not args.no_defer)
+                        defer_optimizer=not args.no_defer, pipeline_encoder=not args.no_pipeline)
     # device-resident synthetic batches (inputs are in HBM when the timed region starts); every timed step stages a batch into the
     # plan's input buffers (device-to-device) and draws a fresh Bernoulli(0.8) loss mask, as the reference loop does per iteration --
     # both inside the step's graph (its prologue kernel: trainer._Prologue)
@@ -622,17 +624,21 @@ def main():
     if args.host_inputs:
         batches = [tuple(t.cpu().pin_memory() if torch.is_tensor(t) else t for t in b) for b in batches]
 
-    def one(k, S):
+    def one(k, S, more=True):
         imgs, boxes, gt, _ = batches[k % NB]
         # the loop runs on the step's stream (callers enter step.on_stream() around their loop), as everything does on ONE stream in
         # the reference's loop: from another stream every step pays two cross-queue hand-overs (inputs ready -> step, step done -> caller).
-        # mask=None: a fresh Bernoulli(0.8) mask per step (FSC_finetune_cross.py:290-292), drawn by the step itself
-        step.load(imgs, boxes, gt, None, S)
+        # mask=None: a fresh Bernoulli(0.8) mask per step (FSC_finetune_cross.py:290-292), drawn by the step itself.
+        # next_imgs: a training loop knows its next batch (the DataLoader has it ready): pipeline_encoder runs that batch's frozen-encoder
+        # forward beside this batch's decoder side.  `more` is False for the LAST step of a timed block: nothing is computed ahead across
+        # the end of a timed region (K timed steps = K encoder forwards + K decoder-side passes + K updates, all inside it).
+        step.load(imgs, boxes, gt, None, S, next_imgs=batches[(k + 1) % NB][0] if more else None)
         return step.step(S)
 
     host_dt = [0.0]
 
     def timed(shots):
+        step.drop_lookahead()      # pipeline_encoder: no encoder forward computed OUTSIDE this timed region is used inside it
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -640,7 +646,7 @@ def main():
         t0 = time.perf_counter()
         with step.on_stream():
             for k, S in enumerate(shots):
-                sums = one(k, S)
+                sums = one(k, S, more=k + 1 < len(shots))
             step.flush()        # defer_optimizer: the last step's update is applied INSIDE the timed region (K steps = K optimizer updates)
         host_dt[0] = time.perf_counter() - t0      # the host's own time to enqueue the block (it runs ahead of the GPU when smaller than dt)
         torch.cuda.synchronize()
@@ -682,8 +688,9 @@ def main():
     kick = (lambda what: wd.kick(what)) if wd is not None else (lambda what: None)
     kick("warm-up: capture of the communicating step")
     with step.on_stream():
-        for k in range(max(args.warmup, 2)):   # the first two steps build the plan and capture the graphs
-            one(k, 3)
+        nw = max(args.warmup, 2)               # the first steps build the plan and capture the graphs (pipeline_encoder: the forms of a step
+        for k in range(nw):                    # -- first of a loop, middle (from --warmup 3 on), last -- so that no timed block captures)
+            one(k, 3, more=k + 1 < nw)
     torch.cuda.synchronize()
     if os.environ.get("COUNTR_BENCH_FAKE_HANG") == "1" and wd is not None:      # (tests/test_ddp_gpu.py: the watchdog's exit path)
         time.sleep(3600)
@@ -738,7 +745,9 @@ def main():
     mix = [shared_shot_num(i, seed=0) for i in range(args.steps)]
     with step.on_stream():
         for S in sorted(set(mix) | {0, 1, 2}):
-            one(0, S); one(1, S)           # build / capture the plans of the other shot counts outside the timed region
+            # build / capture the plans of the other shot counts outside the timed region (pipeline_encoder: the three forms of a step --
+            # own encoder forward + look-ahead, look-ahead only, no look-ahead -- are three graphs per shot count)
+            one(0, S); one(1, S); one(2, S, more=False)
     dt_mix, _ = timed(mix)
     loss = sums[0].item()
     ranks_seen = None
@@ -763,7 +772,12 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                        "optimizer_update": ("deferred: AdamW of step k runs beside the frozen-encoder forward of step k + 1 (bit-identical "
                                             "parameters; the last update of a timed block is flushed inside it)")
-                                           if (step.defer and step.use_graph and (not step.sync.comm or step.sync.capturable)) else "at the tail of its step"},
+                                           if (step.defer and step.use_graph and (not step.sync.comm or step.sync.capturable)) else "at the tail of its step",
+                       "encoder_pipelining": ("on: the frozen-encoder forward of batch k + 1 runs on its own lane of step k's graph beside batch k's "
+                                              "decoder forward / loss / backward / AdamW (bit-identical results); the first step of every timed block "
+                                              "computes its own encoder forward first and the last one computes nothing ahead, so a block of K steps "
+                                              "contains exactly K encoder forwards, K decoder-side passes and K updates")
+                                             if step._pipe_ok() else "off"},
             "final_loss": loss, "host_enqueue_ms_per_step": host_ms,
             "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "inputs": "pinned host memory, copied over PCIe every step" if args.host_inputs else "resident in HBM",

@@ -456,6 +456,18 @@ class Engine:
             self._join_ev = [torch.cuda.Event() for _ in range(2)]
         return self._sides
 
+    def _pipe_stream(self):
+        if getattr(self, "_pipe", None) is None:
+            self._pipe = torch.cuda.Stream(device=self.device)
+            self._pipe_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        return self._pipe
+
+    def pipe_join(self):
+        """The caller's stream waits for the pipelined-encoder lane (the closing edge of run()'s "pfork")."""
+        ps = self._pipe_stream()
+        self._pipe_ev[1].record(ps)
+        torch.cuda.current_stream(self.device).wait_event(self._pipe_ev[1])
+
     def run(self, ops, stream=None):
         main = torch.cuda.current_stream(self.device)
         st_main = C.c_void_p(main.cuda_stream) if stream is None else stream
@@ -465,6 +477,15 @@ class Engine:
             if fn is None:
                 kind = args[0]
                 if kind == "tokready":
+                    continue
+                if kind == "pfork":          # pipelined encoder (trainer.FinetuneStep(pipeline_encoder=True)): the next batch's frozen-encoder
+                    ps = self._pipe_stream()         # forward on its own lane beside this batch's decoder side; joined by pipe_join()
+                    self._pipe_ev[0].record(main)
+                    ps.wait_event(self._pipe_ev[0])
+                    st = C.c_void_p(ps.cuda_stream)
+                    continue
+                if kind == "pmain":
+                    st = st_main
                     continue
                 if kind[0] == "x":           # forward overlap of the exemplar CNN with the encoder (overlap_exemplar)
                     if not self.overlap_exemplar:
@@ -964,6 +985,20 @@ class Engine:
             self._linear(ops, hid, b + ".mlp.fc2.weight", x, rows, D, 4 * D, resid=x, **({} if i + 1 == self.depth else prod))
         self._layernorm(ops, x, "norm", latent, rows, D)
         p.enc_ops = len(ops)
+        # Pipelined-encoder variant (trainer.FinetuneStep(pipeline_encoder=True)): the SAME launches reading the next batch's images from a
+        # buffer shared by all plans and leaving its latent in another one, so that they can run on their own lane beside this batch's
+        # decoder side (which keeps reading this plan's `latent`, down to decoder_embed's weight gradient at the end of the backward).
+        # 16-bit modes only: the fp32 parity mode's unfused attention goes through scratch it shares with the decoder's.
+        p.enc_pipe = None
+        if train and code != F32 and self._fused_attention(D // H):
+            pimg = self._shared("pipe_img", B * 3 * self.img * self.img)
+            plat = self._shared("pipe_latent", rows * D, T)
+            head, tail = [], []
+            self._op(head, L.countr_im2patch, pimg.data_ptr(), patches.data_ptr(), B, self.img, self.img, self.patch, code)
+            self._layernorm(tail, x, "norm", plat, rows, D)
+            assert ops[0][0] is L.countr_im2patch and ops[-1][0] is L.countr_layernorm_fwd
+            p.enc_pipe = head + ops[1:-1] + tail
+            p.pipe_img, p.pipe_latent, p.pipe_latent_bytes = pimg, plat, rows * D * (2 if T in HALF_DTYPES else 4)
 
         # ---------------- decoder: models_mae_cross.py:150-199
         Sy = max(S, 1)
@@ -1271,8 +1306,11 @@ class Engine:
     # ------------------------------------------------------------------ execution API
     def _load_inputs(self, p, imgs, boxes, S):
         p.buf["img"].copy_(imgs, non_blocking=True)
+        self._load_boxes(p, boxes, S)
+
+    def _load_boxes(self, p, boxes, S):
         if S > 0:
-            B = imgs.shape[0]
+            B = boxes.shape[0]
             p.buf["boxes"].view(B, S, 3, 64, 64).copy_(boxes[:, :S], non_blocking=True)
 
     def forward(self, imgs, boxes, shot_num, train=False):

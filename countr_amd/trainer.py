@@ -143,6 +143,12 @@ class _GraphStep:
         self._pc = None                # ... the (skip, zero) key of the update that is still pending
         self._pc_hyper = None          # ... and its scalars {lr, bias corrections, grad_scale}
         self._cur_pc = None
+        self.pipe = False              # FinetuneStep(pipeline_encoder=True): the next batch's frozen-encoder forward beside this batch's decoder side
+        self._pipe_mode = "plain"      # ... what the step that load() prepared will run: plain | coldnext | steady | last
+        self._cur_pipe = "plain"       # ... and what the step being executed / captured runs (part of the graph key)
+        self._pipe_ready = None        # ... the images tensor whose latent is waiting in the shared buffer (identity, not contents)
+        self._pipe_next = None
+        self._pipe_gen = -1
         self.grad_scale = 1.0 / self.accum
         # fp16 mode: torch.cuda.amp.GradScaler as the reference uses it (util/misc.py:260-286; GradScaler() defaults: scale 65536, growth
         # x 2 every 2000 clean steps, x 0.5 and NO optimizer step on a non-finite gradient), kept on the device so that the captured step
@@ -226,6 +232,11 @@ class _GraphStep:
         """Gradient buckets that are not all-reduced in this step (nobody has a gradient for them)."""
         return ()
 
+    def _pipe_ok(self):
+        """The pipelined encoder needs the whole step as ONE graph (one rank, or RCCL with captured collectives): the lane is joined
+        inside the graph that forked it."""
+        return self.pipe and self.use_graph and (not self.sync.comm or self.sync.capturable) and self.eng.code != 0
+
     def _adam_sets(self, touched):
         """(skip, zero): buckets the optimizer skips (never had a gradient) / steps with a zero gradient."""
         return (), ()
@@ -296,6 +307,11 @@ class _GraphStep:
             self.amp[4] = float(int(sd.get("growth_interval", 2000)))
         torch.cuda.current_stream(self.eng.device).wait_stream(self.stream)
         return True
+
+    def drop_lookahead(self):
+        """pipeline_encoder: forget the encoder output computed ahead for the next batch (the next step then computes its own).  For
+        callers that must not carry work across a boundary -- a benchmark's timed region, a change of the input pipeline."""
+        self._pipe_ready = None
 
     def flush(self):
         """defer_optimizer mode: apply the optimizer update that is still pending (the last step's), so that the parameters, the AdamW
@@ -563,6 +579,10 @@ class _GraphStep:
             # defer_optimizer: this execution applies the PREVIOUS step's update (beside its frozen-encoder forward) and leaves its own
             # pending; the record it reads therefore carries the previous update's scalars
             defer = self.defer and self.use_graph and (not self.sync.comm or self.sync.capturable)
+            # pipelined encoder: decided by load() (it chose the copies); only in the whole-step forms -- the lane must be joined inside
+            # the graph that forked it
+            pmode = self._pipe_mode
+            assert pmode == "plain" or (self._pipe_ok() and not defer)
             pc = self._pc if defer else None
             if defer:
                 hyper_now = self.pro.hyper.copy() if last else None
@@ -580,16 +600,18 @@ class _GraphStep:
                     # no collective between the phases (one rank): the whole (micro-)step is ONE graph replay -- every graph boundary
                     # costs ~20 us of idle GPU (4 launches per step before) -- and nothing else is launched between two replays
                     def whole(k, phases=phases):
-                        self._cur_pc = k[2]
+                        self._cur_pc, self._cur_pipe = k[2], k[3]
                         self._run_phases_merged(phases)
                         if k[1] is not None:
                             self._phase_c(k[1])
-                    self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), None if defer else ckey, pc))
+                        if k[3] in ("steady", "coldnext"):
+                            self.eng.pipe_join()
+                    self._run_phase("all", whole, (tuple((name, gkey) for name, _fn, gkey in phases), None if defer else ckey, pc, pmode))
                 elif self.use_graph and self.sync.capturable:
                     # RCCL: the bucket all-reduces are captured WITH the phases (graph nodes on the side stream between them), so a
                     # communicating step is one graph replay as well -- no host-issued collective, no graph boundary per phase
                     def whole(k, phases=phases, cskip=cskip, zfill=zfill, apply_now=not defer):
-                        self._cur_pc = k[4]
+                        self._cur_pc, self._cur_pipe = k[4], k[5]
                         for i, (_name, fn, gkey) in enumerate(phases):
                             fn(gkey)
                             if k[1] is not None and i + 1 < len(phases):
@@ -599,9 +621,12 @@ class _GraphStep:
                             self.sync.finish(skip=cskip)
                             if apply_now:
                                 self._phase_c(k[1])
-                    gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else (), pc))
+                        if k[5] in ("steady", "coldnext"):
+                            self.eng.pipe_join()
+                    gk = ("allc", (tuple((name, gkey) for name, _fn, gkey in phases), ckey, cskip if last else (), zfill if last else (), pc, pmode))
                     self._run_captured_comm(gk, whole)
                 else:
+                    self._cur_pipe = "plain"
                     for i, (name, fn, gkey) in enumerate(phases):
                         self._run_phase(name, fn, gkey)
                         if last and i + 1 < len(phases):
@@ -613,10 +638,14 @@ class _GraphStep:
                         self._run_phase("c", self._phase_c, ckey)
             except BaseException:
                 self.pro.resync()
-                self._cur_pc = None
+                self._cur_pc, self._cur_pipe, self._pipe_ready, self._pipe_mode = None, "plain", None, "plain"
                 raise
             self.pro.executed(self.stream)
-            self._cur_pc = None
+            self._cur_pc, self._cur_pipe = None, "plain"
+            # the latent the encoder lane of this step left behind belongs to the images load() was told come next
+            self._pipe_ready = self._pipe_next if pmode in ("steady", "coldnext") else None
+            self._pipe_gen = eng.generation
+            self._pipe_next, self._pipe_mode = None, "plain"
             if defer:
                 self._pc, self._pc_hyper = (ckey, hyper_now) if last else (None, None)
             if pend is not None:
@@ -634,8 +663,18 @@ class _GraphStep:
 
 class FinetuneStep(_GraphStep):
     def __init__(self, model, batch, lr=1e-5, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-8, use_graph=True,
-                 process_group=None, accum_iter=1, per_rank_shot=False, mask_seed=0, defer_optimizer=False):
-        """defer_optimizer: software pipelining across iterations.  The encoder is frozen (models_mae_cross.py:204-205), so the first
+                 process_group=None, accum_iter=1, per_rank_shot=False, mask_seed=0, defer_optimizer=False, pipeline_encoder=False):
+        """pipeline_encoder (round 6): software pipelining of the FROZEN ENCODER across iterations.  forward_encoder runs under no_grad on
+        frozen weights (models_mae_cross.py:203-205), so batch k + 1's encoder forward depends on nothing step k computes: told the next
+        batch's images (load(..., next_imgs=)), step k's graph runs it on a lane of its own beside batch k's decoder forward, loss,
+        backward, all-reduce and AdamW, and leaves the latent in a buffer the next step's prologue copies into place.  The same launches on
+        the same data: losses, counts, gradients and parameters are bit-identical to the unpipelined step (tests/test_trainer_gpu.py);
+        what changes is that the decoder side's many small launches (normalisations, finishers, gaps between dependent kernels) are
+        filled with the encoder's GEMMs instead of leaving the chip idle: 4.30 -> 3.95 ms per step at B = 8.  A step whose images were NOT
+        announced by the previous load() (the first of a loop, any step behind a gap) computes its own encoder forward first; the last
+        step of a loop passes next_imgs=None.  Whole-step graph modes and the 16-bit precisions only (else the plain step runs); takes
+        the place of defer_optimizer (the update then runs at the tail of its own step, beside the encoder lane).
+        defer_optimizer: software pipelining across iterations.  The encoder is frozen (models_mae_cross.py:204-205), so the first
         ~1.3 ms of a step do not depend on the previous step's optimizer update: AdamW + the shadow refresh of step k (~0.1 ms, bandwidth-
         bound) run at the HEAD of step k + 1's graph on the side lane in front of the exemplar CNN, beside the encoder's GEMMs, instead
         of alone at the tail of step k.  Same launches on the same data in the same order per buffer: parameters are bit-identical to the
@@ -652,7 +691,10 @@ class FinetuneStep(_GraphStep):
         EVERY rank -- zero-filled on the ranks without one -- and stepped by every rank, so parameters stay identical."""
         super().__init__(model, batch, lr, weight_decay, betas, eps, use_graph, process_group, accum_iter, mask_seed)
         self.per_rank = bool(per_rank_shot)
-        self.defer = bool(defer_optimizer)
+        self.pipe = bool(pipeline_encoder) and os.environ.get("COUNTR_PIPELINE_ENCODER", "1") != "0"
+        sp = os.environ.get("COUNTR_PIPE_SPLIT", "")          # experiments: "nf,nh" launches of the encoder lane at the step's head / in front of
+        self.pipe_split = tuple(int(x) for x in sp.split(",")) if sp else (10 ** 6, 0)      # the head's backward (rest: in front of the blocks' backward)
+        self.defer = bool(defer_optimizer) and not self.pipe
         self.mse_ws = torch.zeros(self.eng.L.countr_masked_mse_workspace_floats(batch), device=self.eng.device)
         self.gt = torch.zeros((batch, self.eng.img, self.eng.img), device=self.eng.device)
         self.mask = torch.ones((self.eng.img, self.eng.img), device=self.eng.device)
@@ -672,15 +714,43 @@ class FinetuneStep(_GraphStep):
         _lib.check(eng.L.countr_masked_mse_amp(p.buf["out"].data_ptr(), self.gt.data_ptr(), self.mask.data_ptr(), p.buf["dout"].data_ptr(),
                                                sums.data_ptr(), self.mse_ws.data_ptr(), self.B, HW, 1.0,
                                                self.amp.data_ptr() if self.amp is not None else None, eng._stream()), "masked_mse")
+        if self._cur_pipe in ("steady", "coldnext"):
+            eng.run(self._pipe_part(p, 1))
         eng.run(self._lists(p, acc).bwd_head)
 
     def _prologue_mask(self):
         return self.mask
 
+    def _pipe_part(self, p, k):
+        """Part k of the encoder lane's launches: issued (0) at the head of the step, (1) in front of the head's backward, (2) in front of
+        the decoder blocks' backward -- one ordered lane, forked from the main lane at each of the three points.  `pipe_split` = how many
+        launches the first two parts get (the third takes the rest)."""
+        n = len(p.enc_pipe)
+        nf = min(self.pipe_split[0], n)
+        nh = min(self.pipe_split[1], n - nf)
+        lo, hi = ((0, nf), (nf, nf + nh), (nf + nh, n))[k]
+        if hi <= lo:
+            return []
+        mark = lambda *a: (None, a, None)
+        return [mark("pfork")] + p.enc_pipe[lo:hi] + [mark("pmain")]
+
     def _fwd_list(self, p, pc):
         """The forward launch list of plan p; with a pending optimizer update pc (defer_optimizer) the list that applies it first:
         [fork | lane 1: AdamW + shadow refresh, exemplar CNN | lane 0: the frozen encoder | join | decoder_embed ... head].  Everything
         that reads a trainable parameter sits behind the AdamW on lane 1 or behind the join."""
+        mode = self._cur_pipe
+        if mode != "plain":
+            # pipelined encoder: this batch's latent is in place (steady / last: copied from the shared buffer by the prologue; coldnext:
+            # computed here first) and -- steady / coldnext -- the NEXT batch's frozen-encoder forward runs on its own lane until the end
+            # of the step ("pfork" ... eng.pipe_join() behind the optimizer update)
+            assert pc is None
+            cache = p.__dict__.setdefault("_pipe_lists", {})
+            if mode not in cache:
+                mark = lambda *a: (None, a, None)
+                dec = p.fwd[p.enc_ops:]
+                lane = self._pipe_part(p, 0)
+                cache[mode] = {"steady": lane + dec, "last": dec, "coldnext": p.fwd[:p.enc_ops] + lane + dec}[mode]
+            return cache[mode]
         if pc is None:
             return p.fwd_par
         cache = p.__dict__.setdefault("_defer_lists", {})
@@ -725,7 +795,10 @@ class FinetuneStep(_GraphStep):
 
     def _phase_b(self, key):
         S, acc = key
-        self.eng.run(self._lists(self.eng.plan(self.B, S, True), acc).bwd_rest)
+        p = self.eng.plan(self.B, S, True)
+        if self._cur_pipe in ("steady", "coldnext"):
+            self.eng.run(self._pipe_part(p, 2))
+        self.eng.run(self._lists(p, acc).bwd_rest)
 
     def _phase_b2(self, key):
         S, acc = key
@@ -736,6 +809,8 @@ class FinetuneStep(_GraphStep):
         (_a, fa, ka), (_b, _fb, (S, acc)), (_b2, _fb2, (_S2, acc_tok)) = phases
         fa(ka)
         p = self.eng.plan(self.B, S, True)
+        if self._cur_pipe in ("steady", "coldnext"):
+            self.eng.run(self._pipe_part(p, 2))
         rest, tok = self._lists(p, acc), self._lists(p, acc_tok)
         if rest is tok:
             self.eng.run_backward_rest_and_tok(rest)
@@ -751,49 +826,86 @@ class FinetuneStep(_GraphStep):
         return [("a", self._phase_a, (S, acc)), ("b", self._phase_b, (S, acc)), ("b2", self._phase_b2, (S, acc_tok))]
 
     # ------------------------------------------------------------------ public
-    def load(self, imgs, boxes, gt, mask, S):
+    def load(self, imgs, boxes, gt, mask, S, next_imgs=None):
         """Stage one batch (device or host tensors) into the plan's input buffers on the step's stream.  mask: the iteration's loss
         mask [384, 384], or None -- the step then draws Bernoulli(0.8) itself (mask_seed of the constructor).  Dense fp32 device
         tensors of the buffers' shapes are copied by the prologue kernel at the head of step()'s graph: the sources are kept alive
         until then and MUST NOT BE MODIFIED between load() and the return of the following step() (a persistent input buffer refilled in
         place in between would change the batch that trains); a load() that is superseded by another load() drops its references.
-        Anything else is copied here, tensor by tensor."""
+        Anything else is copied here, tensor by tensor.
+        next_imgs (pipeline_encoder): the images of the batch the NEXT load() will bring -- that very tensor object, unmodified until then
+        -- or None (last iteration / unknown).  The next load() recognises it by identity; any other tensor simply gets its encoder
+        forward computed in its own step."""
         cur = torch.cuda.current_stream(self.eng.device)
         self.stream.wait_stream(cur)           # producers of the inputs ran on the caller's stream
-        src = tuple(t for t in (imgs, boxes, gt, mask) if t is not None)
+        pipe = self._pipe_ok()
+        # this batch's latent is already waiting (and nothing has re-planned the engine or re-loaded its weights since it was computed)
+        have = (pipe and self._pipe_ready is not None and imgs is self._pipe_ready and self.eng._ln_checked
+                and self._pipe_gen == self.eng.generation)
+        if not pipe or next_imgs is None or not torch.is_tensor(next_imgs) or tuple(next_imgs.shape) != (self.B, 3, self.eng.img, self.eng.img):
+            next_imgs = None
+        mode = ("steady" if next_imgs is not None else "last") if have else ("coldnext" if next_imgs is not None else "plain")
+        src = tuple(t for t in (imgs, boxes, gt, mask, next_imgs) if t is not None)
         self._draw_mask = mask is None
-        if mask is None:
-            imgs, boxes, gt = self._to_device((imgs, boxes, gt))
-        else:
-            imgs, boxes, gt, mask = self._to_device((imgs, boxes, gt, mask))
+        raw_imgs = imgs
+        staged = self._to_device(tuple(t for t in ((None if have else imgs), boxes, gt, mask, next_imgs) if t is not None))
+        it_ = iter(staged)
+        imgs = None if have else next(it_)
+        boxes, gt = next(it_), next(it_)
+        mask = next(it_) if mask is not None else None
+        nxt = next(it_) if next_imgs is not None else None
         with torch.cuda.stream(self.stream):
-            self.eng.check_ln_fold(imgs)             # (first batch behind a weight load only: the LayerNorm-fold guard, engine.py)
+            if not have:
+                self.eng.check_ln_fold(imgs)         # (first batch behind a weight load only: the LayerNorm-fold guard, engine.py)
             p = self.eng.plan(self.B, S, True)
+            if mode != "plain" and p.enc_pipe is None:
+                mode, nxt, next_imgs = "plain", None, None
+                assert not have
             self._pending = None
-            if not self._load_fused(p, imgs, boxes, gt, mask, S, keep=src):
-                self.eng._load_inputs(p, imgs, boxes, S)
+            self._pipe_mode, self._pipe_next = mode, next_imgs
+            if not self._load_fused(p, imgs, boxes, gt, mask, S, keep=src, nxt=nxt, have=have):
+                if not have:
+                    self.eng._load_inputs(p, imgs, boxes, S)
+                elif S > 0:
+                    self.eng._load_boxes(p, boxes, S)
                 self.gt.copy_(gt, non_blocking=True)
                 if mask is not None:
                     self.mask.copy_(mask, non_blocking=True)
+                if nxt is not None:
+                    p.pipe_img[:nxt.numel()].view(nxt.shape).copy_(nxt, non_blocking=True)
+                if have:
+                    n = p.buf["latent"].numel()
+                    p.buf["latent"].view(-1).copy_(p.pipe_latent[:n], non_blocking=True)
                 self._staging_consumed()
                 for t in src:                          # their memory must not be recycled before our copies have run
                     if t.is_cuda:
                         t.record_stream(self.stream)
+        del raw_imgs
 
-    def _load_fused(self, p, imgs, boxes, gt, mask, S, keep=()):
+    def _load_fused(self, p, imgs, boxes, gt, mask, S, keep=(), nxt=None, have=False):
         """All staging copies of a batch by the step's prologue kernel when every source is a dense fp32 device tensor of the
-        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices)."""
-        pairs = [(imgs, p.buf["img"]), (gt, self.gt)] + ([(mask, self.mask)] if mask is not None else [])
+        destination's shape; otherwise False (the caller copies tensor by tensor: dtype conversion, strided exemplar slices).
+        pipeline_encoder: `have` -- the batch's latent comes out of the shared buffer instead of its images going in; `nxt` -- the next
+        batch's images go to the encoder lane's input buffer (at most six copies per record: gt, mask, boxes, + two of these)."""
+        pairs = ([] if have else [(imgs, p.buf["img"])]) + [(gt, self.gt)] + ([(mask, self.mask)] if mask is not None else [])
         if S > 0:
             if boxes.dim() != 5 or boxes.shape[1] != S:
                 return False
             pairs.append((boxes, p.buf["boxes"]))
-        for src, dst in pairs:
+        for src, dst in pairs + ([(nxt, p.buf["img"])] if nxt is not None else []):      # (the lane's input buffer has the shape of `img`)
             if (not torch.is_tensor(src) or not src.is_cuda or src.dtype != dst.dtype or not src.is_contiguous() or src.numel() != dst.numel()
                     or (src.numel() * src.element_size()) % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16):
                 return False
-        self._pending = ([s_.data_ptr() for s_, _ in pairs], [d.data_ptr() for _, d in pairs], [s_.numel() * s_.element_size() for s_, _ in pairs],
-                         [s_ for s_, _ in pairs] + [t for t in keep if torch.is_tensor(t)])
+        srcs = [s_.data_ptr() for s_, _ in pairs]
+        dsts = [d.data_ptr() for _, d in pairs]
+        nbytes = [s_.numel() * s_.element_size() for s_, _ in pairs]
+        if nxt is not None:
+            srcs.append(nxt.data_ptr()); dsts.append(p.pipe_img.data_ptr()); nbytes.append(nxt.numel() * nxt.element_size())
+        if have:
+            srcs.append(p.pipe_latent.data_ptr()); dsts.append(p.buf["latent"].data_ptr()); nbytes.append(p.pipe_latent_bytes)
+        if len(srcs) > 6 or any(b % 16 for b in nbytes) or any(a % 16 for a in srcs + dsts):
+            return False
+        self._pending = (srcs, dsts, nbytes, [s_ for s_, _ in pairs] + [t for t in keep if torch.is_tensor(t)] + ([nxt] if nxt is not None else []))
         return True
 
     def step(self, S, lr=None, shots_all=None):

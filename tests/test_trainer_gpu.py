@@ -555,3 +555,77 @@ def test_fp16_scaler_state_roundtrips_through_the_checkpoint_and_gradscaler():
         step2.load_scaler_state(dict(st, growth_factor=3.0))
     mb, _ = make("bf16")
     assert FinetuneStep(mb, batch=2, use_graph=False).scaler_state() is None
+
+
+@pytest.mark.parametrize("precision,accum", [("bf16", 1), ("fp16", 1), ("bf16", 2)])
+def test_pipelined_encoder_is_bit_identical(precision, accum):
+    """FinetuneStep(pipeline_encoder=True): the frozen-encoder forward of batch k + 1 (models_mae_cross.py:203-205: no_grad, frozen
+    weights -- nothing in it depends on step k) runs on its own lane of step k's graph beside batch k's decoder forward, loss, backward
+    and AdamW; the next step's prologue copies the latent into place.  Same launches, same data: every step's loss / counts, every
+    parameter, both AdamW moments and the gradient norm are BIT-identical to the plain step -- over a shot schedule that changes the plan
+    (and with it the encoder's scratch buffers) from step to step, with accumulation windows, with a step whose images were NOT announced
+    (it computes its own encoder forward: 'coldnext'), with an announced batch that never comes (the waiting latent is dropped), and with
+    the last step announcing nothing.  The modes the steps ran in are checked too, so the test cannot pass by never pipelining."""
+    from countr_amd.trainer import FinetuneStep
+    sched = [3, 0, 3, 1, 0, 3, 3, 2, 1]
+    batches = []
+    for it in range(len(sched)):
+        imgs, boxes, gt, _mask = W.make_inputs(batch=2, shots=3, seed=400 + it)
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt)))
+    decoy = batches[0][0].clone()
+    res = {}
+    for pipe in (False, True):
+        m, sd = make(precision)
+        step = FinetuneStep(m, batch=2, lr=1e-3, eps=1e-4, use_graph=True, accum_iter=accum, pipeline_encoder=pipe, mask_seed=5)
+        sums, modes = [], []
+        for it, S in enumerate(sched):
+            imgs, boxes, gt = batches[it]
+            if it == 4:
+                nxt = decoy                           # announces a batch that never comes: step 5 must NOT use that latent
+            elif it == 6 or it + 1 == len(sched):
+                nxt = None                            # a gap: step 7 computes its own encoder forward; the last step announces nothing
+            else:
+                nxt = batches[it + 1][0]
+            step.load(imgs, boxes, gt, None, S, next_imgs=nxt)
+            modes.append(step._pipe_mode)
+            sums.append(step.step(S, lr=1e-3 * (1 + 0.1 * it)).clone())
+        gn = step.grad_norm().clone()
+        torch.cuda.synchronize()
+        res[pipe] = (torch.stack(sums), {k: p.detach().clone() for k, p in m.named_parameters()}, step.eng.M.clone(), step.eng.V.clone(), gn, modes)
+    a, b = res[False], res[True]
+    assert a[5] == ["plain"] * len(sched)
+    assert b[5] == ["coldnext", "steady", "steady", "steady", "steady", "coldnext", "last", "coldnext", "last"], b[5]
+    assert torch.equal(a[0], b[0]), (a[0] - b[0]).abs().max()
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    moved = sum(float((a[1][k].cpu() - torch.from_numpy(sd[k])).abs().max()) > 0 for k in a[1] if k.startswith(("decoder", "decode_head", "shot_token")) and "pos_embed" not in k)
+    assert moved >= 40
+
+
+def test_pipelined_encoder_falls_back_where_it_cannot_run():
+    """fp32 parity mode (its unfused attention shares scratch with the decoder's) and eager steps run the plain step whatever is
+    announced; drop_lookahead() makes the next step compute its own encoder forward."""
+    from countr_amd.trainer import FinetuneStep
+    imgs, boxes, gt, _mask = W.make_inputs(batch=2, shots=3, seed=410)
+    t = tuple(torch.from_numpy(a).cuda() for a in (imgs, boxes, gt))
+    for precision, graph in (("fp32", True), ("bf16", False)):
+        m, _sd = make(precision)
+        step = FinetuneStep(m, batch=2, use_graph=graph, pipeline_encoder=True)
+        step.load(*t, None, 3, next_imgs=t[0])
+        assert step._pipe_mode == "plain"
+        step.step(3)
+    m, _sd = make("bf16")
+    step = FinetuneStep(m, batch=2, use_graph=True, pipeline_encoder=True)
+    step.load(*t, None, 3, next_imgs=t[0])
+    assert step._pipe_mode == "coldnext"
+    a = step.step(3).clone()
+    step.drop_lookahead()
+    step.load(*t, None, 3, next_imgs=t[0])
+    assert step._pipe_mode == "coldnext"
+    step.step(3)
+    step.load(*t, None, 3)
+    assert step._pipe_mode == "last"
+    step.step(3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
