@@ -1330,6 +1330,11 @@ class Engine:
         countr_amd.inference writes the sliding windows there directly, after its own check_ln_fold call).  Returns the output buffer
         [B, H, W]."""
         p = self.plan(B, int(shot_num), False)
+        if os.environ.get("COUNTR_INFER_PIPE_PROTO") == "1":      # TIMING PROTOTYPE ONLY (wrong data flow)
+            mark = lambda *a: (None, a, None)
+            self.run([mark("pfork")] + p.fwd[:p.enc_ops] + [mark("pmain")] + p.fwd[p.enc_ops:])
+            self.pipe_join()
+            return p.buf["out"]
         self.run(p.fwd_par)
         return p.buf["out"]
 

@@ -234,7 +234,12 @@ def test_bench_rccl_one_rank():
     r = run_retry(cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1"))
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["parity_checked"] is True
-    assert j["config"]["optimizer_update"].startswith("deferred")        # captured collectives + the deferred optimizer: one graph per step
+    # captured collectives: one graph per step -- with the NEXT batch's frozen-encoder forward on its own lane of it (round 6; the
+    # optimizer update then runs at the tail of its step, beside that lane; COUNTR_PIPELINE_ENCODER=0: the deferred update of round 5)
+    assert j["config"]["encoder_pipelining"].startswith("on") and j["config"]["optimizer_update"] == "at the tail of its step"
+    r = run_retry(cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", COUNTR_FORCE_COMM="1", COUNTR_BENCH_INIT_PG="1", COUNTR_PIPELINE_ENCODER="0"))
+    j0 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j0["config"]["encoder_pipelining"] == "off" and j0["config"]["optimizer_update"].startswith("deferred") and j0["parity_checked"] is True
     assert j["multi_gpu_safe_mode"]["ms_per_step_host_issued_first"] > 0  # the host-issued form was measured first (the watchdog's line)
 
 
