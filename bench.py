@@ -428,18 +428,26 @@ def time_infer(args, world, rank, dev, steps, warmup):
     frames = wide_frames(8, 672, dev, seed=rank)
     empty = [torch.zeros(1, 0, device=dev)] * len(frames)
 
-    def one():
-        _dms, sums = inference.density_maps(model, frames, empty, 0, max_batch=32, return_sums=True)
-        return torch.stack(sums) / 60
-    for _ in range(max(warmup, 2)):
-        one()
+    def run(n):
+        """n passes over the 8 frames, as a video stream would bring them: inference.density_maps_stream runs pass k + 1's frozen-encoder
+        forward beside pass k's decoder / density head (bit-identical maps).  The first pass of a run computes its own encoder forward and
+        the last one computes nothing ahead: n passes = n encoder forwards + n decoder / head passes + n blends, all inside the run."""
+        cnt = None
+        if args.no_pipeline:
+            for _ in range(n):
+                _dms, sums = inference.density_maps(model, frames, empty, 0, max_batch=32, return_sums=True)
+                cnt = torch.stack(sums) / 60
+            return cnt
+        for _dms, sums in inference.density_maps_stream(model, ((frames, empty) for _ in range(n)), 0, max_batch=32, return_sums=True):
+            cnt = torch.stack(sums) / 60
+        return cnt
+    run(max(warmup, 3))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        cnt = one()
+    cnt = run(steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -462,7 +470,8 @@ def bench_infer(args, world, rank, dev):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "zero-shot inference ViT-B/16 (mae_vit_base_patch16), 8 frames x 4 windows = batch 32 per GPU, "
-                                   "forward + sliding-window blend + counts", "global_batch": world * 32, "parallelism": "replicas%d" % world},
+                                   "forward + sliding-window blend + counts", "global_batch": world * 32, "parallelism": "replicas%d" % world,
+                       "encoder_pipelining": "off" if args.no_pipeline else "on: pass k + 1's frozen-encoder forward beside pass k's decoder / density head (inference.density_maps_stream; bit-identical maps); every timed run computes all of its own encoder forwards"},
             "windows_per_sec": 4 * ips, "mean_count": mean_count, "fwd_tflops": 180.89e9 * 4 * ips / 1e12}))
     if dist.is_initialized():
         dist.barrier()

@@ -462,6 +462,15 @@ class Engine:
             self._pipe_ev = [torch.cuda.Event(), torch.cuda.Event()]
         return self._pipe
 
+    def pipe_claim(self):
+        """Whoever launches the encoder lane owns what it leaves in the shared pipe_latent buffer until the next launch of the lane (by a
+        training step or an inference stream on this engine): the returned token is compared by identity before the latent is used."""
+        self._pipe_token = object()
+        return self._pipe_token
+
+    def pipe_owner(self, token):
+        return token is not None and getattr(self, "_pipe_token", None) is token
+
     def pipe_join(self):
         """The caller's stream waits for the pipelined-encoder lane (the closing edge of run()'s "pfork")."""
         ps = self._pipe_stream()
@@ -985,12 +994,12 @@ class Engine:
             self._linear(ops, hid, b + ".mlp.fc2.weight", x, rows, D, 4 * D, resid=x, **({} if i + 1 == self.depth else prod))
         self._layernorm(ops, x, "norm", latent, rows, D)
         p.enc_ops = len(ops)
-        # Pipelined-encoder variant (trainer.FinetuneStep(pipeline_encoder=True)): the SAME launches reading the next batch's images from a
+        # Pipelined-encoder variant (trainer.FinetuneStep(pipeline_encoder=True); inference.density_maps_stream): the SAME launches reading the next batch's images from a
         # buffer shared by all plans and leaving its latent in another one, so that they can run on their own lane beside this batch's
         # decoder side (which keeps reading this plan's `latent`, down to decoder_embed's weight gradient at the end of the backward).
         # 16-bit modes only: the fp32 parity mode's unfused attention goes through scratch it shares with the decoder's.
         p.enc_pipe = None
-        if train and code != F32 and self._fused_attention(D // H):
+        if code != F32 and self._fused_attention(D // H):
             pimg = self._shared("pipe_img", B * 3 * self.img * self.img)
             plat = self._shared("pipe_latent", rows * D, T)
             head, tail = [], []
@@ -1330,12 +1339,30 @@ class Engine:
         countr_amd.inference writes the sliding windows there directly, after its own check_ln_fold call).  Returns the output buffer
         [B, H, W]."""
         p = self.plan(B, int(shot_num), False)
-        if os.environ.get("COUNTR_INFER_PIPE_PROTO") == "1":      # TIMING PROTOTYPE ONLY (wrong data flow)
-            mark = lambda *a: (None, a, None)
-            self.run([mark("pfork")] + p.fwd[:p.enc_ops] + [mark("pmain")] + p.fwd[p.enc_ops:])
-            self.pipe_join()
-            return p.buf["out"]
         self.run(p.fwd_par)
+        return p.buf["out"]
+
+    def forward_loaded_pipelined(self, B, shot_num, have, ahead):
+        """forward_loaded with the frozen encoder pipelined across calls (inference has no trainable side at all: every forward's encoder
+        is independent of every other forward).  `ahead`: the NEXT batch's windows are already in the plan's p.pipe_img -- their encoder
+        forward runs on a lane of its own beside this batch's decoder / density head and leaves its latent in p.pipe_latent.  `have`:
+        this batch's latent is waiting there (the previous call ran with ahead=True for it) -- it is copied into place and the encoder
+        is not run again.  Same launches on the same data as forward_loaded: bit-identical maps (tests/test_inference_gpu.py)."""
+        p = self.plan(B, int(shot_num), False)
+        if p.enc_pipe is None:
+            raise _lib.CountrError("the pipelined forward needs a 16-bit precision and the fused attention kernel")
+        if have:
+            n = p.buf["latent"].numel()
+            p.buf["latent"].view(-1).copy_(p.pipe_latent[:n], non_blocking=True)
+        key = (bool(have), bool(ahead))
+        cache = p.__dict__.setdefault("_pipe_fwd", {})
+        if key not in cache:
+            mark = lambda *a: (None, a, None)
+            lane = ([mark("pfork")] + p.enc_pipe + [mark("pmain")]) if ahead else []
+            cache[key] = ([] if have else p.fwd[:p.enc_ops]) + lane + p.fwd[p.enc_ops:]
+        self.run(cache[key])
+        if ahead:
+            self.pipe_join()
         return p.buf["out"]
 
     def backward(self, B, shot_num, dout):

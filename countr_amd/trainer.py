@@ -149,6 +149,7 @@ class _GraphStep:
         self._pipe_ready = None        # ... the images tensor whose latent is waiting in the shared buffer (identity, not contents)
         self._pipe_next = None
         self._pipe_gen = -1
+        self._pipe_tok = None
         self.grad_scale = 1.0 / self.accum
         # fp16 mode: torch.cuda.amp.GradScaler as the reference uses it (util/misc.py:260-286; GradScaler() defaults: scale 65536, growth
         # x 2 every 2000 clean steps, x 0.5 and NO optimizer step on a non-finite gradient), kept on the device so that the captured step
@@ -644,6 +645,7 @@ class _GraphStep:
             self._cur_pc, self._cur_pipe = None, "plain"
             # the latent the encoder lane of this step left behind belongs to the images load() was told come next
             self._pipe_ready = self._pipe_next if pmode in ("steady", "coldnext") else None
+            self._pipe_tok = eng.pipe_claim() if self._pipe_ready is not None else None
             self._pipe_gen = eng.generation
             self._pipe_next, self._pipe_mode = None, "plain"
             if defer:
@@ -841,7 +843,7 @@ class FinetuneStep(_GraphStep):
         pipe = self._pipe_ok()
         # this batch's latent is already waiting (and nothing has re-planned the engine or re-loaded its weights since it was computed)
         have = (pipe and self._pipe_ready is not None and imgs is self._pipe_ready and self.eng._ln_checked
-                and self._pipe_gen == self.eng.generation)
+                and self._pipe_gen == self.eng.generation and self.eng.pipe_owner(self._pipe_tok))
         if not pipe or next_imgs is None or not torch.is_tensor(next_imgs) or tuple(next_imgs.shape) != (self.B, 3, self.eng.img, self.eng.img):
             next_imgs = None
         mode = ("steady" if next_imgs is not None else "last") if have else ("coldnext" if next_imgs is not None else "plain")

@@ -197,3 +197,55 @@ def test_panorama_with_more_than_16_windows(fp32_model):
     # 16 windows (width 2304) still go through the window kernels
     img16 = img[:, :, :, :2304].contiguous()
     assert len(inference.window_starts(2304)) == 16 and inference._native_maps(m, [img16], [empty], 0, 32, False) is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,S", [("bf16", 0), ("fp16", 3), ("fp32", 0)])
+def test_stream_with_pipelined_encoder_is_bit_identical(precision, S):
+    """inference.density_maps_stream: while group k's decoder and density head run, group k + 1's windows are already cut and their
+    frozen-encoder forward runs on a lane of its own; group k + 1 starts at decoder_embed (every forward is independent:
+    models_mae_cross.py:201-207 under no_grad).  Same launches, same data: maps and per-image sums BIT-identical to one density_maps
+    call per group -- over groups of different content, a group with another forward batch size in the middle (no look-ahead across
+    it), a group that does not fit the window kernels (17 window positions: torch path), zero-shot and with exemplars.  fp32 has no
+    pipelined form (its unfused attention shares scratch): the stream must simply equal the plain calls.  The engine's forward calls
+    are recorded, so the test cannot pass by never pipelining."""
+    import models_mae_cross
+    from countr_amd import inference
+    m = models_mae_cross.mae_vit_base_patch16(precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict("mae_vit_base_patch16", seed=0).items()})
+    m.to("cuda").eval()
+    empty = torch.zeros(1, 0, device="cuda")
+
+    def group(seed, n, width):
+        imgs, bxs = [], []
+        for k in range(n):
+            img, bx, _pos = W.make_wide_inputs(seed + k, width, max(S, 1))
+            imgs.append(torch.from_numpy(img).cuda())
+            bxs.append(torch.from_numpy(bx).cuda() if S else empty)
+        return imgs, bxs
+    pano = torch.from_numpy(np.random.RandomState(9).uniform(0, 1, size=(1, 3, 384, 384 + 128 * 16)).astype(np.float32)).cuda()
+    _i, pbx, _p = W.make_wide_inputs(1, 672, max(S, 1))
+    groups = [group(500, 4, 672), group(510, 4, 672), group(520, 4, 672), group(530, 2, 672), group(540, 4, 672), group(550, 4, 672),
+              ([pano], [torch.from_numpy(pbx).cuda() if S else empty]), group(560, 4, 672), group(570, 4, 672)]
+    ref = [inference.density_maps(m, g[0], g[1], S, max_batch=32, return_sums=True) for g in groups]
+    eng = m._engine()
+    calls = []
+    orig_p, orig = eng.forward_loaded_pipelined, eng.forward_loaded
+    eng.forward_loaded_pipelined = lambda B, s_, have, ahead: (calls.append((B, have, ahead)), orig_p(B, s_, have, ahead))[1]
+    eng.forward_loaded = lambda B, s_: (calls.append((B, None, None)), orig(B, s_))[1]
+    try:
+        got = list(inference.density_maps_stream(m, iter(groups), S, max_batch=32, return_sums=True))
+    finally:
+        eng.forward_loaded_pipelined, eng.forward_loaded = orig_p, orig
+    assert len(got) == len(ref)
+    for (dms, sums), (rd, rs) in zip(got, ref):
+        assert len(dms) == len(rd)
+        for a, b, x, y in zip(dms, rd, sums, rs):
+            assert torch.equal(a, b) and torch.equal(x, y)
+    if precision == "fp32":
+        assert all(h is None for _B, h, _a in calls)
+    else:
+        # 16 windows | 16 | 16 (no look-ahead: the next group is 8 windows) | 8 on its own | 16 | 16 (next: the panorama, torch path) |
+        # the panorama's 17 single... forwards go through model.forward, not these two entry points | 16 | 16
+        assert calls == [(16, False, True), (16, True, True), (16, True, False), (8, None, None), (16, False, True), (16, True, False),
+                         (16, False, True), (16, True, False)], calls
