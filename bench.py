@@ -791,7 +791,9 @@ def main():
             "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "inputs": "pinned host memory, copied over PCIe every step" if args.host_inputs else "resident in HBM",
             "step_tflops": GF_STEP_PER_IMG * ips / 1e12,
-            "timed_region": "per step (ONE hipGraph replay at N = 1): device-to-device staging of a batch + fresh loss mask + fwd + loss + decoder bwd + grad all-reduce + AdamW",
+            "timed_region": ("per step (ONE hipGraph replay at N = 1): device-to-device staging of a batch + fresh loss mask + fwd + loss + decoder bwd + "
+                             "grad all-reduce + AdamW" + ("; encoder_pipelining: the graph of step k holds batch k + 1's frozen-encoder forward (own lane) "
+                             "beside batch k's decoder side -- a timed block of K steps holds exactly K encoder forwards" if step._pipe_ok() else "")),
             "shot_mix": {"images_per_sec": world * B * args.steps / dt_mix, "ms_per_step": 1e3 * dt_mix / args.steps,
                          "shot_nums": "uniform 0..3 per step (%s)" % "".join(str(x) for x in mix[:32])},
         }

@@ -2,7 +2,7 @@
 # End-of-round evidence from ONE box on HEAD (run through gpurun): bash tools/collect_round.sh [tag]  ->  gpurun_out/<tag>_*
 # bench lines of the three single-GPU workloads, kernel stats + per-step breakdown + one step's launch sequence of the headline step,
 # the counter passes over the eager step (tools/pmc_step.sh), per-step breakdowns of pretraining / inference, the 256x256 kernel's stamps.
-tag=${1:-r5}
+tag=${1:-r6}
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
