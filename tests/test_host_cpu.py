@@ -219,3 +219,32 @@ def test_checkpoint_scaler_entry_is_a_gradscaler_state_or_absent(tmp_path):
     # the file's entry is what torch's own GradScaler writes (same key set)
     ref = torch.amp.GradScaler("cpu", enabled=True)
     assert set(ref.state_dict()) == set(st)
+
+
+def test_density_maps_stream_looks_one_group_ahead(monkeypatch):
+    """Host logic of inference.density_maps_stream (no GPU): group k is handed group k + 1's images as `ahead`, the ownership token a
+    call returns for the encoder forward it ran ahead is handed to the next call as `have` (and only to the next), results come in
+    order, a group the native path refuses goes to density_maps, and an iterator is read exactly one group ahead."""
+    from countr_amd import inference
+    seen, pulled = [], []
+
+    def fake_native(model, images, boxes, shot_num, max_batch, want_sums, have=None, ahead=None, flags=None):
+        seen.append((images, have, ahead))
+        if images == "torchpath":
+            return None
+        flags["ahead"] = ("tok", images) if ahead not in (None, "torchpath") else None
+        return "res:" + images
+
+    monkeypatch.setattr(inference, "_native_maps", fake_native)
+    monkeypatch.setattr(inference, "density_maps", lambda model, images, boxes, S, mb, rs=False: "torch:" + images)
+
+    def gen():
+        for name in ("a", "b", "torchpath", "c", "d"):
+            pulled.append(name)
+            yield name, None
+    out = []
+    for r in inference.density_maps_stream(None, gen(), 0):
+        out.append((r, list(pulled)))
+    assert [r for r, _p in out] == ["res:a", "res:b", "torch:torchpath", "res:c", "res:d"]
+    assert out[0][1] == ["a", "b"] and out[1][1] == ["a", "b", "torchpath"]          # one group of look-ahead, no more
+    assert seen == [("a", None, "b"), ("b", ("tok", "a"), "torchpath"), ("torchpath", None, "c"), ("c", None, "d"), ("d", ("tok", "c"), None)]
