@@ -206,7 +206,7 @@ def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=Tr
     b2b = e0.elapsed_time(e1) * 1e3 / iters
     achieved = ATT_FLOP_PER_IMG_LAYER * batch / (us * 1e-6)
     traffic, traffic_source = None, None
-    for rnd in ("r5", "r4", "r3", "r2"):   # HBM/fabric bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md), NOT this run
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):   # HBM/fabric bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md), NOT this run
         try:
             path = os.path.join(ROOT, "profiles", "%s_attention_traffic.json" % rnd)
             t = json.load(open(path))
@@ -233,7 +233,10 @@ def attention_roofline(model, batch, iters=20, instep_passes=6, shot=3, train=Tr
                             "26.9 % busy, 33.7 % of wave cycles waiting, traffic 1.005 x algorithmic): a persistent form has nothing to amortise "
                             "at B = 8 (1728 strips for 2048 wave slots: one strip per wave), and at B = 32 the launch already is 3.75 rounds of "
                             "workgroups with two per CU in different phases -- the overlap a persistent loop would schedule -- and reaches "
-                            "roofline_b32.frac = 0.25 against the loop's own 0.33 (DESIGN.md section 5).",
+                            "roofline_b32.frac = 0.25 against the loop's own 0.33 (DESIGN.md section 5).  Round 6: the running row max left the loop (the "
+                            "first key tile's max stays the softmax reference; overflow is detected at the end and such a workgroup reruns on the "
+                            "exact loop) -- the microbenchmark's 1611 -> 1398 cycles per step; same-box 17.2 -> 16.4 us stand-alone, 14.7 -> 14.3 in "
+                            "the step (profiles/r6_attention_pmc.txt: 27.5 % matrix-busy); the 40 % of a workgroup's life outside the loop stays.",
             "kernel": "fa_fwd_pipe_kernel<64>: encoder attention core (QK^T, softmax, PV), one launch per layer",
             "us_per_launch": us,
             "timing": "in-step, HIP events on the launch stream, %d encoder launches x %d eager forward passes: median of [attention + next launch] "
@@ -335,7 +338,7 @@ def family_breakdown(model, step, batch, passes=5):
         alg[f] += bytes_a + bytes_b + bytes_c + extra
         nl[f] += 1
     traffic, tpath = None, None
-    for rnd in ("r5", "r4"):
+    for rnd in ("r6", "r5", "r4"):
         try:
             tpath = os.path.join(ROOT, "profiles", "%s_family_traffic.json" % rnd)
             traffic = json.load(open(tpath))
