@@ -110,10 +110,12 @@ def check_supported(cfg, img_size, precision="bf16"):
     """What the gfx950 kernels cover.  The CounTR shapes proper -- a patch grid that tiles the image, head_dim 32 / 64 (the fused
     attention kernels), a token count that is a multiple of 8 -- run in every precision, forward and backward.  mae_vit_huge_patch14
     (models_mae_cross.py:235-239: patch 14 does not divide 384 -> timm's PatchEmbed conv drops the last 6 pixels and leaves 27 x 27 = 729
-    tokens; head_dim 1280 / 16 = 80; the density head turns 27 into a 432 x 432 map) runs FORWARD-ONLY in the fp32 parity mode, as the
-    reference's own forward does (its training loss compares the map with a 384 x 384 ground truth and cannot run: FSC_finetune_cross.py:
-    294): the generic fp32 GEMM path takes head_dim 80 and K = 588, the score / probability matrices are padded to 736 columns
-    (countr_softmax_fwd_ld).  Returns True for such a forward-only configuration."""
+    tokens; head_dim 1280 / 16 = 80; the density head turns 27 into a 432 x 432 map) runs FORWARD-ONLY, as the reference's own forward
+    does (its training loss compares the map with a 384 x 384 ground truth and cannot run: FSC_finetune_cross.py:294), in every
+    precision: head_dim 80 goes through the batched-GEMM attention (score / probability matrices padded to 736 columns,
+    countr_softmax_fwd_ld), the patch matrix with K = 588 (rows of 1176 bytes in 16-bit storage: no 16-byte chunks) stays an fp32
+    product in the 16-bit modes too (0.6 % of the forward), the 729-token decoder runs the fused dh = 32 kernel's ragged form; no
+    LayerNorm folding / pre-scaled q (both are packed for the head_dim-64 encoder).  Returns True for such a forward-only configuration."""
     patch, D, _depth, H, Dd, _dd, Hd = cfg
     bad, special = [], False
     if img_size < patch:
@@ -127,9 +129,6 @@ def check_supported(cfg, img_size, precision="bf16"):
             bad.append("%s head_dim %s (embed_dim %d / %d heads) is not a multiple of 4" % (what, dim / heads, dim, heads))
         elif dim // heads not in (32, 64):
             special = True
-    if special and precision != "fp32" and not bad:
-        bad.append("patch size %d on a %d-pixel input / head_dim %d: this configuration (mae_vit_huge_patch14) runs in the fp32 mode only "
-                   "(precision='fp32'; the 16-bit kernels need head_dim 32 or 64 and a patch grid that tiles the image)" % (patch, img_size, D // max(H, 1)))
     if bad:
         raise _lib.CountrError("this model configuration is not supported by the gfx950 kernels: " + "; ".join(bad))
     return special
@@ -181,7 +180,7 @@ class Engine:
         _lib.check(self.L.countr_init(self.device.index), "countr_init")
         self.cfg = cfg
         self.patch, self.D, self.depth, self.H, self.Dd, self.ddepth, self.Hd = cfg
-        self.forward_only = check_supported(cfg, img_size, precision)      # (mae_vit_huge_patch14: fp32 forward, like the reference's)
+        self.forward_only = check_supported(cfg, img_size, precision)      # (mae_vit_huge_patch14: forward only, like the reference's)
         self.img = img_size
         self.grid = img_size // self.patch
         self.N = self.grid * self.grid
@@ -242,7 +241,7 @@ class Engine:
         # the proj / fc2 / patch-embed epilogues emit the bf16 operand + 64-column row partials, the qkv / fc1 epilogues apply mean and
         # rstd -- _pack_prescaled_q, _build): 24 LayerNorm launches and their 0.5 GB of traffic per step gone.  COUNTR_LN_FOLD=0 disables.
         self.ln_fold = (self.FROZEN_ENCODER and self.half and self.D % 128 == 0 and os.environ.get("COUNTR_LN_FOLD", "1") != "0"
-                        and os.environ.get("COUNTR_LEAN", "1") != "0")
+                        and os.environ.get("COUNTR_LEAN", "1") != "0" and not self.forward_only)
         self.fc1_bias_pre = self.ln_c_qkv = self.ln_c_fc1 = None
         self._ln_checked = False     # check_ln_fold() has looked at the activations this weight set produces
         self.ln_fold_ratio = None    # ... and this is the largest |mean| / sigma it saw at a folded LayerNorm's input
@@ -956,7 +955,10 @@ class Engine:
 
         # ---------------- encoder (no grad): models_mae_cross.py:136-148
         img = A("img", (B, 3, self.img, self.img), f32)
-        patches = A("patches", (rows, 3 * self.patch * self.patch), T)
+        # (a patch row that is not a whole number of 16-byte chunks in 16-bit storage -- patch 14: K = 588 -- keeps the patch matrix and
+        # its product in fp32: mae_vit_huge_patch14's forward-only configuration)
+        pe_code = code if (3 * self.patch * self.patch) % 8 == 0 else F32
+        patches = A("patches", (rows, 3 * self.patch * self.patch), T if pe_code == code else f32)
         x = A("x", (rows, D), f32)
         xn = A("xn", (rows, D), T)
         pad = self.Np - N       # rows behind the last image's tokens that the padded attention products read (zeros, never written)
@@ -966,7 +968,7 @@ class Engine:
         att = A("att", (rows, D), T)
         hid = A("hid", (rows, 4 * D), T)
         latent = A("latent", (rows, D), T)
-        self._op(ops, L.countr_im2patch, img.data_ptr(), patches.data_ptr(), B, self.img, self.img, self.patch, code)
+        self._op(ops, L.countr_im2patch, img.data_ptr(), patches.data_ptr(), B, self.img, self.img, self.patch, pe_code)
         Kp = 3 * self.patch * self.patch
         pre_q, fold = self.prescale_q, self.ln_fold
         if (pre_q or fold) and self.qkv_bias_pre is None:
@@ -976,7 +978,8 @@ class Engine:
         lnst = A("lnstats", (rows, D // 64, 2), f32) if fold else None
         prod = dict(ln_xcopy=xn.data_ptr(), ln_stats_out=lnst.data_ptr()) if fold else {}
         cons = (lambda cvec: dict(ln_stats=lnst.data_ptr(), ln_colsum=cvec.data_ptr(), ln_nblk=D // 64, ln_eps=self.ln_eps)) if fold else (lambda cvec: {})
-        self._gemm(ops, code, OP_ROW, OP_ROW, A=patches.data_ptr(), B=self._wp("patch_embed.proj.weight"), C=x.data_ptr(),
+        self._gemm(ops, pe_code, OP_ROW, OP_ROW, A=patches.data_ptr(),
+                   B=self._wp("patch_embed.proj.weight") if pe_code == code else self._pp("patch_embed.proj.weight"), C=x.data_ptr(),
                    bias=self._pp("patch_embed.proj.bias"), resid=self._pp("pos_embed"), lda=Kp, ldb=Kp, ldc=D, ldres=D,
                    M=rows, N=D, K=Kp, res_mod=N, out_bf16=0, **prod)
         for i in range(self.depth):

@@ -425,7 +425,7 @@ def test_masked_mse_and_adamw(hip):
     assert relerr(p2, torch.cat([a, b])) < 1e-5
 
 
-@pytest.mark.parametrize("B,N,H,dh", [(2, 576, 12, 64), (2, 576, 16, 32), (1, 200, 3, 64), (1, 64, 2, 32)])
+@pytest.mark.parametrize("B,N,H,dh", [(2, 576, 12, 64), (2, 576, 16, 32), (1, 200, 3, 64), (1, 64, 2, 32), (2, 729, 16, 32)])
 def test_flash_attention_fwd(hip, B, N, H, dh):
     """Fused bf16 attention vs fp64 softmax(q k^T * scale) v on the same (bf16-representable) inputs, including a
     spiked key that forces the online-softmax rescale branch and ragged N (not a multiple of the 64-key tile)."""
