@@ -199,13 +199,22 @@ __global__ void upsample2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ 
   }
 }
 
+// XCD-aware block order of the stencil kernels below (workgroup b runs on XCD b % 8, each XCD has its own L2): with xcd != 0 (the grid is
+// then a multiple of 8 blocks that covers the map once) XCD x works on the x-th CONTIGUOUS eighth of the pixels, so that the rows two
+// neighbouring output rows share are fetched into ONE L2 -- in launch order the blocks of an image row alternate over all eight, and
+// every L2 fetches (nearly) the whole map: 3-4 x the map's bytes from the memory side for the adjoint's 4 x 4 taps.
+__device__ __forceinline__ int up2_block(int xcd) {
+  const int b = (int)blockIdx.x;
+  return xcd ? (b & 7) * ((int)gridDim.x >> 3) + (b >> 3) : b;
+}
+
 // Same result, one thread per COARSE pixel and 8 channels: the 3x3 clamped neighbourhood is loaded once (9 loads for 4 outputs
 // instead of 16) and interpolated separably in the same order as above (horizontal, then vertical), so the values are identical.
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_fwd_quad_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void upsample2x_fwd_quad_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int xcd) {
   const int CV = C / 8;
   const int64_t total = (int64_t)B * H * W * CV;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)up2_block(xcd) * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     int64_t t = i / CV;
     const int mx = (int)(t % W); t /= W;
@@ -258,10 +267,10 @@ __device__ __forceinline__ void up2_adj_taps(int m, int n, int (&f)[4], float (&
 }
 
 template <typename T, int VEC>
-__global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int H, int W, int C) {
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int H, int W, int C, int xcd) {
   const int CV = C / VEC;
   const int64_t total = (int64_t)B * H * W * CV;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)up2_block(xcd) * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     int64_t t = i / CV;
     const int mx = (int)(t % W); t /= W;
@@ -638,17 +647,27 @@ extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* d
   COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_wgrad");
 }
 
+// Grid of the XCD-aware form (up2_block): one pass over the map, a multiple of 8 blocks, uncapped; COUNTR_UP2_XCD=0 keeps launch order.
+static int up2_xcd_grid(int64_t work, int& nb) {
+  static const int on = []() { const char* e = getenv("COUNTR_UP2_XCD"); return e ? atoi(e) : 1; }();
+  const int64_t b = (work + 255) / 256;
+  if (!on || b < 64 || b > (1 << 22)) return 0;
+  nb = (int)((b + 7) / 8 * 8);
+  return 1;
+}
+
 extern "C" int countr_upsample2x_fwd(const void* in, void* out, int B, int H, int W, int C, int dtype, void* stream) {
   if (!in || !out || (C != 1 && C % 8)) { countr_set_error("countr_upsample2x_fwd: C must be 1 or a multiple of 8"); return -1; }
   const int64_t total = (int64_t)B * 4 * H * W * (C == 1 ? 1 : C / 8);
   const int nb = nblocks(total, 256, 8192);
-  const int nbq = nblocks(total / 4, 256, 8192);     // multi-channel maps: one thread per 2x2 block of fine pixels (quad kernel)
+  int nbq = nblocks(total / 4, 256, 8192);     // multi-channel maps: one thread per 2x2 block of fine pixels (quad kernel)
+  const int xcd = up2_xcd_grid(total / 4, nbq);
   if (dtype == COUNTR_BF16) {
     if (C == 1) hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
-    else hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<bf16_t>), dim3(nbq), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<bf16_t>), dim3(nbq), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, B, H, W, C, xcd);
   } else {
     if (C == 1) hipLaunchKernelGGL((upsample2x_fwd_kernel<float, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
-    else hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<float>), dim3(nbq), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C);
+    else hipLaunchKernelGGL((upsample2x_fwd_quad_kernel<float>), dim3(nbq), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, B, H, W, C, xcd);
   }
   COUNTR_LAUNCH_CHECK("countr_upsample2x_fwd");
 }
@@ -656,14 +675,16 @@ extern "C" int countr_upsample2x_fwd(const void* in, void* out, int B, int H, in
 extern "C" int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, int W, int C, int dtype, void* stream) {
   if (!dout || !din || (C != 1 && C % 8)) { countr_set_error("countr_upsample2x_bwd: C must be 1 or a multiple of 8"); return -1; }
   const int64_t total = (int64_t)B * H * W * (C == 1 ? 1 : C / 8);
-  const int nb = nblocks(total, 256, 8192);
-  // (a 2x2-coarse-block variant like the forward's was measured: 50.7 vs 50.2 us at 96 -> 192 and slower on the small maps)
+  int nb = nblocks(total, 256, 8192);
+  // (a 2x2-coarse-block variant like the forward's was measured: 50.7 vs 50.2 us at 96 -> 192 and slower on the small maps -- the
+  // kernel is not bound by its load count but by the memory side: see up2_block)
+  const int xcd = C == 1 ? 0 : up2_xcd_grid(total, nb);
   if (dtype == COUNTR_BF16) {
-    if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C);
-    else hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C);
+    if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C, 0);
+    else hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C, xcd);
   } else {
-    if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, C);
-    else hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, C);
+    if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, C, 0);
+    else hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, C, xcd);
   }
   COUNTR_LAUNCH_CHECK("countr_upsample2x_bwd");
 }
