@@ -303,6 +303,45 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, T* __restrict_
   }
 }
 
+// The adjoint for the density head's maps (C = 256, W % 8 == 0): one workgroup per 8-pixel chunk of a coarse row (32 channel vectors x
+// 8 pixels), its (image, row, chunk) taken from the block index with wave-uniform arithmetic -- the per-pixel kernel above spends ~490
+// of its 705 VALU instructions per thread on per-lane indices (three integer divisions, 64-bit address products with quarter-rate
+// multiplies) and is bound by them, not by memory (54 us for 189 MB at 96 -> 192 in the step).  Same taps in the same order: identical
+// values.  Workgroup order: XCD x takes the x-th contiguous eighth of the chunks (up2_block).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_chunk_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int H, int W, int xcd) {
+  constexpr int C = 256;
+  const int nxc = W >> 3;
+  const int lb = __builtin_amdgcn_readfirstlane(up2_block(xcd));
+  const int row = lb / nxc, xc = lb - row * nxc;     // (uniform)
+  const int b = row / H, my = row - b * H;
+  if (b >= B) return;
+  const int cv = threadIdx.x & 31, mx = xc * 8 + (threadIdx.x >> 5);
+  int fy[4], fx[4];
+  float wy[4], wx[4];
+  up2_adj_taps(my, H, fy, wy);
+  up2_adj_taps(mx, W, fx, wx);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const T* img = dout + (int64_t)b * 4 * H * W * C;                 // (uniform base; 32-bit offsets inside an image)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (wy[a] == 0.f) continue;
+    const int ro = fy[a] * 2 * W * C + cv * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (wx[c] == 0.f) continue;
+      float v[8];
+      ld8<T>(img + (ro + fx[c] * C), v);
+      const float ww = wy[a] * wx[c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += ww * v[e];
+    }
+  }
+  st8<T>(din + (int64_t)b * H * W * C + ((my * W + mx) * C + cv * 8), acc);
+}
+
 // ---------------- dpre = dh * gelu'(pre)
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ pre, T* __restrict__ dpre, int64_t n8) {
@@ -649,11 +688,20 @@ extern "C" int countr_conv3x3_c3_wgrad(const float* in, const void* dy, float* d
 
 // Grid of the XCD-aware form (up2_block): one pass over the map, a multiple of 8 blocks, uncapped; COUNTR_UP2_XCD=0 keeps launch order.
 static int up2_xcd_grid(int64_t work, int& nb) {
-  static const int on = []() { const char* e = getenv("COUNTR_UP2_XCD"); return e ? atoi(e) : 1; }();
+  const char* e = getenv("COUNTR_UP2_XCD");
+  const int on = e ? atoi(e) : 1;
   const int64_t b = (work + 255) / 256;
   if (!on || b < 64 || b > (1 << 22)) return 0;
   nb = (int)((b + 7) / 8 * 8);
   return 1;
+}
+
+// the adjoint's chunk form (upsample2x_bwd_chunk_kernel): 256 channels, rows of whole 8-pixel chunks, 32-bit element offsets inside
+// one image's fine map; COUNTR_UP2_ROWS=0 keeps the per-pixel kernel
+static bool up2_rows_form(int B, int H, int W, int C) {
+  const char* e = getenv("COUNTR_UP2_ROWS");      // (read per call: A/B and tests inside one process; not on a replay path)
+  const int on = e ? atoi(e) : 1;
+  return on && C == 256 && (W % 8) == 0 && W >= 8 && (long long)4 * H * W * C < (1ll << 30) && (long long)B * H * (W / 8) < (1ll << 30);
 }
 
 extern "C" int countr_upsample2x_fwd(const void* in, void* out, int B, int H, int W, int C, int dtype, void* stream) {
@@ -679,6 +727,12 @@ extern "C" int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, 
   // (a 2x2-coarse-block variant like the forward's was measured: 50.7 vs 50.2 us at 96 -> 192 and slower on the small maps -- the
   // kernel is not bound by its load count but by the memory side: see up2_block)
   const int xcd = C == 1 ? 0 : up2_xcd_grid(total, nb);
+  if (up2_rows_form(B, H, W, C)) {     // the density head's maps: one workgroup per 8-pixel chunk of a coarse row
+    const int nbr = (B * H * (W / 8) + 7) / 8 * 8;
+    if (dtype == COUNTR_BF16) hipLaunchKernelGGL((upsample2x_bwd_chunk_kernel<bf16_t>), dim3(nbr), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, 1);
+    else hipLaunchKernelGGL((upsample2x_bwd_chunk_kernel<float>), dim3(nbr), dim3(256), 0, STREAM(stream), (const float*)dout, (float*)din, B, H, W, 1);
+    COUNTR_LAUNCH_CHECK("countr_upsample2x_bwd");
+  }
   if (dtype == COUNTR_BF16) {
     if (C == 1) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C, 0);
     else hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8>), dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dout, (bf16_t*)din, B, H, W, C, xcd);

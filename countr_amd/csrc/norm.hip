@@ -350,7 +350,11 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
 // Backward pass 1: per-channel sums of g = dy * 1[y>0] and g * xhat over a pixel split.
 // dy is either a tensor (T) or, for the fused 1x1 head, d1[b,p] * w1[c].
 // partial layout: [B][ns][3][C] = {sum g, sum g*xhat, sum d1*y (dw1, head only)}
-template <typename T, int NT = 256>
+// HEAD (the fused 1x1 head, dy = d1[b,p] * w1[c]): with m = d1 * 1[y>0] every sum is a combination of TWO per-channel sums,
+// S1 = sum m and S2 = sum m * xhat -- sum g = w1 S1, sum g * xhat = w1 S2, sum d1 * y = gamma S2 + beta S1 (y = xhat gamma + beta where
+// the mask is set) -- 7 VALU operations per element instead of 11 on the 151-MB map of the 192 x 192 stage (the pass is as much
+// VALU- as bandwidth-bound: 9.4 M (pixel, 8-channel) items of ~90 instructions); the mask is computed exactly as the apply pass does.
+template <typename T, int NT = 256, bool HEAD = false>
 __global__ __launch_bounds__(NT) void gn_relu_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const float* __restrict__ d1, const float* __restrict__ w1,
                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -392,23 +396,35 @@ __global__ __launch_bounds__(NT) void gn_relu_bwd_reduce_kernel(const T* __restr
       for (int e = 0; e < 8; ++e) {
         const float xh = (v[u][e] - mu) * rs;
         const float yv = xh * ga[e] + be[e];
-        const float gg = (yv > 0.f) ? (w1 ? dd[u] * w[e] : d[u][e]) : 0.f;
-        sg[e] += gg;
-        sgx[e] += gg * xh;
-        if (w1) sw[e] += dd[u] * fmaxf(yv, 0.f);
+        if constexpr (HEAD) {
+          const float md = (yv > 0.f) ? dd[u] : 0.f;
+          sg[e] += md;             // S1
+          sgx[e] += md * xh;       // S2
+        } else {
+          const float gg = (yv > 0.f) ? (w1 ? dd[u] * w[e] : d[u][e]) : 0.f;
+          sg[e] += gg;
+          sgx[e] += gg * xh;
+          if (w1) sw[e] += dd[u] * fmaxf(yv, 0.f);
+        }
       }
     }
   }
   float* o = partial + ((int64_t)b * ns + split) * 3 * GN_C;
   reduce_vec_same_chanvec<8, NW>(sg, smv);
   reduce_vec_same_chanvec<8, NW>(sgx, smv);
-  if (w1) reduce_vec_same_chanvec<8, NW>(sw, smv);
+  if (!HEAD && w1) reduce_vec_same_chanvec<8, NW>(sw, smv);
   if (threadIdx.x < 32) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      o[cv * 8 + e] = sg[e];
-      o[GN_C + cv * 8 + e] = sgx[e];
-      o[2 * GN_C + cv * 8 + e] = w1 ? sw[e] : 0.f;
+      if constexpr (HEAD) {
+        o[cv * 8 + e] = w[e] * sg[e];
+        o[GN_C + cv * 8 + e] = w[e] * sgx[e];
+        o[2 * GN_C + cv * 8 + e] = ga[e] * sgx[e] + be[e] * sg[e];
+      } else {
+        o[cv * 8 + e] = sg[e];
+        o[GN_C + cv * 8 + e] = sgx[e];
+        o[2 * GN_C + cv * 8 + e] = w1 ? sw[e] : 0.f;
+      }
     }
   }
 }
@@ -1023,6 +1039,7 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
     // 48x48 and 24x24: 17.4 -> 11.6 us); 1024 falls off a cliff (step +230 us: 128-VGPR budget)
     const int nt = w1 ? 256 : 512;   // (the fused-head form -- 192x192, x only -- is better off with 256: 41.4 vs 44.4 us)
     if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    else if (d1 && w1 && !getenv("COUNTR_GN_HEAD_OLD")) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256, true>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);

@@ -313,6 +313,40 @@ def test_upsample2x_fwd_bwd(hip, Cc, tdt, code, tol, H, W):
     assert relerr(dx, xr.grad.permute(0, 2, 3, 1)) < tol
 
 
+@pytest.mark.parametrize("B,H,W", [(8, 24, 24), (2, 96, 96), (5, 32, 40), (3, 64, 8)])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_upsample2x_chunk_kernel_equals_the_per_pixel_kernels(hip, monkeypatch, tdt, code, tol, B, H, W):
+    """The density head's maps (256 channels, rows of whole 8-pixel chunks) run the bilinear adjoint with one workgroup per 8-pixel chunk
+    of a coarse row, indices from wave-uniform arithmetic (upsample2x_bwd_chunk_kernel: the per-pixel kernel spends two thirds of its
+    instructions on per-lane indices), and both directions in an XCD-contiguous block order; same loads and arithmetic in the same order
+    -- the outputs must be IDENTICAL to the per-pixel kernels' (COUNTR_UP2_ROWS=0, with and without the XCD order) and meet the
+    oracle's tolerance."""
+    Cc = 256
+    x = rnd((B, H, W, Cc), 31).to(tdt).cuda()
+    dy = rnd((B, 2 * H, 2 * W, Cc), 32).to(tdt).cuda()
+    outs = {}
+    for name, env in (("rows", {}), ("pixel_xcd", {"COUNTR_UP2_ROWS": "0"}), ("pixel", {"COUNTR_UP2_ROWS": "0", "COUNTR_UP2_XCD": "0"})):
+        for k in ("COUNTR_UP2_ROWS", "COUNTR_UP2_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        y = torch.full((B, 2 * H, 2 * W, Cc), float("nan"), device="cuda", dtype=tdt)
+        dx = torch.full((B, H, W, Cc), float("nan"), device="cuda", dtype=tdt)
+        _lib.check(hip.countr_upsample2x_fwd(P(x), P(y), B, H, W, Cc, code, st()))
+        _lib.check(hip.countr_upsample2x_bwd(P(dy), P(dx), B, H, W, Cc, code, st()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all(), name
+        outs[name] = (y, dx)
+    for name in ("pixel_xcd", "pixel"):
+        assert torch.equal(outs["rows"][0], outs[name][0]), name
+        assert torch.equal(outs["rows"][1], outs[name][1]), name
+    xr = x.cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = R.upsample2x(xr)
+    assert relerr(outs["rows"][0].cpu(), yr.permute(0, 2, 3, 1)) < tol
+    yr.backward(dy.cpu().double().permute(0, 3, 1, 2))
+    assert relerr(outs["rows"][1].cpu(), xr.grad.permute(0, 2, 3, 1)) < tol
+
+
 @pytest.mark.parametrize("tdt,code,tol", DT)
 def test_gelu_bwd_colsum(hip, tdt, code, tol):
     M, N = 1152, 2048
