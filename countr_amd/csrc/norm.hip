@@ -1039,7 +1039,7 @@ extern "C" int countr_groupnorm_relu_bwd(const void* x, const void* dy, const fl
     // 48x48 and 24x24: 17.4 -> 11.6 us); 1024 falls off a cliff (step +230 us: 128-VGPR budget)
     const int nt = w1 ? 256 : 512;   // (the fused-head form -- 192x192, x only -- is better off with 256: 41.4 vs 44.4 us)
     if (nt == 512) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 512>), dim3(ns, B), dim3(512), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
-    else if (d1 && w1 && !getenv("COUNTR_GN_HEAD_OLD")) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256, true>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
+    else if (d1 && w1) hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256, true>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     else hipLaunchKernelGGL((gn_relu_bwd_reduce_kernel<bf16_t, 256>), dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, workspace, HW, G);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), workspace, gamma, gmean, per_image, HW, G, ns);
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)dy, d1, w1, stats, gamma, beta, gmean, (bf16_t*)dx, HW, G, ns);
