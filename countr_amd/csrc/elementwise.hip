@@ -306,8 +306,9 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, T* __restrict_
 // The adjoint for the density head's maps (C = 256, W % 8 == 0): one workgroup per 8-pixel chunk of a coarse row (32 channel vectors x
 // 8 pixels), its (image, row, chunk) taken from the block index with wave-uniform arithmetic -- the per-pixel kernel above spends ~490
 // of its 705 VALU instructions per thread on per-lane indices (three integer divisions, 64-bit address products with quarter-rate
-// multiplies) and is bound by them, not by memory (54 us for 189 MB at 96 -> 192 in the step).  Same taps in the same order: identical
-// values.  Workgroup order: XCD x takes the x-th contiguous eighth of the chunks (up2_block).
+// multiplies); this form runs 339.  Same taps in the same order: identical values.  Workgroup order: XCD x takes the x-th contiguous
+// eighth of the chunks (up2_block).  Back to back 50.7 -> 37.2 us at 96 -> 192 with both; in the step 54 -> 52 us, because there the
+// input is the 151-MB map the convolution's dgrad has just written and the pass runs at the memory side's pace (tools/ubench_mall.py).
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_chunk_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int H, int W, int xcd) {
   constexpr int C = 256;
@@ -724,8 +725,7 @@ extern "C" int countr_upsample2x_bwd(const void* dout, void* din, int B, int H, 
   if (!dout || !din || (C != 1 && C % 8)) { countr_set_error("countr_upsample2x_bwd: C must be 1 or a multiple of 8"); return -1; }
   const int64_t total = (int64_t)B * H * W * (C == 1 ? 1 : C / 8);
   int nb = nblocks(total, 256, 8192);
-  // (a 2x2-coarse-block variant like the forward's was measured: 50.7 vs 50.2 us at 96 -> 192 and slower on the small maps -- the
-  // kernel is not bound by its load count but by the memory side: see up2_block)
+  // (a 2x2-coarse-block variant like the forward's was measured: 50.7 vs 50.2 us at 96 -> 192 and slower on the small maps)
   const int xcd = C == 1 ? 0 : up2_xcd_grid(total, nb);
   if (up2_rows_form(B, H, W, C)) {     // the density head's maps: one workgroup per 8-pixel chunk of a coarse row
     const int nbr = (B * H * (W / 8) + 7) / 8 * 8;
