@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("COUNTR_LIB", os.path.join(_HERE, "libcountr_hip.so"))
 LIB_PATH_F16 = os.environ.get("COUNTR_LIB_F16", os.path.join(_HERE, "libcountr_hip_f16.so"))
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 OP_ROW, OP_COL, OP_IM2ROW, OP_IM2COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
         ("rowsum_slabs", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
+        ("gn_rows", C.c_void_p),
     ]
 
 
@@ -74,6 +75,7 @@ def _declare(L):
     L.countr_gemm.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, vp]
     L.countr_gemm_rowsum_slabs.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
     L.countr_gemm_tiles.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
+    L.countr_gemm_gn_rows.argtypes = [C.POINTER(GemmArgs), i32, i32, i32]
     L.countr_gemm_group.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, i32, vp]
     L.countr_gemm_group_tiles.argtypes = [C.POINTER(GemmArgs), i32, i32, i32, i32]
     L.countr_splitk_reduce.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
@@ -93,6 +95,7 @@ _SIGS = {
     "countr_groupnorm_nsplit": [_i],
     "countr_groupnorm_bwd_image_sums_offset": [_i, _i],
     "countr_groupnorm_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "countr_groupnorm_relu_fwd_rows": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "countr_groupnorm_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "countr_instnorm_workspace_floats": [_i, _i],
     "countr_instnorm_relu_pool_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp],

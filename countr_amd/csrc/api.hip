@@ -55,7 +55,9 @@ int countr_check_launch(const char* what) {
 }
 
 extern "C" const char* countr_last_error(void) { return g_err; }
-extern "C" int countr_version(void) { return 8; }   // 2: countr_gemm_args grew (ln_* fields, rowsum_slabs); 3: prefetch hint; 4: countr_gemm_group; 5: countr_step_prologue; 6: countr_softmax_fwd_ld; 7: *_amp (device-side GradScaler); 8: countr_transpose16
+thread_local int countr_dry_run = 0;
+
+extern "C" int countr_version(void) { return 9; }   // 2: countr_gemm_args grew (ln_* fields, rowsum_slabs); 3: prefetch hint; 4: countr_gemm_group; 5: countr_step_prologue; 6: countr_softmax_fwd_ld; 7: *_amp (device-side GradScaler); 8: countr_transpose16; 9: countr_gemm_args.gn_rows + countr_groupnorm_relu_fwd_rows
 
 extern "C" int countr_init(int device) {
   int n = 0;

@@ -198,6 +198,37 @@ __device__ __forceinline__ float gelu_fast_grad(float x) { float c, e; gelu_fast
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x); }
 template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { if constexpr (sizeof(T) == 2) return gelu_fast_grad(x); else return gelu_erf_grad(x); }
 
+// GroupNorm statistics from a convolution's epilogue (countr_gemm_args.gn_rows): the lane holds the eight ROUNDED 16-bit outputs of row m
+// at columns [col, col + 8) -- the four lanes of a DPP quad hold one 32-channel block of the row (col % 32 == 8 (lane & 3)) -- and the
+// block's {sum, sum of squares} goes to rows[m][N / 32][2].  One fixed tree per row (pairs inside the lane, then the quad butterfly): the
+// value does not depend on the kernel, the tile or the batch a row is computed in (gemm256.hip and linear.hip share this function).
+typedef __attribute__((ext_vector_type(4))) unsigned countr_u32x4_t;
+// {sum, sum of squares} of the 32-channel block whose four 8-value pieces the lanes of a DPP quad hold (every lane of the quad gets both):
+// THE tree of a pixel's GroupNorm partials, shared by the convolution epilogues and by the statistics pass that reads the map itself
+// (norm.hip::gn_stats_tree_kernel), so that the two routes to a GroupNorm's statistics agree bit for bit
+__device__ __forceinline__ void countr_gn_quad_sums(const countr_u32x4_t packed, float& s1, float& s2) {
+  s1 = 0.f; s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float lo, hi;
+    unpack2h(packed[e], lo, hi);
+    s1 += lo + hi;
+    s2 += __builtin_fmaf(lo, lo, hi * hi);
+  }
+  s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);     // lane ^ 1
+  s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);     // lane ^ 2
+}
+__device__ __forceinline__ void countr_gn_row_partials(const countr_u32x4_t packed, float* __restrict__ rows, int m, int N, int col, int lane) {
+  if (!rows) return;      // (uniform)
+  float s1, s2;
+  countr_gn_quad_sums(packed, s1, s2);
+  if ((lane & 3) == 0) *reinterpret_cast<float2*>(rows + ((int64_t)m * (N >> 5) + (col >> 5)) * 2) = make_float2(s1, s2);
+}
+
+// != 0 while a query (countr_gemm_gn_rows) walks the launch path: the lean kernels' launch functions then return 0 without launching,
+// so that "would this launch run on a kernel with that epilogue?" is answered by the selection code itself (defined in api.hip)
+extern thread_local int countr_dry_run;
+
 // Error plumbing shared by all translation units (defined in api.hip).
 extern "C" void countr_set_error(const char* msg);
 int countr_check_launch(const char* what);

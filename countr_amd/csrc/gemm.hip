@@ -210,6 +210,17 @@ extern "C" int countr_gemm_rowsum_slabs(const countr_gemm_args* a, int dtype, in
   return a->splitk > 1 ? a->splitk : 1;
 }
 
+// 1 when countr_gemm on these arguments runs on a kernel whose epilogue writes a->gn_rows (the bf16 (IM2ROW, ROW) launches of the lean
+// convolution kernels: shape, alignment and the environment switches decide), else 0: the caller then keeps the separate statistics pass
+extern "C" int countr_gemm_gn_rows(const countr_gemm_args* a, int dtype, int modeA, int modeB) {
+  if (!a || dtype != COUNTR_BF16 || modeA != COUNTR_OP_IM2ROW || modeB != COUNTR_OP_ROW || !a->A || !a->B || !a->C || a->partial || (a->N % 32)) return 0;
+  countr_dry_run = 1;
+  int rc = countr_big_conv(a, nullptr);
+  if (rc == 1) rc = countr_lean_conv(a, nullptr);
+  countr_dry_run = 0;
+  return rc == 0;
+}
+
 extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream) {
   if (!a || !a->A || !a->B || (!a->C && !a->partial)) { countr_set_error("countr_gemm: null pointer"); return -1; }
   if ((a->splitk > 1 && !a->partial) || (a->partial && a->nbatch > 1)) { countr_set_error("countr_gemm: bad split-K setup"); return -1; }
@@ -223,6 +234,9 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   if (modeA == COUNTR_OP_COL && (a->M % epc)) { countr_set_error("countr_gemm: M must be a multiple of the chunk for COL A"); return -1; }
   if (modeB == COUNTR_OP_COL && (a->N % epc)) { countr_set_error("countr_gemm: N must be a multiple of the chunk for COL B"); return -1; }
   if ((modeA == COUNTR_OP_IM2ROW || modeB == COUNTR_OP_IM2COL) && (a->Cin % 64 || a->H <= 0 || a->W <= 0)) { countr_set_error("countr_gemm: conv modes need Cin % 64 == 0"); return -1; }
+  if (a->gn_rows && !(dtype == COUNTR_BF16 && modeA == COUNTR_OP_IM2ROW && modeB == COUNTR_OP_ROW)) {
+    countr_set_error("countr_gemm: gn_rows is an output of the bf16 (IM2ROW, ROW) convolution launches only"); return -1;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COUNTR_BF16 && modeA == COUNTR_OP_ROW && modeB == COUNTR_OP_ROW) {   // (GELU_BWD: the lean kernel only)
     const int rb = countr_big_linear(a, s);    // chip-filling grids of 256 x 256 tiles (fc1): the 8-phase kernel of gemm256.hip
@@ -243,6 +257,10 @@ extern "C" int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int 
   }
   if (a->rowsum_partial && a->rowsum_slabs > 0 && a->rowsum_slabs != (a->splitk > 1 ? a->splitk : 1)) {
     countr_set_error("countr_gemm: rowsum_slabs does not match countr_gemm_rowsum_slabs() for this launch"); return -1;
+  }
+  if (a->gn_rows) {
+    countr_set_error("countr_gemm: gn_rows needs the lean bf16 convolution kernels ((IM2ROW, ROW), more than 256 output tiles, N % 128 == 0, bf16 output without activation)");
+    return -1;
   }
   if (a->ln_xcopy || a->ln_stats_out || a->ln_stats || a->ln_colsum) {
     countr_set_error("countr_gemm: the LayerNorm-folding fields need the lean bf16 (ROW, ROW) kernel (N % 128 == 0, K % 64 == 0, aligned operands, bias)");

@@ -58,6 +58,7 @@ struct BigArgs {
   const float* colsum;       // [N]
   float ln_eps;
   float* stamps;             // G256_STAMP builds
+  float* gn_rows;            // CONV (optional): [M][N/32][2] = {sum, sum of squares} of every 32-channel block of the ROUNDED output row
 };
 
 constexpr int UNIT = 16384, B_BASE = 65536;
@@ -548,7 +549,9 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) pp[e] = gelu_sig2(pp[e]);
       }
-      *reinterpret_cast<u32x4_t*>(g.C + o) = u32x4_t{pack2bf(pp[0][0], pp[0][1]), pack2bf(pp[1][0], pp[1][1]), pack2bf(pp[2][0], pp[2][1]), pack2bf(pp[3][0], pp[3][1])};
+      const u32x4_t packed = u32x4_t{pack2bf(pp[0][0], pp[0][1]), pack2bf(pp[1][0], pp[1][1]), pack2bf(pp[2][0], pp[2][1]), pack2bf(pp[3][0], pp[3][1])};
+      *reinterpret_cast<u32x4_t*>(g.C + o) = packed;
+      if constexpr (CONV && EPI == EPI_BF16) countr_gn_row_partials(packed, g.gn_rows, m, g.N, sn0 + ccol, lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(512, 2) void g256_kernel(const BigArgs g) {
 
 template <bool CONV, int EPI, bool LN>
 int launch_big(const BigArgs& a0, hipStream_t s) {
+  if (countr_dry_run) return 0;     // (a selection query: countr_gemm_gn_rows)
   BigArgs a = a0;
   a.npf = countr_prefetch_blocks(a.launch_tiles, a.pf, a.pf_bytes);
   static bool attr_set = false;
@@ -615,7 +619,7 @@ int countr_big_linear(const countr_gemm_args* a, hipStream_t s) {
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.tilesN = a->N / 256;
   g.launch_tiles = (int)tiles; g.pf = (const char*)a->prefetch; g.pf_bytes = a->prefetch_bytes;
   g.resid = a->resid; g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.ldres = (int)a->ldres; g.res_mod = a->res_mod;
-  g.H = g.Wd = g.Cin = g.cpt_log = 0; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps; g.stamps = nullptr;
+  g.H = g.Wd = g.Cin = g.cpt_log = 0; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps; g.stamps = nullptr; g.gn_rows = nullptr;
 #ifdef G256_STAMP
   g.stamps = (float*)a->C2; g.C2 = nullptr;
 #endif
@@ -644,6 +648,7 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   if ((a->ldb % 8) || (a->ldc % 8) || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15)) return 1;
   if ((int64_t)(a->M + 2 * a->W + 2 + 256) * a->Cin * 2 >= (int64_t)0x7f000000ll || (int64_t)a->N * a->ldb * 2 >= (int64_t)0x7f000000ll) return 1;
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
+  if (a->gn_rows && ((uintptr_t)a->gn_rows & 7)) return 1;
   const long tilesN = a->N / 256, tiles = (long)((a->M + 255) / 256) * tilesN;
   // split rounds: full rounds here, at most half a round of tiles behind them on the 128-row kernel
   long head = tiles;
@@ -673,7 +678,7 @@ int countr_big_conv(const countr_gemm_args* a, hipStream_t s) {
   g.launch_tiles = (int)head; g.pf = nullptr; g.pf_bytes = 0;
   g.resid = nullptr; g.xcopy = nullptr; g.stats_out = nullptr; g.ldres = 0; g.res_mod = 0;
   g.H = a->H; g.Wd = a->W; g.Cin = a->Cin; g.cpt_log = a->Cin == 128 ? 1 : a->Cin == 256 ? 2 : 3;
-  g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f; g.stamps = nullptr;
+  g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f; g.stamps = nullptr; g.gn_rows = a->gn_rows;
 #ifdef G256_STAMP
   g.stamps = (float*)a->C2;
 #endif

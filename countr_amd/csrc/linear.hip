@@ -60,6 +60,7 @@ struct LinArgs {
   const float* stats_in;
   const float* colsum;
   float ln_eps;
+  float* gn_rows;      // CONV (optional): GroupNorm row partials of the rounded output (common.hpp::countr_gn_row_partials)
 };
 
 constexpr int STAGE_BYTES = 32768, B_OFF = 16384;
@@ -542,7 +543,9 @@ __global__ __launch_bounds__(256 * WMB * WNB + 64 * NLD, NLD ? ((STAGES == 2 && 
 #pragma unroll
           for (int e = 0; e < 4; ++e) p[e] = gelu_sig2(p[e]);
         }
-        *reinterpret_cast<u32x4_t*>(g.C + o) = u32x4_t{pack2bf(p[0][0], p[0][1]), pack2bf(p[1][0], p[1][1]), pack2bf(p[2][0], p[2][1]), pack2bf(p[3][0], p[3][1])};
+        const u32x4_t packed = u32x4_t{pack2bf(p[0][0], p[0][1]), pack2bf(p[1][0], p[1][1]), pack2bf(p[2][0], p[2][1]), pack2bf(p[3][0], p[3][1])};
+        *reinterpret_cast<u32x4_t*>(g.C + o) = packed;
+        if constexpr (CONV && EPI == EPI_BF16) countr_gn_row_partials(packed, g.gn_rows, m, g.N, sn0 + ccol, lane);
       } else {
         f4_t v = *reinterpret_cast<const f4_t*>(src + j * RSTEP * OPITCH);
         v += f4_t{bcol[0], bcol[1], bcol[2], bcol[3]};
@@ -598,6 +601,7 @@ int launch_lin(const LinArgs& a0, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
+  if (countr_dry_run) return 0;     // (a selection query: countr_gemm_gn_rows)
   a.launch_tiles = ((a.M + BMt - 1) / BMt - a.tile_m0) * a.tilesN;
   a.npf = countr_prefetch_blocks(a.launch_tiles, a.pf, a.pf_bytes);
   hipLaunchKernelGGL((lin_kernel<WMB, NLD, EPI, STAGES, CONV, WNB, LN, TM>), dim3(a.launch_tiles + a.npf), dim3(256 * WMB * WNB + 64 * NLD), lds, s, a);
@@ -643,6 +647,7 @@ int countr_lean_linear(const countr_gemm_args* a, hipStream_t s) {
   if (ln_in && (epi == EPI_RES || !a->ln_stats || !a->ln_colsum || (((uintptr_t)a->ln_stats | (uintptr_t)a->ln_colsum) & 15) || a->ln_nblk != a->K / 64 || (a->K % 128))) return 1;
   LinArgs g;
   g.xcopy = (char*)a->ln_xcopy; g.stats_out = a->ln_stats_out; g.stats_in = a->ln_stats; g.colsum = a->ln_colsum; g.ln_eps = a->ln_eps;
+  g.gn_rows = nullptr;
   g.A = (const char*)a->A; g.W = (const char*)a->B; g.C = (char*)a->C; g.C2 = (char*)a->C2; g.bias = a->bias ? a->bias : zero_bias; g.resid = a->resid;
   g.M = a->M; g.N = a->N; g.K = a->K; g.lda = (int)a->lda; g.ldw = (int)a->ldb; g.ldc = (int)a->ldc; g.ldres = (int)a->ldres;
   g.res_mod = a->res_mod; g.tilesN = a->N / 128; g.tile_m0 = 0; g.H = g.Wd = g.Cin = 0;
@@ -711,6 +716,7 @@ int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0) {
   if (a->bias && ((uintptr_t)a->bias & 15)) return 1;
   const long tiles = (long)((a->M + 127) / 128) * (a->N / 128);
   if (tiles <= 256 && row0 == 0) return 1;     // small maps: the generic kernel's split-K / wave-specialised 128x128 forms
+  if (a->gn_rows && ((uintptr_t)a->gn_rows & 7)) return 1;
   const float* zero_bias = nullptr;
   if (!a->bias && !(zero_bias = countr_zero_vec(a->N))) return -1;
   LinArgs g;
@@ -722,6 +728,7 @@ int countr_lean_conv_rows(const countr_gemm_args* a, hipStream_t s, int row0) {
   g.res_mod = 0; g.tilesN = a->N / 128; g.tile_m0 = row0 / 128; g.H = a->H; g.Wd = a->W; g.Cin = a->Cin;
   g.pf = nullptr; g.pf_bytes = 0; g.launch_tiles = 0; g.npf = 0;
   g.xcopy = nullptr; g.stats_out = nullptr; g.stats_in = nullptr; g.colsum = nullptr; g.ln_eps = 0.f;
+  g.gn_rows = a->gn_rows;
   // 128 x 256 tiles when the width allows (the density head's 256 output channels in ONE workgroup: the im2row operand -- nine taps of
   // a map that does not fit the L2 -- is then staged once per row block, not once per column tile: 192x192 366 vs 402 us), else 256 x 128
   // (the 192 x 256 form on the convolutions: faster back to back -- 349 -> 331 us -- and not in the step, where the im2row operand

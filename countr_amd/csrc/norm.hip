@@ -265,6 +265,89 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
+// 16-bit maps, 8 groups of 32 channels: the statistics pass over the MAP with exactly the association of the route through a
+// convolution's epilogue -- per pixel and group the quad tree of countr_gn_quad_sums, per split 32 pixel-slot accumulators walked in
+// pixel order, the slots summed in order (gn_stats_rows_kernel below) -- so that a GroupNorm's statistics do not depend on which of the
+// two routes a batch size selects (the lean convolution kernels serve maps of more than 256 tiles: 48 x 48 at B = 8, not at B = 1).
+// thread = (channel vector cv, pixel slot ps of 8); a thread carries the four slots ps, ps + 8, ps + 16, ps + 24.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_tree_kernel(const T* __restrict__ x, float* __restrict__ part /* [B][ns][G][2] */, int HW) {
+  constexpr int G = 8;
+  static_assert(sizeof(T) == 2, "16-bit maps");
+  __shared__ float sm[2][32][G];
+  const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
+  const int per = (HW + ns - 1) / ns;
+  const int p0 = split * per, p1 = min(HW, p0 + per);
+  const int cv = threadIdx.x & 31, ps = threadIdx.x >> 5;
+  const T* xb = x + (int64_t)b * HW * GN_C + cv * 8;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int pb = p0 + ps; pb < p1; pb += 32) {
+    countr_u32x4_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (pb + 8 * r < p1) v[r] = *reinterpret_cast<const countr_u32x4_t*>(xb + (int64_t)(pb + 8 * r) * GN_C);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (pb + 8 * r >= p1) continue;      // (the same for the four lanes of a quad: they hold one pixel)
+      float s1, s2;
+      countr_gn_quad_sums(v[r], s1, s2);
+      s[r] += s1;
+      q[r] += s2;
+    }
+  }
+  if ((cv & 3) == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sm[0][ps + 8 * r][cv >> 2] = s[r]; sm[1][ps + 8 * r][cv >> 2] = q[r]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float gs = 0.f, gq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { gs += sm[0][i][threadIdx.x]; gq += sm[1][i][threadIdx.x]; }
+    const float n = (float)(p1 - p0) * (GN_C / G);
+    const float m = n > 0 ? gs / n : 0.f;
+    float* o = part + (((int64_t)b * ns + split) * G + threadIdx.x) * 2;
+    o[0] = m;
+    o[1] = fmaxf(gq - gs * m, 0.f);  // M2 about the split mean
+  }
+}
+
+// The same split partials from the ROW partials a convolution's epilogue left (countr_gemm_args.gn_rows: [B * HW][G][2] = {sum, sum of
+// squares} of each pixel's 32-channel groups, G = 8): 64 bytes per pixel instead of the 512-byte pixel.  thread = (group, pixel slot),
+// 32 slots; a wave reads 8 consecutive pixels = 512 contiguous bytes per load.
+__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const float* __restrict__ rows, float* __restrict__ part /* [B][ns][G][2] */,
+                                                            int HW) {
+  constexpr int G = 8;
+  __shared__ float sm[2][32][G];
+  const int b = blockIdx.y, split = blockIdx.x, ns = gridDim.x;
+  const int per = (HW + ns - 1) / ns;
+  const int p0 = split * per, p1 = min(HW, p0 + per);
+  const int g = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const float2* rb = reinterpret_cast<const float2*>(rows) + (int64_t)b * HW * G + g;
+  float s = 0.f, q = 0.f;
+  constexpr int U = 4;
+  for (int pb = p0 + slot; pb < p1; pb += 32 * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (pb + 32 * u < p1) ? rb[(int64_t)(pb + 32 * u) * G] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { s += v[u].x; q += v[u].y; }
+  }
+  sm[0][slot][g] = s;
+  sm[1][slot][g] = q;
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float gs = 0.f, gq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { gs += sm[0][i][threadIdx.x]; gq += sm[1][i][threadIdx.x]; }
+    const float n = (float)(p1 - p0) * (GN_C / G);
+    const float m = n > 0 ? gs / n : 0.f;
+    float* o = part + (((int64_t)b * ns + split) * G + threadIdx.x) * 2;
+    o[0] = m;
+    o[1] = fmaxf(gq - gs * m, 0.f);  // M2 about the split mean
+  }
+}
+
 // Per-(image, group) mean / rstd from the split partials {mean_s, M2_s}: one wave per group, lanes over the splits, the exact
 // two-pass combination  mean = sum n_s mean_s / N,  M2 = sum (M2_s + n_s (mean_s - mean)^2)  (all loads in flight at once).
 __global__ void gn_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats /* [B][G][2] */, int HW, int G,
@@ -1005,14 +1088,17 @@ static int gn_splits_fwd(int HW) {
   return ns > lo ? ns : lo;
 }
 
-extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
-                                         const float* b1, float* out1, float* stats, float* workspace, int B, int HW, int C,
-                                         int G, float eps, int dtype, void* stream) {
+static int groupnorm_relu_fwd(const void* x, const float* rows, const float* gamma, const float* beta, void* y, const float* w1,
+                              const float* b1, float* out1, float* stats, float* workspace, int B, int HW, int C, int G, float eps,
+                              int dtype, void* stream, const char* who) {
   if (!x || !gamma || !beta || !stats || !workspace || C != GN_C || G > 16 || (GN_C / G) % 8 || (!y && !w1)) { countr_set_error("countr_groupnorm_relu_fwd: bad args (C must be 256, G <= 16)"); return -1; }
+  if (rows && (G != 8 || dtype != COUNTR_BF16 || ((uintptr_t)rows & 7))) { countr_set_error("countr_groupnorm_relu_fwd_rows: row partials are those of 8 groups of 32 channels in a 16-bit map"); return -1; }
   const int ns = gn_splits_fwd(HW);
   const int nblk = min((HW + 7) / 8, 512);
   if (dtype == COUNTR_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, HW, G);
+    if (rows) hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(ns, B), dim3(256), 0, STREAM(stream), rows, workspace, HW);
+    else if (G == 8) hipLaunchKernelGGL(gn_stats_tree_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, HW);
+    else hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(ns, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, HW, G);
     hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(B), dim3(64 * G), 0, STREAM(stream), workspace, stats, HW, G, ns, eps);
     hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const bf16_t*)x, workspace, gamma, beta, (bf16_t*)y, w1, b1, out1, stats, HW, G, ns, eps);
   } else {
@@ -1020,7 +1106,21 @@ extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, cons
     hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(B), dim3(64 * G), 0, STREAM(stream), workspace, stats, HW, G, ns, eps);
     hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(nblk, B), dim3(256), 0, STREAM(stream), (const float*)x, workspace, gamma, beta, (float*)y, w1, b1, out1, stats, HW, G, ns, eps);
   }
-  COUNTR_LAUNCH_CHECK("countr_groupnorm_relu_fwd");
+  COUNTR_LAUNCH_CHECK(who);
+}
+
+extern "C" int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
+                                         const float* b1, float* out1, float* stats, float* workspace, int B, int HW, int C,
+                                         int G, float eps, int dtype, void* stream) {
+  return groupnorm_relu_fwd(x, nullptr, gamma, beta, y, w1, b1, out1, stats, workspace, B, HW, C, G, eps, dtype, stream, "countr_groupnorm_relu_fwd");
+}
+
+// ... with the statistics pass reading the ROW partials the producing convolution left (countr_gemm_args.gn_rows) instead of the map
+extern "C" int countr_groupnorm_relu_fwd_rows(const void* x, const float* rows, const float* gamma, const float* beta, void* y,
+                                              const float* w1, const float* b1, float* out1, float* stats, float* workspace, int B,
+                                              int HW, int C, int G, float eps, int dtype, void* stream) {
+  if (!rows) { countr_set_error("countr_groupnorm_relu_fwd_rows: null row partials"); return -1; }
+  return groupnorm_relu_fwd(x, rows, gamma, beta, y, w1, b1, out1, stats, workspace, B, HW, C, G, eps, dtype, stream, "countr_groupnorm_relu_fwd_rows");
 }
 
 // workspace: fp32 [B][ns][3][C]; dgamma/dbeta(/dw1) accumulate flag applies to all.

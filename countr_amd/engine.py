@@ -871,17 +871,33 @@ class Engine:
         return 8 if ktiles >= 64 else (4 if ktiles >= 32 else 1)
 
     # 3x3 conv (NHWC, pad 1) as implicit GEMM (forward, and dgrad with the dgrad-form weights)
-    def _conv_fwd(self, ops, x, w_ohwi, bias_ptr, out, Bn, H, W, Cin, Cout):
+    def _conv_fwd(self, ops, x, w_ohwi, bias_ptr, out, Bn, H, W, Cin, Cout, gn_rows=None):
+        """gn_rows (a callable -> fp32 buffer [Bn * H * W, Cout / 32, 2], or None): ask for the GroupNorm row partials of the rounded
+        output from the convolution's epilogue (countr_gemm_args.gn_rows).  Returns the buffer when the launch runs on a kernel with
+        that epilogue (countr_gemm_gn_rows: the lean 16-bit kernels on maps of more than 256 tiles), else None -- the caller then keeps
+        the statistics pass over the map."""
         M, K = Bn * H * W, 9 * Cin
         sk = self._act_splitk(H * W, K)
+        if sk == 1 and gn_rows is not None and self.code == BF16 and os.environ.get("COUNTR_GN_ROWS", "1") != "0":
+            q = GemmArgs()
+            kw = dict(A=x.data_ptr() or 16, B=w_ohwi.data_ptr() or 16, C=out.data_ptr() or 16, bias=bias_ptr, ldb=K, ldc=Cout, M=M, N=Cout, K=K,
+                      H=H, W=W, Cin=Cin, out_bf16=int(out.dtype in HALF_DTYPES), alpha=1.0, nbatch=1, nb1=1, splitk=1)
+            for k_, v_ in kw.items():
+                setattr(q, k_, v_)
+            if int(self.L.countr_gemm_gn_rows(C.byref(q), self.code, OP_IM2ROW, OP_ROW)) == 1:
+                rows = gn_rows()
+                self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), C=out.data_ptr(), bias=bias_ptr,
+                           ldb=K, ldc=Cout, M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, out_bf16=int(out.dtype in HALF_DTYPES), gn_rows=rows.data_ptr())
+                return rows
         if sk > 1:
             part = self._shared("actsk", sk * M * Cout)
             self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), partial=part.data_ptr(), ldb=K, ldc=Cout,
                        M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, splitk=sk)
             self._op(ops, self.L.countr_splitk_finish, part.data_ptr(), out.data_ptr(), bias_ptr, sk, M, Cout, int(out.dtype in HALF_DTYPES))
-            return
+            return None
         self._gemm(ops, self.code, OP_IM2ROW, OP_ROW, A=x.data_ptr(), B=w_ohwi.data_ptr(), C=out.data_ptr(), bias=bias_ptr,
                    ldb=K, ldc=Cout, M=M, N=Cout, K=K, H=H, W=W, Cin=Cin, out_bf16=int(out.dtype in HALF_DTYPES))
+        return None
 
     def _conv_wgrad(self, ops, dy, x, wname, Bn, H, W, Cin, Cout, bias_name=None):
         bk = 64 if self.code == BF16 else 32
@@ -1131,15 +1147,19 @@ class Engine:
             hn = "decode_head%d" % i
             ci = A("hc%d" % i, (B, hs[i], hs[i], 256), T)
             si = A("hstats%d" % i, (B, 8, 2), f32)
-            self._conv_fwd(ops, hin[i], self.Wf[hn + ".0.weight"], self._pp(hn + ".0.bias"), ci, B, hs[i], hs[i], cin[i], 256)
+            # GroupNorm statistics: from the row partials the convolution's epilogue leaves where the launch runs on the lean kernels
+            # (64 bytes per pixel instead of a pass over the 512-byte pixels: 30 -> 9 us on the 192 x 192 map), else from the map
+            gnr = self._conv_fwd(ops, hin[i], self.Wf[hn + ".0.weight"], self._pp(hn + ".0.bias"), ci, B, hs[i], hs[i], cin[i], 256,
+                                 gn_rows=lambda n=B * hs[i] * hs[i]: self._shared("gn_rows", n * 16))
+            gn_fwd = (L.countr_groupnorm_relu_fwd, (ci.data_ptr(),)) if gnr is None else (L.countr_groupnorm_relu_fwd_rows, (ci.data_ptr(), gnr.data_ptr()))
             if i < 3:
-                self._op(ops, L.countr_groupnorm_relu_fwd, ci.data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"),
+                self._op(ops, gn_fwd[0], *gn_fwd[1], self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"),
                          hact_tmp.data_ptr(), None, None, None, si.data_ptr(), gn_ws.data_ptr(), B, hs[i] * hs[i], 256, 8, 1e-5, code)
                 up = A("hu%d" % i, (B, hs[i + 1], hs[i + 1], 256), T)
                 self._op(ops, L.countr_upsample2x_fwd, hact_tmp.data_ptr(), up.data_ptr(), B, hs[i], hs[i], 256, code)
                 hin.append(up)
             else:
-                self._op(ops, L.countr_groupnorm_relu_fwd, ci.data_ptr(), self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), None,
+                self._op(ops, gn_fwd[0], *gn_fwd[1], self._pp(hn + ".1.weight"), self._pp(hn + ".1.bias"), None,
                          self._pp(hn + ".3.weight"), self._pp(hn + ".3.bias"), o1.data_ptr(), si.data_ptr(), gn_ws.data_ptr(), B,
                          hs[i] * hs[i], 256, 8, 1e-5, code)
                 self._op(ops, L.countr_upsample2x_fwd, o1.data_ptr(), out.data_ptr(), B, hs[3], hs[3], 1, F32)

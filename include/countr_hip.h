@@ -48,7 +48,7 @@ int countr_init(int device);            /* selects device, checks it is gfx950-c
                                            thread-safe.  A bias-less countr_gemm / countr_conv launch on a device without it fails
                                            with a negative code and a message naming countr_init (it does not allocate lazily:
                                            no allocation inside a launch) */
-int countr_version(void);               /* ABI version, currently 8 (8: countr_transpose16 added, no layout change; 7: countr_masked_mse_amp / countr_patch_mse_amp / countr_adamw_step_amp added, no layout change; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
+int countr_version(void);               /* ABI version, currently 9 (9: countr_gemm_args grew at its end (gn_rows) + countr_groupnorm_relu_fwd_rows -- rebuild callers; 8: countr_transpose16 added, no layout change; 7: countr_masked_mse_amp / countr_patch_mse_amp / countr_adamw_step_amp added, no layout change; 6: countr_softmax_fwd_ld added, no layout change; 5: countr_step_prologue added, no layout change; countr_gemm_args grew at its end -- round 3: ln_* fields, rowsum_slabs; round 4: prefetch hint (3) -- so a caller built against an older version must be rebuilt; 4: countr_gemm_group / countr_gemm_group_tiles added, no layout change) */
 const char* countr_last_error(void);    /* thread-local message of the last failing call        */
 
 /*
@@ -108,9 +108,20 @@ typedef struct countr_gemm_args {
    * (fc2: 38.7 us in the step, 28.7 us with the panel resident: tools/bench_chain.py). */
   const void* prefetch;
   int64_t prefetch_bytes;
+  /* GroupNorm statistics from the convolution's epilogue (ABI 9; bf16 (IM2ROW, ROW) launches on the lean kernels -- maps of more than
+   * 256 output tiles --, N % 32 == 0): gn_rows[m][N / 32][2] receives {sum, sum of squares} of every 32-channel block of output row m,
+   * taken from the ROUNDED 16-bit values the launch stores (what a separate statistics pass over C would read).  The density head's
+   * Conv2d -> GroupNorm(8, 256) pairs (models_mae_cross.py:80-100): countr_groupnorm_relu_fwd_rows then reads 64 bytes per pixel
+   * instead of the 512-byte pixel itself.  A launch that would run on a kernel without this epilogue fails instead of leaving the
+   * buffer unwritten. */
+  float* gn_rows;
 } countr_gemm_args;
 
 int countr_gemm(const countr_gemm_args* a, int dtype, int modeA, int modeB, void* stream);
+
+/* 1 when countr_gemm on these arguments runs on a kernel whose epilogue writes a->gn_rows (ABI 9), else 0 -- shape, alignment and the
+ * environment's kernel selectors decide; a caller asks before it replaces its statistics pass by countr_groupnorm_relu_fwd_rows. */
+int countr_gemm_gn_rows(const countr_gemm_args* a, int dtype, int modeA, int modeB);
 
 /* Number of [M]-slabs the launch described by a (rowsum_slabs ignored) writes to rowsum_partial.  Depends on the shape and on the
  * environment switches only; callers size rowsum_partial with it and pass the value back in a->rowsum_slabs. */
@@ -179,6 +190,12 @@ long long countr_groupnorm_bwd_image_sums_offset(int B, int HW);
 int countr_groupnorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* w1,
                               const float* b1, float* out1, float* stats, float* workspace, int B, int HW,
                               int C, int G, float eps, int dtype, void* stream);
+/* The same, with the statistics pass reading rows [B*HW][8][2] -- the {sum, sum of squares} per 32-channel group that the convolution
+ * which produced x left through countr_gemm_args.gn_rows (ABI 9; 16-bit maps, G == 8) -- instead of the map: Conv2d -> GroupNorm of
+ * decode_head1..3 on the big maps (models_mae_cross.py:86-100). */
+int countr_groupnorm_relu_fwd_rows(const void* x, const float* rows, const float* gamma, const float* beta, void* y,
+                                   const float* w1, const float* b1, float* out1, float* stats, float* workspace, int B,
+                                   int HW, int C, int G, float eps, int dtype, void* stream);
 /* dy (same dtype as x) is the gradient of y, or pass dy = NULL with d1 [B,HW] fp32 + w1 for the fused head.
  * dgamma/dbeta/dw1 [256], db1 [1] fp32 (each optional). */
 int countr_groupnorm_relu_bwd(const void* x, const void* dy, const float* d1, const float* w1,

@@ -978,6 +978,90 @@ def test_g256_conv3x3_matches_fp64_and_lean(hip, monkeypatch, Bsz, H, W, Cin, Co
     assert torch.equal(outs["2"], outs["0"]), (outs["2"].double() - outs["0"].double()).abs().max().item()
 
 
+@pytest.mark.parametrize("Bsz,H,W,Cin,Cout", [(2, 96, 96, 256, 256), (1, 192, 192, 256, 256), (23, 64, 64, 128, 256), (3, 100, 100, 128, 512),
+                                              (8, 48, 48, 256, 256)])
+def test_conv3x3_groupnorm_row_partials(hip, monkeypatch, Bsz, H, W, Cin, Cout):
+    """countr_gemm_args.gn_rows (ABI 9): the 16-bit convolution kernels leave {sum, sum of squares} of every 32-channel block of every
+    ROUNDED output row -- what a GroupNorm statistics pass over the stored map would read.  Against fp64 sums of the stored map (the
+    partials are fp32 trees over 32 values: 1e-6), unchanged outputs, and -- because a row's value must not depend on the kernel, the
+    tile or the batch it was computed in -- bit for bit between the 256 x 256 kernel (incl. its split rounds: 23 images of 64 x 64),
+    the 128-row kernel alone, and a launch over the first image only; rows behind M are not written; countr_gemm_gn_rows answers the
+    selection question and a launch that falls to a kernel without the epilogue fails instead of leaving the buffer unwritten."""
+    x = _mk((Bsz, H, W, Cin), torch.bfloat16, 161)
+    w = (_mk((Cout, 3, 3, Cin), torch.float32, 162) * 0.1).to(torch.bfloat16)
+    bias = _mk((Cout,), torch.float32, 163)
+    M, K, NG = Bsz * H * W, 9 * Cin, Cout // 32
+
+    def launch(mode, m_rows, with_rows=True):
+        monkeypatch.setenv("COUNTR_G256", mode)
+        out = torch.full((m_rows, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rows = torch.full((m_rows + 4, NG, 2), float("nan"), device="cuda", dtype=torch.float32)
+        a = _lib.GemmArgs()
+        a.A, a.B, a.C, a.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr()
+        a.ldb, a.ldc = K, Cout
+        a.M, a.N, a.K = m_rows, Cout, K
+        a.H, a.W, a.Cin = H, W, Cin
+        a.out_bf16, a.alpha = 1, 1.0
+        a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+        if with_rows:
+            a.gn_rows = rows.data_ptr()
+            assert hip.countr_gemm_gn_rows(C.byref(a), 1, 2, 0) == 1
+        _lib.check(hip.countr_gemm(C.byref(a), 1, 2, 0, _stream()), "conv")
+        torch.cuda.synchronize()
+        return out, rows
+
+    out_ref, _ = launch("2", M, with_rows=False)
+    res = {}
+    for mode in ("2", "1", "0"):
+        out, rows = launch(mode, M)
+        assert torch.equal(out, out_ref), mode                       # the epilogue's extra work changes no output
+        assert torch.isnan(rows[M:]).all() and torch.isfinite(rows[:M]).all(), mode
+        v = out.double().view(M, NG, 32)
+        s1, s2 = v.sum(-1), (v * v).sum(-1)
+        assert (rows[:M, :, 0].double() - s1).abs().max().item() <= 2e-6 * s1.abs().max().item() + 1e-6, mode
+        assert (rows[:M, :, 1].double() - s2).abs().max().item() <= 2e-6 * s2.abs().max().item() + 1e-6, mode
+        res[mode] = rows[:M].clone()
+    assert torch.equal(res["2"], res["0"]) and torch.equal(res["1"], res["0"])
+    if Cout == 256:
+        # the two routes to a GroupNorm's statistics -- the pass over the stored map and the pass over these row partials -- agree BIT FOR
+        # BIT (one association tree: common.hpp::countr_gn_quad_sums, norm.hip::gn_stats_tree_kernel / gn_stats_rows_kernel): which
+        # route a batch size selects must not change a result
+        gam = _mk((256,), torch.float32, 165) * 0.2 + 1.0
+        bet = _mk((256,), torch.float32, 166) * 0.1
+        got = {}
+        for route in ("map", "rows"):
+            ws = torch.zeros(Bsz * 128 * 3 * 256 + 64 + 16 * Bsz + Bsz * 3 * 256, device="cuda")
+            stats = torch.empty((Bsz, 8, 2), device="cuda")
+            y = torch.empty_like(out_ref)
+            if route == "map":
+                _lib.check(hip.countr_groupnorm_relu_fwd(out_ref.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), None, None, None,
+                                                         stats.data_ptr(), ws.data_ptr(), Bsz, H * W, 256, 8, 1e-5, 1, _stream()), "gn")
+            else:
+                _lib.check(hip.countr_groupnorm_relu_fwd_rows(out_ref.data_ptr(), res["0"].data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(),
+                                                              None, None, None, stats.data_ptr(), ws.data_ptr(), Bsz, H * W, 256, 8, 1e-5, 1,
+                                                              _stream()), "gn rows")
+            torch.cuda.synchronize()
+            got[route] = (stats, y)
+        assert torch.equal(got["map"][0], got["rows"][0]) and torch.equal(got["map"][1], got["rows"][1])
+    if Bsz > 1 and H * W * (Cout // 128) > 256 * 128:                # the first image alone still runs on the lean kernels
+        _o, rows1 = launch("1", H * W)
+        assert torch.equal(rows1[:H * W], res["0"][:H * W])
+    # a map of fewer than 257 tiles runs on the generic kernel: the query says so, the launch refuses
+    xs = _mk((1, 24, 24, Cin), torch.bfloat16, 164)
+    outs = torch.empty((576, Cout), device="cuda", dtype=torch.bfloat16)
+    rows = torch.zeros((576, NG, 2), device="cuda")
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C, a.bias = xs.data_ptr(), w.data_ptr(), outs.data_ptr(), bias.data_ptr()
+    a.ldb, a.ldc = K, Cout
+    a.M, a.N, a.K = 576, Cout, K
+    a.H, a.W, a.Cin = 24, 24, Cin
+    a.out_bf16, a.alpha = 1, 1.0
+    a.nbatch = 1; a.nb1 = 1; a.splitk = 1
+    a.gn_rows = rows.data_ptr()
+    assert hip.countr_gemm_gn_rows(C.byref(a), 1, 2, 0) == 0
+    assert hip.countr_gemm(C.byref(a), 1, 2, 0, _stream()) != 0 and b"gn_rows" in hip.countr_last_error()
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(4608, 768, 3072, "res"), (4608, 3072, 768, "gelu"), (4608, 2304, 768, "bf16"), (1152, 512, 512, "res"), (40, 128, 128, "bf16")])
 def test_prefetch_hint_changes_nothing(hip, M, N, K, epi):
     """countr_gemm_args.prefetch (ABI 3): spare workgroups of a single-round launch read a range and leave -- the 128-row kernel, the

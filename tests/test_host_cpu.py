@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), "include/countr_hip.h declares %s but libcountr_hip.so does not export it" % s
-    assert L.countr_version() == _lib.ABI_VERSION == 8
+    assert L.countr_version() == _lib.ABI_VERSION == 9
     L16 = _lib.lib("f16")                        # the fp16 build of the same sources exports the same ABI
     assert all(hasattr(L16, s) for s in syms) and L16.countr_version() == _lib.ABI_VERSION and L16 is not L
 

@@ -126,6 +126,37 @@ def test_groupnorm_relu_fwd_bwd(hip, HW, tdt, code, tol):
     assert relerr(dw1, w1r.grad) < 2e-3 and relerr(db1, b1r.grad) < 1e-4
 
 
+@pytest.mark.parametrize("HW", [96 * 96, 48 * 48, 35 * 35, 100])
+def test_groupnorm_statistics_from_row_partials(hip, HW):
+    """countr_groupnorm_relu_fwd_rows (ABI 9): the statistics pass reads {sum, sum of squares} per pixel and 32-channel group (what a
+    convolution's epilogue leaves through countr_gemm_args.gn_rows) instead of the map -- same split partials, same finalize, same
+    apply pass: mean / rstd within 2e-6 of the map-reading pass and of fp64, outputs equal to 1 bf16 ulp."""
+    B, Cc, G = 3, 256, 8
+    x = (rnd((B, HW, Cc), 41, 1.5) + 0.3).to(torch.bfloat16).cuda()
+    g = (1 + 0.1 * rnd((Cc,), 42)).cuda(); b = (0.1 * rnd((Cc,), 43)).cuda()
+    v = x.float().view(B * HW, G, 32)
+    rows = torch.stack([v.sum(-1), (v * v).sum(-1)], dim=-1).contiguous()
+    ns = hip.countr_groupnorm_nsplit(HW)
+    outs = {}
+    for name in ("map", "rows"):
+        ws = torch.zeros(B * 128 * 3 * Cc + 64 + 16 * B + B * 3 * Cc, device="cuda")
+        stats = torch.empty((B, G, 2), device="cuda")
+        y = torch.empty_like(x)
+        if name == "map":
+            _lib.check(hip.countr_groupnorm_relu_fwd(P(x), P(g), P(b), P(y), None, None, None, P(stats), P(ws), B, HW, Cc, G, 1e-5, 1, st()))
+        else:
+            _lib.check(hip.countr_groupnorm_relu_fwd_rows(P(x), P(rows), P(g), P(b), P(y), None, None, None, P(stats), P(ws), B, HW, Cc, G, 1e-5, 1, st()))
+        torch.cuda.synchronize()
+        outs[name] = (stats.clone(), y.clone())
+    xd = x.double().view(B, HW, G, 32)
+    mean = xd.mean(dim=(1, 3)); var = xd.var(dim=(1, 3), unbiased=False)
+    ref = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], dim=-1)
+    for name in ("map", "rows"):
+        assert (outs[name][0].double().cpu() - ref.cpu()).abs().max().item() <= 3e-6 * ref.abs().max().item(), name
+    assert relerr(outs["rows"][1], outs["map"][1].double()) <= 2 ** -7
+    assert (outs["rows"][1].float() - outs["map"][1].float()).abs().mean().item() <= 1e-4
+
+
 @pytest.mark.parametrize("use_ws", [False, True])   # True: pixel-band two-kernel path where the shape qualifies
 @pytest.mark.parametrize("H,Cc,avg", [(64, 64, 0), (32, 128, 0), (16, 256, 0), (8, 512, 1), (40, 64, 0), (12, 128, 0)])   # 40, 12: odd band counts
 @pytest.mark.parametrize("tdt,code,tol", DT)
