@@ -318,6 +318,25 @@ def test_huge_patch14_factory_runs():
             assert abs(out.sum() - ref.sum()) / abs(ref.sum()) < cbar, (prec, out.sum() / 60, ref.sum() / 60)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_groupnorm_statistics_route_does_not_change_a_bit(prec, monkeypatch):
+    """The density head's GroupNorm statistics come from the convolution epilogue's row partials where the launch runs on the lean
+    kernels (48 x 48 and up at B = 8, 192 x 192 only at B = 1) and from a pass over the map elsewhere: the two routes share one
+    association tree, so the model's output with the epilogue route switched off (COUNTR_GN_ROWS=0) equals the default BIT FOR BIT,
+    and image i of a batch of 8 (three stages on the epilogue route) equals image i alone (one stage)."""
+    imgs, boxes, _gt, _mask = W.make_inputs(batch=8, shots=3, seed=21)
+    x, bx = torch.from_numpy(imgs).cuda(), torch.from_numpy(boxes).cuda()
+    outs = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("COUNTR_GN_ROWS", route)
+        m, _sd = build(prec, seed=4)
+        with torch.no_grad():
+            outs[route] = (m(x, bx, 3).clone(), m(x[5:6], bx[5:6], 3).clone())
+        del m
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    assert torch.equal(outs["1"][0][5], outs["1"][1][0])
+
+
 def test_backward_after_overwriting_forward_is_refused():
     """The engine keeps one set of activation buffers per (batch, shot_num): backward() of a forward that a later train-mode
     forward of the same shape has overwritten must raise, not return gradients of the wrong activations."""
