@@ -1111,6 +1111,8 @@ class Engine:
             d["xo"] = A(b + ".xo", (rows, Dd), T)
             self._layernorm(ops, x1, b + ".norm1", d["n1"], rows, Dd, d["m1"], d["r1"])
             self._linear(ops, d["n1"], b + ".attn.wq.weight", d["q"], rows, Dd, Dd)
+            if i == 0:
+                p.first_xattn = len(ops)      # the first launch that reads the exemplar tokens' keys / values (decoder_ops_with_exemplar_lane)
             self._op(ops, L.countr_xattn_fwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), d["xo"].data_ptr(), B, N, Sy, Dd,
                      Hd, Dd, (Dd // Hd) ** -0.5, code)
             x2 = A(b + ".x2", (rows, Dd), f32)
@@ -1365,6 +1367,24 @@ class Engine:
         self.run(p.fwd_par)
         return p.buf["out"]
 
+    def decoder_ops_with_exemplar_lane(self, p):
+        """The decoder-side forward launches of plan p (p.fwd behind the encoder) for the pipelined forms, where no encoder runs on the
+        main lane in front of them: the exemplar CNN and the blocks' wk / wv projections (a chain of ~15 launches of a few workgroups
+        each, ~150 us at 24 exemplars) go to side lane 1 and the main lane runs what does not read the exemplar tokens -- decoder_embed and
+        the first block's self-attention half, up to the query projection -- beside them; joined in front of the first cross-attention.
+        In the plain forward the chain hides beside the encoder (p.fwd_par); inline it was the head of the decoder's critical path."""
+        dec = p.fwd[p.enc_ops:]
+        ex, xi = getattr(p, "ex_range", None), getattr(p, "first_xattn", None)
+        if (ex is None or xi is None or not self.overlap_exemplar or self.code != BF16 or os.environ.get("COUNTR_PIPE_EXEMPLAR_LANE", "1") == "0"
+                or not (p.enc_ops <= ex[0] <= ex[1] <= xi)):
+            return dec
+        cached = getattr(p, "_dec_lane", None)
+        if cached is None:
+            mark = lambda *a: (None, a, None)
+            cached = p._dec_lane = ([mark("xfork"), mark("xlane", 1)] + p.fwd[ex[0]:ex[1]] + [mark("xlane", 0)] + p.fwd[p.enc_ops:ex[0]]
+                                    + p.fwd[ex[1]:xi] + [mark("xjoin")] + p.fwd[xi:])
+        return cached
+
     def forward_loaded_pipelined(self, B, shot_num, have, ahead):
         """forward_loaded with the frozen encoder pipelined across calls (inference has no trainable side at all: every forward's encoder
         is independent of every other forward).  `ahead`: the NEXT batch's windows are already in the plan's p.pipe_img -- their encoder
@@ -1382,7 +1402,7 @@ class Engine:
         if key not in cache:
             mark = lambda *a: (None, a, None)
             lane = ([mark("pfork")] + p.enc_pipe + [mark("pmain")]) if ahead else []
-            cache[key] = ([] if have else p.fwd[:p.enc_ops]) + lane + p.fwd[p.enc_ops:]
+            cache[key] = ([] if have else p.fwd[:p.enc_ops]) + lane + self.decoder_ops_with_exemplar_lane(p)
         self.run(cache[key])
         if ahead:
             self.pipe_join()

@@ -749,7 +749,7 @@ class FinetuneStep(_GraphStep):
             cache = p.__dict__.setdefault("_pipe_lists", {})
             if mode not in cache:
                 mark = lambda *a: (None, a, None)
-                dec = p.fwd[p.enc_ops:]
+                dec = self.eng.decoder_ops_with_exemplar_lane(p)
                 lane = self._pipe_part(p, 0)
                 cache[mode] = {"steady": lane + dec, "last": dec, "coldnext": p.fwd[:p.enc_ops] + lane + dec}[mode]
             return cache[mode]
