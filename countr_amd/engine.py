@@ -151,6 +151,16 @@ class _Fake:
         return torch.empty((), dtype=self.dtype).element_size()
 
 
+class _Cols:
+    """Columns [off, ...) of a row-major buffer as a launch operand (data_ptr only; works on the sizing pass's stand-ins too)."""
+
+    def __init__(self, t, off):
+        self.t, self.off = t, off
+
+    def data_ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+
 class Plan:
     """Launch lists + buffers for one (B, S, train) configuration."""
 
@@ -1076,13 +1086,24 @@ class Engine:
                          BS, sizes[i], sizes[i], chans[i], int(last), 1e-5, code, in_ws.data_ptr(), ch[i].data_ptr() if ch is not None else None, int(xh))
         # the cross-attention keys / values depend on the exemplar tokens only: all blocks' wk / wv projections (tiny GEMMs, 4 tiles each)
         # follow the tokens directly -- with exemplars that is inside the side lane that runs beside the encoder
-        kv = []
+        # wk and wv of a block lie side by side in the parameter buffer (weights and biases alike: ParamLayout): ONE product per block
+        # writes k | v as the two column halves of a [B * S, 2 Dd] buffer (countr_xattn_*'s ldkv) -- two launches less on the exemplar lane,
+        # which heads the decoder's critical path in the pipelined forms
+        kv, lay = [], self.layout
         for i in range(self.ddepth):
             b = "decoder_blocks.%d" % i
-            k_, v_ = A(b + ".k", (B * Sy, Dd), T), A(b + ".v", (B * Sy, Dd), T)
-            self._linear(ops, ytok, b + ".attn.wk.weight", k_, B * Sy, Dd, Dd)
-            self._linear(ops, ytok, b + ".attn.wv.weight", v_, B * Sy, Dd, Dd)
-            kv.append((k_, v_))
+            wk, wv = b + ".attn.wk.weight", b + ".attn.wv.weight"
+            joint = (lay.off[wv] == lay.off[wk] + Dd * Dd and lay.off[wv[:-6] + "bias"] == lay.off[wk[:-6] + "bias"] + Dd
+                     and os.environ.get("COUNTR_JOINT_KV", "1") != "0")
+            if joint:
+                kvb = A(b + ".kv", (B * Sy, 2 * Dd), T)
+                self._linear(ops, ytok, wk, kvb, B * Sy, 2 * Dd, Dd)
+                kv.append((_Cols(kvb, 0), _Cols(kvb, Dd), 2 * Dd))
+            else:
+                k_, v_ = A(b + ".k", (B * Sy, Dd), T), A(b + ".v", (B * Sy, Dd), T)
+                self._linear(ops, ytok, wk, k_, B * Sy, Dd, Dd)
+                self._linear(ops, ytok, wv, v_, B * Sy, Dd, Dd)
+                kv.append((k_, v_, Dd))
         if S > 0:
             p.ex_range = (ex0, len(ops))
         blk = []
@@ -1107,14 +1128,14 @@ class Engine:
             d["n1"] = A(b + ".n1", (rows, Dd), T)
             d["m1"], d["r1"] = A(b + ".m1", (rows,), f32), A(b + ".r1", (rows,), f32)
             d["q"] = A(b + ".q", (rows, Dd), T)
-            d["k"], d["v"] = kv[i]
+            d["k"], d["v"], d["ldkv"] = kv[i]
             d["xo"] = A(b + ".xo", (rows, Dd), T)
             self._layernorm(ops, x1, b + ".norm1", d["n1"], rows, Dd, d["m1"], d["r1"])
             self._linear(ops, d["n1"], b + ".attn.wq.weight", d["q"], rows, Dd, Dd)
             if i == 0:
                 p.first_xattn = len(ops)      # the first launch that reads the exemplar tokens' keys / values (decoder_ops_with_exemplar_lane)
             self._op(ops, L.countr_xattn_fwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), d["xo"].data_ptr(), B, N, Sy, Dd,
-                     Hd, Dd, (Dd // Hd) ** -0.5, code)
+                     Hd, d["ldkv"], (Dd // Hd) ** -0.5, code)
             x2 = A(b + ".x2", (rows, Dd), f32)
             self._linear(ops, d["xo"], b + ".attn.proj.weight", x2, rows, Dd, Dd, resid=x1)
             d["n2"] = A(b + ".n2", (rows, Dd), T)
@@ -1280,7 +1301,7 @@ class Engine:
                 self._linear_bwd(ops, g_t, d["xo"], b + ".attn.proj.weight", rows, Dd, Dd, dx=dproj_in, group=grp)
                 dk, dv, dkT, dvT = dk_b[i], dv_b[i], dkT_b[i], dvT_b[i]
                 self._op(ops, L.countr_xattn_bwd, d["q"].data_ptr(), d["k"].data_ptr(), d["v"].data_ptr(), dproj_in.data_ptr(), dq.data_ptr(),
-                         dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, Dd, (Dd // Hd) ** -0.5, code,
+                         dk.data_ptr(), dv.data_ptr(), xws.data_ptr(), B, N, Sy, Dd, Hd, d["ldkv"], (Dd // Hd) ** -0.5, code,
                          dkT.data_ptr() if dkT is not None else None, dvT.data_ptr() if dvT is not None else None)
                 if i == 0:
                     ops.append((None, ("tokready",), None))   # every block's dK / dV is final: the exemplar-token backward may start (run_backward_rest_and_tok)
