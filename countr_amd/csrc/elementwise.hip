@@ -60,25 +60,98 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
   __syncthreads();
   const int cv = threadIdx.x & 7;  // 8 output channels
   const int64_t npix = (int64_t)S * H * W;
+  const int HW = H * W;
+  // (the exemplar crops are 64 x 64: shifts instead of the two divisions per pixel where both sizes are powers of two)
+  const bool pow2 = ((W & (W - 1)) | (H & (H - 1))) == 0;
+  const int lw = 31 - __builtin_clz(W), lhw = 31 - __builtin_clz(HW);
   for (int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (int64_t)gridDim.x * 32) {
-    const int x = (int)(pix % W), y = (int)((pix / W) % H), s = (int)(pix / ((int64_t)W * H));
+    int x, y, s;
+    if (pow2) { const int p32 = (int)pix; s = p32 >> lhw; const int r = p32 & (HW - 1); y = r >> lw; x = r & (W - 1); }
+    else { x = (int)(pix % W); y = (int)((pix / W) % H); s = (int)(pix / ((int64_t)W * H)); }
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = sb[cv * 8 + e];
+    // one 64-bit base per pixel, 32-bit offsets per tap (the per-tap 64-bit products were a third of the kernel's instructions);
+    // same taps in the same order: identical values
+    const float* img = in + (int64_t)s * 3 * HW;
+    bool vy[3], vx[3];
+    int ro[3], xo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vy[k] = (unsigned)(y + k - 1) < (unsigned)H;
+      vx[k] = (unsigned)(x + k - 1) < (unsigned)W;
+      ro[k] = (y + k - 1) * W;
+      xo[k] = x + k - 1;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
           float v = 0.f;
-          if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = in[(((int64_t)s * 3 + c) * H + yy) * W + xx];
+          if (vy[ky] && vx[kx]) v = img[c * HW + ro[ky] + xo[kx]];
           const float* wr = sw + ((c * 3 + ky) * 3 + kx) * 64 + cv * 8;
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[e] += v * wr[e];
         }
     st8<T>(out + pix * 64 + cv * 8, acc);
+  }
+}
+
+// The same convolution, FOUR pixels of an image row per thread (W % 4 == 0): a tap's eight weights are read from LDS once for four
+// pixels and the 3 x 6 input window of a channel is loaded once (54 loads + 54 LDS reads per four pixels instead of 108 + 216), the
+// pixel decode is paid once -- the per-pixel kernel above is bound by exactly these instructions (560 VALU per pixel and channel
+// vector for 108 packed FMAs).  Same taps in the same order per output: identical values.  The exemplar lane heads the decoder's
+// critical path in the pipelined step, so this launch is on it.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd4_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, T* __restrict__ out, int S,
+                                                              int H, int W) {
+  __shared__ float sw[27 * 64];  // [k][co]
+  __shared__ float sb[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) { const int co = i / 27, k = i - co * 27; sw[k * 64 + co] = w[i]; }
+  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int cv = threadIdx.x & 7;  // 8 output channels
+  const int W4 = W >> 2, HW = H * W;
+  const int nq = S * H * W4;       // quads of four pixels
+  for (int q = blockIdx.x * 32 + (threadIdx.x >> 3); q < nq; q += gridDim.x * 32) {
+    const int xq = q % W4, t = q / W4, y = t % H, s = t / H;
+    const int x0 = xq * 4;
+    float acc[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[p][e] = sb[cv * 8 + e];
+    const float* img = in + (int64_t)s * 3 * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        float v[6];      // columns x0 - 1 .. x0 + 4 of this input row (zero padding outside the image)
+        const bool vy = (unsigned)yy < (unsigned)H;
+        const float* row = img + c * HW + yy * W + x0;
+        const float4 mid = vy ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = (vy && x0 > 0) ? row[-1] : 0.f;
+        v[1] = mid.x; v[2] = mid.y; v[3] = mid.z; v[4] = mid.w;
+        v[5] = (vy && x0 + 4 < W) ? row[4] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float* wr = sw + ((c * 3 + ky) * 3 + kx) * 64 + cv * 8;
+          float wv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wv[e] = wr[e];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] += v[p + kx] * wv[e];
+        }
+      }
+    T* o = out + ((int64_t)(s * H + y) * W + x0) * 64 + cv * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) st8<T>(o + p * 64, acc[p]);
   }
 }
 
@@ -666,6 +739,15 @@ extern "C" int countr_conv3x3_c3_fwd(const float* in, const float* w, const floa
   // every block first stages the 64x27 weights into LDS: few, long-lived blocks (COUNTR_C3_BLOCKS overrides the cap for tuning)
   constexpr int cap = 256;   // measured at 24 boxes: 2048 blocks 31.2 us, 512 23.6, 256 22.2, 128 38.2
   const int nb = nblocks((int64_t)S * H * W, 32, cap);
+  // four pixels per thread where rows are whole quads and 16-byte aligned (the 64 x 64 exemplar crops): COUNTR_C3_QUAD=0 keeps the per-pixel kernel
+  const char* eq = getenv("COUNTR_C3_QUAD");      // (read per call: tests compare the two kernels inside one process)
+  const int quad = eq ? atoi(eq) : 1;
+  if (quad && (W % 4) == 0 && ((uintptr_t)in & 15) == 0 && (int64_t)S * H * W < ((int64_t)1 << 30)) {
+    const int nbq = nblocks((int64_t)S * H * (W / 4), 32, cap);
+    if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_fwd4_kernel<bf16_t>, dim3(nbq), dim3(256), 0, STREAM(stream), in, w, bias, (bf16_t*)out, S, H, W);
+    else hipLaunchKernelGGL(conv3x3_c3_fwd4_kernel<float>, dim3(nbq), dim3(256), 0, STREAM(stream), in, w, bias, (float*)out, S, H, W);
+    COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_fwd");
+  }
   if (dtype == COUNTR_BF16) hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (bf16_t*)out, S, H, W);
   else hipLaunchKernelGGL(conv3x3_c3_fwd_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), in, w, bias, (float*)out, S, H, W);
   COUNTR_LAUNCH_CHECK("countr_conv3x3_c3_fwd");

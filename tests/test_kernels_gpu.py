@@ -322,6 +322,26 @@ def test_im2patch_and_c3conv(hip, tdt, code, tol):
     assert relerr(dw, wr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("S,H,W", [(24, 64, 64), (3, 20, 12), (2, 5, 8), (1, 64, 4)])
+@pytest.mark.parametrize("tdt,code,tol", DT)
+def test_first_exemplar_conv_quad_kernel_equals_the_per_pixel_kernel(hip, monkeypatch, tdt, code, tol, S, H, W):
+    """conv3x3_c3_fwd4_kernel (four pixels of a row per thread: a tap's weights read from LDS once for four pixels, the 3 x 6 input
+    window loaded once) against the per-pixel kernel (COUNTR_C3_QUAD=0): same taps in the same order per output -- IDENTICAL values --
+    and against conv2d in fp64; image borders at every quad position, rows of one quad."""
+    x = torch.rand((S, 3, H, W), generator=torch.Generator().manual_seed(61)).cuda()
+    w = rnd((64, 3, 3, 3), 62, 0.2).cuda(); bias = rnd((64,), 63, 0.1).cuda()
+    outs = {}
+    for q in ("1", "0"):
+        monkeypatch.setenv("COUNTR_C3_QUAD", q)
+        y = torch.full((S, H, W, 64), float("nan"), device="cuda", dtype=tdt)
+        _lib.check(hip.countr_conv3x3_c3_fwd(P(x), P(w), P(bias), P(y), S, H, W, code, st()))
+        torch.cuda.synchronize()
+        outs[q] = y
+    assert torch.isfinite(outs["1"].float()).all() and torch.equal(outs["1"], outs["0"])
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    assert relerr(outs["1"], ref) < tol
+
+
 @pytest.mark.parametrize("H,W", [(24, 20), (5, 7), (2, 2), (4, 2), (1, 6)])   # even sizes: 2x2-block kernels; odd: per-pixel kernels
 @pytest.mark.parametrize("Cc", [256, 1])
 @pytest.mark.parametrize("tdt,code,tol", DT)
